@@ -1,0 +1,45 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def unpack_lines(z, prefix):
+    from pyrad_amd import synthetic
+    return {f: np.ascontiguousarray(z["%s.%s" % (prefix, f)]) for f in synthetic.FIELDS}
+
+
+def rel_err(a, b, floor=0.0):
+    """max |a-b| / max(|b|, floor) over elements where the denominator is non-zero;
+    exact zeros in b must be matched by exact zeros in a."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    both_nan = np.isnan(a) & np.isnan(b)
+    den = np.maximum(np.abs(b), floor)
+    zero = den == 0
+    if zero.any():
+        assert np.all(a[zero] == 0), "non-zero where the reference is exactly zero"
+    ok = ~zero & ~both_nan
+    if not ok.any():
+        return 0.0
+    return float(np.max(np.abs(a[ok] - b[ok]) / den[ok]))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden

@@ -1,0 +1,477 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs only in the build container (it needs /root/reference, which never travels
+to the GPU box); its outputs, the ``*.npz`` files next to it, are committed and
+are what the tests read.  The files hold data only: the inputs handed to the
+reference and the numbers it returned.
+
+Offline harness.  ``pyradUtilities`` cannot be imported as is (it
+needs bs4 and fetches from hitran.org at import, ut:13, ut:1005) and
+``pyradInteractive`` runs an input() loop at import (ui:761-762), so before
+anything from /root/reference is imported:
+  1. a stand-in module object named ``pyradUtilities`` is placed in sys.modules; it
+     serves in-memory synthetic line lists / Q tables / molecule parameters in the
+     reference's own schemas (pyrad_amd.synthetic) and exposes BASE_RESOLUTION;
+  2. an empty stand-in ``pyradInteractive`` is placed in sys.modules;
+  3. matplotlib uses the Agg backend;
+  4. np.linspace is wrapped so that ``num=int(num)`` (the reference passes a float,
+     cls:402-404, 704; NumPy >= 1.18 raises TypeError, older NumPy truncated).
+The numeric modules pyradLineshape / pyradIntensity / pyradPlanck / pyradClasses
+are then the reference's own files, executed unmodified.
+
+Usage:  python tests/golden/make_golden.py        (rewrites every tests/golden/G*.npz)
+"""
+from __future__ import annotations
+
+import io
+import os
+import sys
+import types
+import contextlib
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from pyrad_amd import synthetic  # noqa: E402
+
+REFERENCE = "/root/reference"
+
+# ----------------------------------------------------------------------------
+# harness
+# ----------------------------------------------------------------------------
+_DATA = {}   # global_iso -> dict(lines=SoA, species=str)
+
+
+def _install_harness():
+    utils = types.ModuleType("pyradUtilities")
+    utils.RES_MULTIPLIER = 1
+    utils.BASE_RESOLUTION = .01 * utils.RES_MULTIPLIER
+    utils.VERSION = "1.75"
+    utils.returnXscTemperaturePressureValues = lambda: {}
+    utils.writeCurveToFile = lambda *a, **k: None
+
+    def readMolParams(iso):
+        return list(_DATA[iso]["params"])
+
+    def gatherData(iso, lo, hi):
+        return synthetic.lines_to_reference_dict(_DATA[iso]["lines"], lo, hi)
+
+    def getQData(iso):
+        return _DATA[iso]["q"]
+
+    utils.readMolParams = readMolParams
+    utils.gatherData = gatherData
+    utils.getQData = getQData
+    sys.modules["pyradUtilities"] = utils
+    sys.modules["pyradInteractive"] = types.ModuleType("pyradInteractive")
+
+    import matplotlib
+    matplotlib.use("Agg")
+
+    _linspace = np.linspace
+
+    def linspace(start, stop, num=50, *a, **k):
+        return _linspace(start, stop, int(num), *a, **k)
+
+    np.linspace = linspace
+    sys.path.insert(0, REFERENCE)
+    with contextlib.redirect_stdout(io.StringIO()):
+        import pyradLineshape, pyradIntensity, pyradPlanck, pyradClasses  # noqa: E401
+    return utils, pyradLineshape, pyradIntensity, pyradPlanck, pyradClasses
+
+
+UT, LS, INT, PL, CLS = _install_harness()
+
+
+def _reset_reference_state():
+    LS.cachedLorentz.clear(); LS.cachedGaussian.clear()
+    LS.newLorentz.clear(); LS.newGaussian.clear()
+    CLS.Layer.hasAtmosphere = False
+
+
+def register(species, lines, q=None, params=None):
+    sp = synthetic.SPECIES[species]
+    _DATA[sp["global_iso"]] = dict(
+        lines=lines, q=q if q is not None else synthetic.q_table(species),
+        params=params if params is not None else synthetic.mol_params(species))
+
+
+MOL_NAME = {"co2": "co2", "h2o": "h2o", "ch4": "ch4", "o3": "o3"}
+
+
+def run_reference_layer(cfg, want=("xsec", "abs_coef", "transmittance")):
+    """Build the reference's Layer from a config dict and pull results through the
+    reference's own getters."""
+    _reset_reference_state()
+    UT.BASE_RESOLUTION = cfg["base_resolution"]
+    out = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        layer = CLS.Layer(cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"],
+                          name=cfg.get("name", "golden"),
+                          dynamicResolution=cfg.get("dynamic_resolution", True))
+        for mol in cfg["molecules"]:
+            species = mol["species"]
+            register(species, mol["lines"])
+            depth = mol.get("isotope_depth", 1)
+            if depth == 2:
+                register(species + "_636", mol["lines2"])
+            layer.addMolecule(MOL_NAME[species], isotopeDepth=depth, **mol["conc"])
+        out["abs_coef"] = np.array(CLS.getAbsCoef(layer))
+        out["transmittance"] = np.array(CLS.getTransmittance(layer))
+        out["xsec"] = [np.array(CLS.getCrossSection(m)) for m in layer]
+        out["iso_xsec"] = [[np.array(CLS.getCrossSection(i)) for i in m] for m in layer]
+        out["mol_abs_coef"] = [np.array(CLS.getAbsCoef(m)) for m in layer]
+        out["x_axis"] = np.array(layer.xAxis)
+        out["resolution"] = layer.resolution
+        out["dfc"] = layer.distanceFromCenter
+        out["W"] = len(np.arange(0, layer.distanceFromCenter, layer.resolution))
+        out["n_work"] = len(layer.yAxis)
+        out["concentration"] = [m.concentration for m in layer]
+        if "surface_T" in cfg:
+            surf = layer.planck(cfg["surface_T"])
+            out["planck_surface"] = np.array(surf)
+            out["planck_layer"] = np.array(layer.planck(layer.T))
+            out["transmission"] = np.array(layer.transmission(surf))
+            out["band_integral"] = float(CLS.integrateSpectrum(out["transmission"], CLS.pi,
+                                                                 res=cfg["base_resolution"]))
+            out["absorbance"] = np.array(CLS.getAbsorbance(layer))
+            out["optical_depth"] = np.array(CLS.getOpticalDepth(layer))
+            out["emissivity"] = np.array(CLS.getEmissivity(layer))
+        # per-line derived quantities straight from the reference's Line properties
+        first_iso = layer[0][0]
+        out["line_nu"] = np.array([ln.wavenumber for ln in first_iso])
+        out["line_lhw"] = np.array([ln.lorentzHW for ln in first_iso])
+        out["line_ghw"] = np.array([ln.gaussianHW for ln in first_iso])
+        out["line_broadened"] = np.array([ln.broadenedLine for ln in first_iso])
+        out["line_index"] = np.array([int((ln.wavenumber - layer.rangeMin) / layer.resolution)
+                                      for ln in first_iso], dtype=np.int64)
+    UT.BASE_RESOLUTION = .01
+    return out, layer
+
+
+def pack_lines(prefix, lines):
+    return {"%s.%s" % (prefix, f): lines[f] for f in synthetic.FIELDS}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024.0))
+
+
+def cfg_scalars(cfg):
+    return dict(depth=np.float64(cfg["depth"]), T=np.int64(cfg["T"]), P=np.float64(cfg["P"]),
+                range_min=np.float64(cfg["range_min"]), range_max=np.float64(cfg["range_max"]),
+                base_resolution=np.float64(cfg["base_resolution"]),
+                dynamic_resolution=np.bool_(cfg.get("dynamic_resolution", True)))
+
+
+# ----------------------------------------------------------------------------
+# G0: function-level vectors
+# ----------------------------------------------------------------------------
+def g0():
+    rng = np.random.default_rng(100)
+    T_list = np.array([200, 250, 296, 320], dtype=np.float64)
+    E = rng.uniform(0, 5000, 64)
+    nu = rng.uniform(50, 3000, 64)
+    S = 10.0 ** rng.uniform(-28, -19, 64)
+    out = dict(T_list=T_list, E=E, nu=nu, S=S, c2=np.float64(INT.c2))
+    out["boltzmann"] = np.stack([INT.boltzmannFactors(E, t) for t in T_list])
+    out["stimulated"] = np.stack([INT.stimulatedEmissions(nu, t) for t in T_list])
+    q = 286.09 * (T_list / 296.0)
+    out["q"] = q
+    out["intensity"] = np.stack([INT.intensityFactor(S, nu, t, E, qq, 286.09) for t, qq in zip(T_list, q)])
+    # known answers quoted in SURVEY.md §8c
+    out["ka_boltzmann_1000_250"] = np.float64(INT.boltzmannFactors(1000, 250))
+    out["ka_stimulated_667_250"] = np.float64(INT.stimulatedEmissions(667, 250))
+    out["ka_intensity"] = np.float64(INT.intensityFactor(1e-20, 667, 250, 1000, 250, 286))
+    # half-widths
+    ga = rng.uniform(.05, .1, 64); gs = rng.uniform(.06, .12, 64); n = rng.uniform(.5, .8, 64)
+    out.update(ga=ga, gs=gs, n_air=n)
+    m = 43.98983 / 1000 / CLS.avo
+    out["m"] = np.float64(m)
+    out["ghw"] = np.stack([LS.gaussianHW(nu, t, m) for t in T_list])
+    out["lhw"] = np.stack([LS.lorentzHW(ga, gs, 1013.25, t, 4e-4, n) for t in T_list])
+    out["lhw_lowP"] = np.stack([LS.lorentzHW(ga, gs, 10.0, t, .01, n) for t in T_list])
+    # line shapes on arange grids, a few half-widths per regime
+    x = np.arange(0, 5.0, 0.01)
+    xf = np.arange(0, 0.05, 0.001)
+    hw_l = np.array([0.07, 0.0123, 0.5, 1e-3])
+    hw_g = np.array([7.2e-4, 1e-3, 0.02, 0.3])
+    out.update(x=x, xf=xf, hw_l=hw_l, hw_g=hw_g)
+    LS.cachedLorentz.clear(); LS.cachedGaussian.clear()
+    out["lorentz"] = np.stack([np.array(LS.lorentzLineShape(hw, x)) for hw in hw_l])
+    out["gauss"] = np.stack([np.array(LS.gaussianLineShape(hw, x)) for hw in hw_g])
+    out["gauss_fine"] = np.stack([np.array(LS.gaussianLineShape(hw, xf)) for hw in hw_g])
+    pv_g = np.array([7.2e-4, 7.2e-4, 1e-3, 0.01, 0.05])
+    pv_l = np.array([0.07, 7.2e-5, 1e-3, 0.02, 0.0006])
+    out.update(pv_g=pv_g, pv_l=pv_l)
+    out["pvoigt"] = np.stack([np.array(LS.pseudoVoigtShape(g, l, x)) for g, l in zip(pv_g, pv_l)])
+    out["pvoigt_fine"] = np.stack([np.array(LS.pseudoVoigtShape(g, l, xf)) for g, l in zip(pv_g, pv_l)])
+    LS.cachedLorentz.clear(); LS.cachedGaussian.clear(); LS.newLorentz.clear(); LS.newGaussian.clear()
+    # planck
+    pn = np.array([0.0, 1.0, 100.0, 600.0, 650.0, 700.0, 2500.0, 10000.0])
+    out["planck_n"] = pn
+    out["planck_wn"] = np.stack([PL.planckWavenumber(pn, t) for t in (200, 288, 296, 320)])
+    hz = np.array([1e11, 1e12, 2e13, 1e14])
+    lam = np.array([0.5, 4.0, 10.0, 15.0, 100.0])
+    out.update(planck_hz_x=hz, planck_lam_x=lam)
+    out["planck_hz"] = np.stack([PL.planckHz(hz, t) for t in (200.0, 288.0)])
+    out["planck_lam"] = np.stack([PL.planckWavelength(lam, t) for t in (200.0, 288.0)])
+    # the single CO2-like line of SURVEY §8c
+    one = {k: np.array([v]) for k, v in dict(nu=650.003, sw=1e-20, a=1.0, elower=1000.0, gamma_air=.07,
+                                             gamma_self=.09, delta_air=-.002, n_air=.7).items()}
+    cfg = dict(depth=10.0, T=296, P=1013.25, range_min=600, range_max=700, base_resolution=.01,
+               dynamic_resolution=True, molecules=[dict(species="co2", conc=dict(ppm=400), lines=one)])
+    ref, _ = run_reference_layer(cfg)
+    out.update({"one." + k: v for k, v in pack_lines("lines", one).items()})
+    out["one.xsec"] = ref["xsec"][0]
+    out["one.lhw"] = ref["line_lhw"]; out["one.ghw"] = ref["line_ghw"]
+    out["one.broadened"] = ref["line_broadened"]
+    # conversions / concentration setters (cls:121-156, 543-560)
+    layer = CLS.Layer(1, 296, 1013.25, 600, 601, name="x")
+    with contextlib.redirect_stdout(io.StringIO()):
+        register("co2", one)
+        mol = layer.addMolecule("co2", ppm=1)
+        conc = []
+        for kind, v in (("ppm", 400.0), ("ppb", 1.0), ("ppb", 1800.0), ("%", 1.0), ("concentration", 0.0004)):
+            {"ppm": mol.setPPM, "ppb": mol.setPPB, "%": mol.setPercentage,
+             "concentration": mol.setConcentration}[kind](v)
+            conc.append(mol.concentration)
+    out["conc_values"] = np.array(conc)
+    out["convert"] = np.array([CLS.convertLength(2.0, "m"), CLS.convertLength(2.0, "ft"), CLS.convertLength(2.0, "in"),
+                               CLS.convertPressure(2.0, "atm"), CLS.convertPressure(2.0, "bar"),
+                               CLS.convertPressure(2.0, "pa"), CLS.convertRange(15.0, "um"),
+                               CLS.convertTemperature(15.0, "C"), CLS.convertTemperature(59.0, "F")])
+    save("G0_functions", **out)
+
+
+# ----------------------------------------------------------------------------
+# G1: C1-shaped gas cell at two temperatures
+# ----------------------------------------------------------------------------
+def g1():
+    cfg = synthetic.config_c1(n_lines=2000)
+    arrays = dict(cfg_scalars(cfg))
+    arrays.update(pack_lines("lines", cfg["molecules"][0]["lines"]))
+    arrays["conc_ppm"] = np.float64(400)
+    for T in (296, 250):
+        c = dict(cfg, T=T, surface_T=288)
+        ref, _ = run_reference_layer(c)
+        p = "T%d." % T
+        arrays[p + "xsec"] = ref["xsec"][0]
+        arrays[p + "abs_coef"] = ref["abs_coef"]
+        arrays[p + "transmittance"] = ref["transmittance"]
+        arrays[p + "transmission"] = ref["transmission"]
+        arrays[p + "band_integral"] = np.float64(ref["band_integral"])
+        arrays[p + "line_index"] = ref["line_index"]
+        arrays[p + "line_lhw"] = ref["line_lhw"]
+        arrays[p + "line_ghw"] = ref["line_ghw"]
+        if T == 296:
+            arrays["x_axis"] = ref["x_axis"]
+            arrays["absorbance"] = ref["absorbance"]
+            arrays["optical_depth"] = ref["optical_depth"]
+            arrays["planck_surface"] = ref["planck_surface"]
+            arrays["W"] = np.int64(ref["W"])
+    save("G1_c1_cell", **arrays)
+
+
+# ----------------------------------------------------------------------------
+# G2: edge lines (index truncation, clipped wings, rounding-decided indices)
+# ----------------------------------------------------------------------------
+def g2():
+    rmin, rmax = 600, 700
+    nus = np.array([rmin - 4.5, rmin - 0.015, rmin - 0.005, 600.07, 600.29, 600.3, 612.345678,
+                    650.0, 699.99, rmax - 0.001, 699.995, rmax + 0.004, rmax + 0.011, rmax + 4.9])
+    n = len(nus)
+    rng = np.random.default_rng(102)
+    lines = dict(nu=nus, sw=10.0 ** rng.uniform(-22, -19, n), a=np.ones(n),
+                 elower=rng.uniform(0, 3000, n), gamma_air=rng.uniform(.05, .1, n),
+                 gamma_self=rng.uniform(.06, .12, n), delta_air=rng.uniform(-.01, 0, n),
+                 n_air=rng.uniform(.5, .8, n))
+    cfg = dict(depth=10.0, T=296, P=1013.25, range_min=rmin, range_max=rmax, base_resolution=.01,
+               dynamic_resolution=True, molecules=[dict(species="co2", conc=dict(ppm=400), lines=lines)])
+    arrays = dict(cfg_scalars(cfg)); arrays.update(pack_lines("lines", lines))
+    ref, _ = run_reference_layer(cfg)
+    arrays["xsec"] = ref["xsec"][0]; arrays["abs_coef"] = ref["abs_coef"]
+    arrays["line_index"] = ref["line_index"]
+    # each edge line alone, so a wrong clip cannot hide under a neighbour
+    singles = []
+    for i in range(n):
+        one = {k: v[i:i + 1] for k, v in lines.items()}
+        r, _ = run_reference_layer(dict(cfg, molecules=[dict(species="co2", conc=dict(ppm=400), lines=one)]))
+        singles.append(r["xsec"][0])
+    arrays["single_xsec"] = np.stack(singles)
+    save("G2_edges", **arrays)
+
+
+# ----------------------------------------------------------------------------
+# G3: pressure ladder (W from 1 to 987, including the regrid path)
+# ----------------------------------------------------------------------------
+def g3():
+    arrays = {}
+    Ps = np.array([1013.25, 500.0, 101.325, 10.1325, 1.0, 10132.5, 20000.0])
+    arrays["P_list"] = Ps
+    rmin, rmax = 640, 660
+    for j, P in enumerate(Ps):
+        lo, hi = synthetic.layer_window(P, rmin, rmax)
+        lines = synthetic.make_lines(300 + j, 120, lo, hi)
+        cfg = dict(depth=100.0, T=260, P=float(P), range_min=rmin, range_max=rmax, base_resolution=.01,
+                   dynamic_resolution=True, surface_T=288,
+                   molecules=[dict(species="co2", conc=dict(ppm=400), lines=lines)])
+        ref, _ = run_reference_layer(cfg)
+        p = "P%d." % j
+        arrays.update(pack_lines(p + "lines", lines))
+        arrays[p + "xsec"] = ref["xsec"][0]
+        arrays[p + "abs_coef"] = ref["abs_coef"]
+        arrays[p + "transmission"] = ref["transmission"]
+        arrays[p + "resolution"] = np.float64(ref["resolution"])
+        arrays[p + "W"] = np.int64(ref["W"])
+        arrays[p + "n_work"] = np.int64(ref["n_work"])
+    arrays.update(depth=np.float64(100.0), T=np.int64(260), range_min=np.float64(rmin), range_max=np.float64(rmax),
+                  base_resolution=np.float64(.01))
+    save("G3_pressure_ladder", **arrays)
+
+
+# ----------------------------------------------------------------------------
+# G4: regimes (forced Lorentz, Voigt, Gaussian)
+# ----------------------------------------------------------------------------
+def g4():
+    arrays = {}
+    rmin, rmax = 645, 655
+    # (a) 1 atm: gamma chosen so ratios straddle 100 -> Lorentz and Voigt both live
+    lo, hi = synthetic.layer_window(1013.25, rmin, rmax)
+    lines = synthetic.make_lines(400, 200, lo, hi)
+    lines["gamma_air"] = np.linspace(0.04, 0.12, 200)
+    cfg = dict(depth=10.0, T=296, P=1013.25, range_min=rmin, range_max=rmax, base_resolution=.01,
+               dynamic_resolution=True, molecules=[dict(species="co2", conc=dict(ppm=400), lines=lines)])
+    ref, _ = run_reference_layer(cfg)
+    arrays.update(pack_lines("a.lines", lines)); arrays["a.xsec"] = ref["xsec"][0]
+    arrays["a.ratio"] = ref["line_lhw"] / ref["line_ghw"]
+    # (b) fine base grid at low pressure: Gaussian and Voigt lines with W > 1
+    #     BASE = 1e-5, P = 0.05 mbar -> dfc = 2.47e-4, W = 25; gamma spans both sides of ratio .01
+    rmin2, rmax2 = 650.0, 650.05
+    P = 0.05
+    lo, hi = synthetic.layer_window(P, rmin2, rmax2)
+    lines_b = synthetic.make_lines(401, 60, lo, hi, decimals=7)
+    lines_b["gamma_air"] = np.linspace(0.02, 0.5, 60)
+    cfg_b = dict(depth=1000.0, T=220, P=P, range_min=rmin2, range_max=rmax2, base_resolution=1e-5,
+                 dynamic_resolution=False, molecules=[dict(species="co2", conc=dict(ppm=400), lines=lines_b)])
+    ref_b, _ = run_reference_layer(cfg_b)
+    arrays.update(pack_lines("b.lines", lines_b)); arrays["b.xsec"] = ref_b["xsec"][0]
+    arrays["b.ratio"] = ref_b["line_lhw"] / ref_b["line_ghw"]
+    arrays["b.W"] = np.int64(ref_b["W"])
+    arrays["b.abs_coef"] = ref_b["abs_coef"]
+    # (c) the same grid at 2 mbar: Voigt with a live Gaussian core and W = 987
+    P = 2.0
+    lo, hi = synthetic.layer_window(P, rmin2, rmax2)
+    lines_c = synthetic.make_lines(402, 40, lo, hi, decimals=7)
+    cfg_c = dict(depth=1000.0, T=220, P=P, range_min=rmin2, range_max=rmax2, base_resolution=1e-5,
+                 dynamic_resolution=False, molecules=[dict(species="co2", conc=dict(ppm=400), lines=lines_c)])
+    ref_c, _ = run_reference_layer(cfg_c)
+    arrays.update(pack_lines("c.lines", lines_c)); arrays["c.xsec"] = ref_c["xsec"][0]
+    arrays["c.ratio"] = ref_c["line_lhw"] / ref_c["line_ghw"]
+    arrays["c.W"] = np.int64(ref_c["W"])
+    save("G4_regimes", **arrays)
+
+
+# ----------------------------------------------------------------------------
+# G5: native 0.001 grid (W = 5000) and the dynamic-resolution interp path
+# ----------------------------------------------------------------------------
+def g5():
+    arrays = {}
+    rmin, rmax = 650, 660
+    lo, hi = synthetic.layer_window(1013.25, rmin, rmax)
+    lines = synthetic.make_lines(500, 150, lo, hi)
+    arrays.update(pack_lines("lines", lines))
+    for tag, dyn in (("native", False), ("dynamic", True)):
+        cfg = dict(depth=10.0, T=296, P=1013.25, range_min=rmin, range_max=rmax, base_resolution=.001,
+                   dynamic_resolution=dyn, surface_T=288,
+                   molecules=[dict(species="co2", conc=dict(ppm=400), lines=lines)])
+        ref, _ = run_reference_layer(cfg)
+        arrays[tag + ".xsec"] = ref["xsec"][0]
+        arrays[tag + ".abs_coef"] = ref["abs_coef"]
+        arrays[tag + ".transmission"] = ref["transmission"]
+        arrays[tag + ".W"] = np.int64(ref["W"])
+        arrays[tag + ".n_work"] = np.int64(ref["n_work"])
+        arrays[tag + ".resolution"] = np.float64(ref["resolution"])
+        arrays[tag + ".x_axis"] = ref["x_axis"]
+    save("G5_native_0p001", **arrays)
+
+
+# ----------------------------------------------------------------------------
+# G6: composition (2 isotopologues, 3 molecules, % / ppm / ppb)
+# ----------------------------------------------------------------------------
+def g6():
+    arrays = {}
+    rmin, rmax = 1000, 1040
+    lo, hi = synthetic.layer_window(800.0, rmin, rmax)
+    l_co2 = synthetic.make_lines(600, 300, lo, hi)
+    l_co2b = synthetic.make_lines(601, 150, lo, hi)
+    l_h2o = synthetic.make_lines(602, 250, lo, hi)
+    l_ch4 = synthetic.make_lines(603, 200, lo, hi)
+    cfg = dict(depth=250.0, T=275, P=800.0, range_min=rmin, range_max=rmax, base_resolution=.01,
+               dynamic_resolution=True, surface_T=290,
+               molecules=[dict(species="co2", conc=dict(ppm=400), lines=l_co2, lines2=l_co2b, isotope_depth=2),
+                          dict(species="h2o", conc={"%": 1.5}, lines=l_h2o),
+                          dict(species="ch4", conc=dict(ppb=1800), lines=l_ch4)])
+    ref, _ = run_reference_layer(cfg)
+    arrays.update(cfg_scalars(cfg))
+    arrays.update(pack_lines("co2.lines", l_co2)); arrays.update(pack_lines("co2_636.lines", l_co2b))
+    arrays.update(pack_lines("h2o.lines", l_h2o)); arrays.update(pack_lines("ch4.lines", l_ch4))
+    arrays["concentration"] = np.array(ref["concentration"])
+    for i, name in enumerate(("co2", "h2o", "ch4")):
+        arrays[name + ".xsec"] = ref["xsec"][i]
+        arrays[name + ".abs_coef"] = ref["mol_abs_coef"][i]
+    arrays["co2.iso0.xsec"] = ref["iso_xsec"][0][0]
+    arrays["co2.iso1.xsec"] = ref["iso_xsec"][0][1]
+    arrays["abs_coef"] = ref["abs_coef"]; arrays["transmittance"] = ref["transmittance"]
+    arrays["transmission"] = ref["transmission"]; arrays["band_integral"] = np.float64(ref["band_integral"])
+    save("G6_composition", **arrays)
+
+
+# ----------------------------------------------------------------------------
+# G7: 3-layer column fold of Layer.transmission (cls:784-787)
+# ----------------------------------------------------------------------------
+def g7():
+    arrays = {}
+    rmin, rmax = 660, 680
+    specs = [(20000.0, 288, 1013.25), (50000.0, 262, 600.0), (120000.0, 231, 150.0)]   # depth cm, T, P
+    lo, hi = synthetic.layer_window(1013.25, rmin, rmax)
+    l_co2 = synthetic.make_lines(700, 260, lo, hi)
+    l_h2o = synthetic.make_lines(701, 180, lo, hi)
+    arrays.update(pack_lines("co2.lines", l_co2)); arrays.update(pack_lines("h2o.lines", l_h2o))
+    arrays["layer_depth"] = np.array([s[0] for s in specs]); arrays["layer_T"] = np.array([s[1] for s in specs])
+    arrays["layer_P"] = np.array([s[2] for s in specs])
+    arrays["h2o_perc"] = np.array([1.0, 0.2, 0.01])
+    arrays.update(range_min=np.float64(rmin), range_max=np.float64(rmax), base_resolution=np.float64(.01),
+                  surface_T=np.int64(290))
+    spectrum = None
+    for i, (depth, T, P) in enumerate(specs):
+        cfg = dict(depth=depth, T=T, P=P, range_min=rmin, range_max=rmax, base_resolution=.01,
+                   dynamic_resolution=True,
+                   molecules=[dict(species="co2", conc=dict(ppm=400), lines=l_co2),
+                              dict(species="h2o", conc=dict(percentage=float(arrays["h2o_perc"][i])), lines=l_h2o)])
+        ref, layer = run_reference_layer(cfg)
+        if spectrum is None:
+            spectrum = layer.planck(290)
+            arrays["surface"] = np.array(spectrum)
+        spectrum = layer.transmission(spectrum)
+        arrays["L%d.transmittance" % i] = ref["transmittance"]
+        arrays["L%d.abs_coef" % i] = ref["abs_coef"]
+        arrays["L%d.spectrum" % i] = np.array(spectrum)
+    arrays["toa_band_integral"] = np.float64(CLS.integrateSpectrum(spectrum, CLS.pi, res=.01))
+    save("G7_column", **arrays)
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REFERENCE):
+        sys.exit("needs /root/reference (build container only)")
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    for name in which:
+        globals()[name]()
