@@ -1,0 +1,209 @@
+/*
+ * pyrad_hip.h — C ABI of the MI355X (gfx950) line-by-line absorption engine.
+ *
+ * The reference (bschrag620/PyRad) has no FFI: its seam is a Python method contract,
+ * Isotope.createCrossSection() (pyradClasses.py:361-407) plus the property chain
+ * absCoef -> transmittance -> transmission (pyradClasses.py:322-340, 581-606, 707-732,
+ * 784-787) and pyradPlanck.planckWavenumber (pyradPlanck.py:38-44).  This header is the
+ * C boundary a maintainer binds with ctypes in place of those bodies.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every function returns int
+ *     (LBL_OK or a negative lbl_status); no C++ exception crosses the boundary.
+ *   - lbl_last_error(ctx) returns a NUL-terminated description of the last failure
+ *     on that context (ctx == NULL: last failure of a ctx-less call on this thread).
+ *   - Host pointers are C-contiguous float64 arrays owned by the caller; the library
+ *     never keeps a host pointer past return.
+ *   - Device objects (lbl_lines, lbl_buffer, lbl_comm) belong to the context that made
+ *     them and must be destroyed before it.
+ *   - A context is bound to one HIP device and one HIP stream and is NOT thread-safe.
+ *     "_dev" entry points only enqueue work on the context stream; lbl_sync() or any
+ *     download drains it.  Host-pointer entry points are synchronous.
+ *   - All arithmetic is IEEE fp64 (the reference is NumPy float64); grid indices int64.
+ */
+#ifndef PYRAD_HIP_H
+#define PYRAD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBL_ABI_VERSION 1
+
+typedef enum lbl_status {
+    LBL_OK = 0,
+    LBL_ERR_BAD_ARG = -1,     /* NULL pointer, negative size, unsorted lines, ... */
+    LBL_ERR_NO_DEVICE = -2,   /* no HIP device / device index out of range */
+    LBL_ERR_HIP = -3,         /* a HIP runtime call failed */
+    LBL_ERR_RCCL = -4,        /* an RCCL call failed */
+    LBL_ERR_OOM = -5,         /* device allocation failed */
+    LBL_ERR_STATE = -6        /* object belongs to another context, comm not initialised, ... */
+} lbl_status;
+
+typedef struct lbl_ctx lbl_ctx;
+typedef struct lbl_lines lbl_lines;     /* device-resident HITRAN line list (SoA, sorted by nu) */
+typedef struct lbl_buffer lbl_buffer;   /* device-resident float64 array */
+typedef struct lbl_comm lbl_comm;       /* RCCL communicator, one rank per process */
+
+/* Per-isotopologue scalars read by Isotope.createCrossSection (pyradClasses.py:361-407):
+ * layer.T, layer.P (mbar), molecule.concentration (volume fraction, the q of
+ * Line.lorentzHW, pyradClasses.py:258), isotope.molmass (g/mol, pyradClasses.py:296),
+ * isotope.q[layer.T] and isotope.q296 (pyradClasses.py:389). */
+typedef struct lbl_iso_params {
+    double T;
+    double P;
+    double q_frac;
+    double molmass;
+    double Q_T;
+    double Q_296;
+} lbl_iso_params;
+
+/* Layer grid (pyradClasses.py:648-676, 698-705).  The host computes these with the
+ * reference's own expressions so that the integer truncations agree:
+ *   resolution      = layer.resolution                        (pyradClasses.py:659-662)
+ *   n_work          = int((rangeMax-rangeMin)/resolution)      (pyradClasses.py:700)
+ *   n_base          = int((rangeMax-rangeMin)/BASE_RESOLUTION) (pyradClasses.py:672)
+ *   window          = len(arange(0, distanceFromCenter, resolution))  (pyradClasses.py:377)
+ * Wing support of a line is centre +- (window-2) grid points (pyradClasses.py:394). */
+typedef struct lbl_grid {
+    double range_min;
+    double range_max;
+    double resolution;
+    double base_resolution;
+    int64_t n_work;
+    int64_t n_base;
+    int64_t window;
+    /* Contiguous shard of the WORK grid this call computes: points
+     * [shard_first, shard_first + shard_count).  shard_count == 0 means the whole grid.
+     * Output buffers stay globally indexed (n_base long) so that the shards of all ranks
+     * can be all-gathered in place.  A sharded call requires resolution == base_resolution. */
+    int64_t shard_first;
+    int64_t shard_count;
+} lbl_grid;
+
+/* ---- library / context ------------------------------------------------------------- */
+int lbl_abi_version(void);
+int lbl_device_count(int* count);
+int lbl_ctx_create(int device, lbl_ctx** out);
+int lbl_ctx_destroy(lbl_ctx* ctx);
+const char* lbl_last_error(const lbl_ctx* ctx);
+int lbl_sync(lbl_ctx* ctx);
+/* Native hipStream_t of the context (as void*) so a host can order foreign work on it. */
+int lbl_ctx_stream(lbl_ctx* ctx, void** stream);
+/* Name of the device ("gfx950..."), CU count, HBM bytes. */
+int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
+
+/* Tuning knobs for A/B parity and benchmarking (no reference counterpart):
+ *   "accum_variant"          0 IEEE divide + exp per pair | 1 running fraction | 2 (default) + Gaussian recurrence
+ *   "accum_points_per_lane"  0 (auto) | 1 | 2 | 4 | 8 */
+int lbl_set_option(lbl_ctx* ctx, const char* key, int value);
+
+/* ---- device buffers (float64) ------------------------------------------------------- */
+int lbl_buffer_create(lbl_ctx* ctx, int64_t n, lbl_buffer** out);
+int lbl_buffer_destroy(lbl_buffer* buf);
+int lbl_buffer_size(const lbl_buffer* buf, int64_t* n);
+int lbl_buffer_upload(lbl_buffer* buf, const double* host, int64_t n, int64_t dst_offset);
+int lbl_buffer_download(lbl_buffer* buf, double* host, int64_t n, int64_t src_offset);
+int lbl_buffer_fill(lbl_buffer* buf, double value);                    /* async */
+int lbl_buffer_devptr(lbl_buffer* buf, void** devptr);                 /* for RCCL / interop */
+
+/* ---- line lists ------------------------------------------------------------------- */
+/* Upload the seven per-line HITRAN fields Line carries and uses (pyradClasses.py:237-263;
+ * Einstein A is carried by the reference but never read).  nu must be non-decreasing. */
+int lbl_lines_create(lbl_ctx* ctx, const double* nu, const double* sw, const double* elower,
+                     const double* gamma_air, const double* gamma_self, const double* n_air,
+                     const double* delta_air, int64_t n_lines, lbl_lines** out);
+int lbl_lines_destroy(lbl_lines* lines);
+int lbl_lines_count(const lbl_lines* lines, int64_t* n);
+
+/* ---- the hot path: Isotope.createCrossSection (pyradClasses.py:361-407) ----------- */
+/* One-shot, host in / host out: per-line half-widths (pyradClasses.py:252-263), regime
+ * select (pyradClasses.py:378-387), profile (pyradLineshape.py:39, 52, 58-76), intensity
+ * (pyradIntensity.py:30-32), centre index (pyradClasses.py:390), accumulate
+ * (pyradClasses.py:392-400) and regrid to the base grid (pyradClasses.py:401-405).
+ * xsec_out has n_base elements (cm^2/molecule); regime_counts = {gaussian, lorentz, voigt}
+ * as printed at pyradClasses.py:406 (may be NULL). */
+int lbl_xsec_accumulate(lbl_ctx* ctx, const double* nu, const double* sw, const double* elower,
+                        const double* gamma_air, const double* gamma_self, const double* n_air,
+                        const double* delta_air, int64_t n_lines, const lbl_iso_params* iso,
+                        const lbl_grid* grid, double* xsec_out, int64_t regime_counts[3]);
+
+/* Device-resident, asynchronous, batched form: job j accumulates lines[j] under iso[j] /
+ * grid[j] into out[j] (n_base doubles).  All jobs run in one launch sequence so that
+ * isotopologues, molecules and layers fill the chip together. */
+int lbl_xsec_accumulate_dev(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
+                            const lbl_iso_params* iso, const lbl_grid* grid,
+                            lbl_buffer* const* out);
+/* Regime counters of the most recent lbl_xsec_accumulate_dev (drains the stream):
+ * counts[3*j + {0,1,2}] = {gaussian, lorentz, voigt} of job j. */
+int lbl_last_regime_counts(lbl_ctx* ctx, int n_jobs, int64_t* counts);
+/* Debug / parity aid: per-line centre index (pyradClasses.py:390), Lorentz and Doppler
+ * half-widths (pyradClasses.py:256-263) and corrected intensity (pyradIntensity.py:30-32)
+ * as the device computed them.  Any output may be NULL. */
+int lbl_line_quantities(lbl_ctx* ctx, lbl_lines* lines, const lbl_iso_params* iso,
+                        const lbl_grid* grid, int64_t* index, double* lorentz_hw,
+                        double* gauss_hw, double* intensity, int32_t* regime);
+
+/* ---- fused layer sweep (pyradClasses.py:566-571, 581-587, 707-716, 784-787; pyradPlanck.py:38-44)
+ * For every base-grid point j:
+ *   xs_m   = sum of the isotopologue cross sections of molecule m        (pyradClasses.py:566-571)
+ *   k      = sum_m xs_m * conc[m] * P / 1e4 / kB / T                      (pyradClasses.py:583, 707-712)
+ *   trans  = exp(-k * depth)                                             (pyradClasses.py:716)
+ *   I_out  = trans * I_in + (1 - trans) * B(nu_j, T)                      (pyradClasses.py:784-787)
+ * nu_j is the reference's xAxis = linspace(range_min, range_max, n, endpoint=True)
+ * (pyradClasses.py:702-705).  iso_mol[i] (non-decreasing, 0-based) maps isotopologue i to
+ * its molecule.  I_in == NULL with surface_T > 0 uses I_in = B(nu_j, surface_T)
+ * (pyradInteractive.py:400).  Any of abs_coef / trans / I_out may be NULL.
+ * Only points [first, first+count) are swept (count == 0: all n); buffers are indexed by j. */
+int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* xsec, const int32_t* iso_mol,
+                        int n_mol, const double* conc, double P, double T, double depth,
+                        double range_min, double range_max, int64_t n,
+                        int64_t first, int64_t count,
+                        lbl_buffer* I_in, double surface_T,
+                        lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out);
+
+/* Column fold of Layer.transmission over layers bottom to top (pyradClasses.py:784-787):
+ *   I <- trans_l * I + (1 - trans_l) * B(nu_j, layer_T[l]),  I_0 = I_in or B(nu_j, surface_T). */
+int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const* trans, const double* layer_T,
+                         double range_min, double range_max, int64_t n,
+                         int64_t first, int64_t count,
+                         lbl_buffer* I_in, double surface_T, lbl_buffer* I_out);
+
+/* Elementwise optical properties of a transmittance array (pyradClasses.py:73-76, 330-340,
+ * 596-606, 718-732): kind 0 emissivity/emittance = 1 - T; 1 absorbance = log10(1/T);
+ * 2 optical depth = -ln T. */
+int lbl_optical_dev(lbl_ctx* ctx, lbl_buffer* trans, int64_t n, int kind, lbl_buffer* out);
+
+/* Planck radiance on the layer axis (pyradPlanck.py:38-44 via pyradClasses.py:781-782). */
+int lbl_planck_dev(lbl_ctx* ctx, double range_min, double range_max, int64_t n, double T,
+                   lbl_buffer* out);
+
+/* integrateSpectrum (pyradClasses.py:26-29): sum(nan_to_num(y)) * unit_angle * res.
+ * Deterministic fixed-tree reduction; synchronous (returns the scalar). */
+int lbl_band_integral(lbl_ctx* ctx, lbl_buffer* spectrum, int64_t n, double unit_angle, double res,
+                      double* result);
+
+/* Line survey histogram, Isotope.createLineSurvey (pyradClasses.py:409-428): raw S summed
+ * into the bin of each line's centre index; out has n_base elements. */
+int lbl_line_survey_dev(lbl_ctx* ctx, lbl_lines* lines, const lbl_grid* grid, lbl_buffer* out);
+
+/* ---- multi-GPU: one process per GPU, grid sharded by contiguous range --------------- */
+#define LBL_UNIQUE_ID_BYTES 128
+/* Rank 0 calls lbl_comm_unique_id and hands the 128 bytes to every rank out of band
+ * (file, env, torch.distributed store, MPI ...); then every rank calls lbl_comm_create. */
+int lbl_comm_unique_id(char id[LBL_UNIQUE_ID_BYTES]);
+int lbl_comm_create(lbl_ctx* ctx, const char id[LBL_UNIQUE_ID_BYTES], int world_size, int rank,
+                    lbl_comm** out);
+int lbl_comm_destroy(lbl_comm* comm);
+/* The single RCCL all-gather of the path: every rank contributes count doubles starting at
+ * send_offset of `send`, and receives world_size*count doubles into `recv` (rank order).
+ * Enqueued on the context stream (send may alias recv at its own slot: in-place). */
+int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count,
+                      lbl_buffer* recv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYRAD_HIP_H */

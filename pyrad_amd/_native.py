@@ -1,0 +1,389 @@
+"""ctypes binding of ``libpyrad_hip.so`` (the C ABI in ``include/pyrad_hip.h``).
+
+No PyTorch, no Triton: the Python host talks to the HIP kernels through plain
+pointers and sizes.  If the shared library is missing or cannot be loaded this module
+raises — there is deliberately no CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpyrad_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+LBL_OK = 0
+ERR_NAMES = {0: "LBL_OK", -1: "LBL_ERR_BAD_ARG", -2: "LBL_ERR_NO_DEVICE", -3: "LBL_ERR_HIP",
+             -4: "LBL_ERR_RCCL", -5: "LBL_ERR_OOM", -6: "LBL_ERR_STATE"}
+UNIQUE_ID_BYTES = 128
+
+
+class LblError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "LBL_ERR_?"), code, message))
+        self.code = code
+
+
+class NoDeviceError(LblError):
+    pass
+
+
+class IsoParams(C.Structure):
+    """lbl_iso_params"""
+    _fields_ = [("T", C.c_double), ("P", C.c_double), ("q_frac", C.c_double),
+                ("molmass", C.c_double), ("Q_T", C.c_double), ("Q_296", C.c_double)]
+
+
+class Grid(C.Structure):
+    """lbl_grid"""
+    _fields_ = [("range_min", C.c_double), ("range_max", C.c_double), ("resolution", C.c_double),
+                ("base_resolution", C.c_double), ("n_work", C.c_int64), ("n_base", C.c_int64),
+                ("window", C.c_int64), ("shard_first", C.c_int64), ("shard_count", C.c_int64)]
+
+
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes): every symbol include/pyrad_hip.h declares
+SIGNATURES = {
+    "lbl_abi_version": (C.c_int, []),
+    "lbl_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "lbl_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "lbl_ctx_destroy": (C.c_int, [_P]),
+    "lbl_last_error": (C.c_char_p, [_P]),
+    "lbl_sync": (C.c_int, [_P]),
+    "lbl_ctx_stream": (C.c_int, [_P, C.POINTER(_P)]),
+    "lbl_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "lbl_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "lbl_buffer_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
+    "lbl_buffer_destroy": (C.c_int, [_P]),
+    "lbl_buffer_size": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "lbl_buffer_upload": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    "lbl_buffer_download": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    "lbl_buffer_fill": (C.c_int, [_P, C.c_double]),
+    "lbl_buffer_devptr": (C.c_int, [_P, C.POINTER(_P)]),
+    "lbl_lines_create": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(_P)]),
+    "lbl_lines_destroy": (C.c_int, [_P]),
+    "lbl_lines_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "lbl_xsec_accumulate": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(IsoParams),
+                                      C.POINTER(Grid), _P, C.POINTER(C.c_int64)]),
+    "lbl_xsec_accumulate_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(IsoParams), C.POINTER(Grid),
+                                          C.POINTER(_P)]),
+    "lbl_last_regime_counts": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
+    "lbl_line_quantities": (C.c_int, [_P, _P, C.POINTER(IsoParams), C.POINTER(Grid), _P, _P, _P, _P, _P]),
+    "lbl_layer_sweep_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int, _D,
+                                      C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
+                                      C.c_int64, C.c_int64, _P, C.c_double, _P, _P, _P]),
+    "lbl_column_sweep_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), _D, C.c_double, C.c_double, C.c_int64,
+                                       C.c_int64, C.c_int64, _P, C.c_double, _P]),
+    "lbl_optical_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "lbl_planck_dev": (C.c_int, [_P, C.c_double, C.c_double, C.c_int64, C.c_double, _P]),
+    "lbl_band_integral": (C.c_int, [_P, _P, C.c_int64, C.c_double, C.c_double, _D]),
+    "lbl_line_survey_dev": (C.c_int, [_P, _P, C.POINTER(Grid), _P]),
+    "lbl_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "lbl_comm_create": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
+    "lbl_comm_destroy": (C.c_int, [_P]),
+    "lbl_allgather_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 with hipcc (``make`` in pyrad_amd/csrc)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library (once) and declare every signature."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pyrad_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _as_f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class _Handle:
+    __slots__ = ("ptr", "ctx", "__weakref__")
+
+    def __init__(self, ptr, ctx):
+        self.ptr = ptr
+        self.ctx = ctx
+
+
+class Context:
+    """One HIP device + one stream (lbl_ctx).  Not thread-safe."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = _P()
+        rc = self.lib.lbl_ctx_create(int(device), C.byref(h))
+        if rc != LBL_OK:
+            msg = (self.lib.lbl_last_error(None) or b"").decode()
+            raise (NoDeviceError if rc == -2 else LblError)(rc, msg)
+        self.h = h
+        self.device = int(device)
+        self._children = []
+
+    # -- plumbing ------------------------------------------------------------------------
+    def check(self, rc):
+        if rc != LBL_OK:
+            raise LblError(rc, (self.lib.lbl_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            for child in list(self._children):
+                child.free()
+            self.check(self.lib.lbl_ctx_destroy(self.h))
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self.check(self.lib.lbl_sync(self.h))
+
+    def stream(self) -> int:
+        s = _P()
+        self.check(self.lib.lbl_ctx_stream(self.h, C.byref(s)))
+        return s.value or 0
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        ncu = C.c_int()
+        hbm = C.c_int64()
+        self.check(self.lib.lbl_device_info(self.h, name, 256, C.byref(ncu), C.byref(hbm)))
+        return dict(name=name.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
+
+    def set_option(self, key: str, value: int):
+        self.check(self.lib.lbl_set_option(self.h, key.encode(), int(value)))
+
+    # -- objects -------------------------------------------------------------------------
+    def buffer(self, n: int, data=None) -> "Buffer":
+        b = Buffer(self, n)
+        if data is not None:
+            b.upload(data)
+        return b
+
+    def lines(self, lines: dict) -> "Lines":
+        return Lines(self, lines)
+
+    # -- hot path ------------------------------------------------------------------------
+    def xsec_accumulate(self, lines: dict, iso: IsoParams, grid: Grid):
+        """One-shot host in / host out (lbl_xsec_accumulate). Returns (xsec, regime_counts)."""
+        arrs = [_as_f64(lines[k]) for k in Lines.ORDER]
+        out = np.empty(int(grid.n_base), dtype=np.float64)
+        counts = (C.c_int64 * 3)()
+        self.check(self.lib.lbl_xsec_accumulate(self.h, *[_ptr(a) for a in arrs], len(arrs[0]),
+                                                C.byref(iso), C.byref(grid), _ptr(out), counts))
+        return out, tuple(int(c) for c in counts)
+
+    def xsec_accumulate_dev(self, jobs):
+        """jobs: list of (Lines, IsoParams, Grid, Buffer). Asynchronous."""
+        n = len(jobs)
+        if n == 0:
+            return
+        L = (_P * n)(*[j[0].h for j in jobs])
+        I = (IsoParams * n)(*[j[1] for j in jobs])
+        G = (Grid * n)(*[j[2] for j in jobs])
+        O = (_P * n)(*[j[3].h for j in jobs])
+        self.check(self.lib.lbl_xsec_accumulate_dev(self.h, n, L, I, G, O))
+
+    def last_regime_counts(self, n_jobs: int):
+        counts = (C.c_int64 * (3 * n_jobs))()
+        self.check(self.lib.lbl_last_regime_counts(self.h, n_jobs, counts))
+        return np.array(counts, dtype=np.int64).reshape(n_jobs, 3)
+
+    def line_quantities(self, lines: "Lines", iso: IsoParams, grid: Grid):
+        n = lines.n
+        index = np.empty(n, np.int64); lhw = np.empty(n); ghw = np.empty(n); inten = np.empty(n)
+        regime = np.empty(n, np.int32)
+        self.check(self.lib.lbl_line_quantities(self.h, lines.h, C.byref(iso), C.byref(grid), _ptr(index), _ptr(lhw),
+                                                _ptr(ghw), _ptr(inten), _ptr(regime)))
+        return dict(index=index, lhw=lhw, ghw=ghw, intensity=inten, regime=regime)
+
+    def layer_sweep_dev(self, xsec, iso_mol, conc, P, T, depth, range_min, range_max, n,
+                        I_in=None, surface_T=0.0, abs_coef=None, trans=None, I_out=None, first=0, count=0):
+        n_iso = len(xsec)
+        X = (_P * max(n_iso, 1))(*[b.h for b in xsec])
+        M = (C.c_int32 * max(n_iso, 1))(*[int(m) for m in iso_mol])
+        cc = (C.c_double * max(len(conc), 1))(*[float(c) for c in conc])
+        self.check(self.lib.lbl_layer_sweep_dev(
+            self.h, n_iso, X, M, len(conc), cc, float(P), float(T), float(depth), float(range_min),
+            float(range_max), int(n), int(first), int(count), I_in.h if I_in is not None else None,
+            float(surface_T), abs_coef.h if abs_coef is not None else None, trans.h if trans is not None else None,
+            I_out.h if I_out is not None else None))
+
+    def column_sweep_dev(self, trans, layer_T, range_min, range_max, n, I_out, I_in=None, surface_T=0.0,
+                         first=0, count=0):
+        nl = len(trans)
+        Tb = (_P * max(nl, 1))(*[b.h for b in trans])
+        TT = (C.c_double * max(nl, 1))(*[float(t) for t in layer_T])
+        self.check(self.lib.lbl_column_sweep_dev(self.h, nl, Tb, TT, float(range_min), float(range_max), int(n),
+                                                 int(first), int(count),
+                                                 I_in.h if I_in is not None else None, float(surface_T), I_out.h))
+
+    def optical_dev(self, trans, n, kind, out):
+        self.check(self.lib.lbl_optical_dev(self.h, trans.h, int(n), int(kind), out.h))
+
+    def planck_dev(self, range_min, range_max, n, T, out):
+        self.check(self.lib.lbl_planck_dev(self.h, float(range_min), float(range_max), int(n), float(T), out.h))
+
+    def band_integral(self, spectrum, n, unit_angle, res) -> float:
+        r = C.c_double()
+        self.check(self.lib.lbl_band_integral(self.h, spectrum.h, int(n), float(unit_angle), float(res), C.byref(r)))
+        return r.value
+
+    def line_survey_dev(self, lines, grid, out):
+        self.check(self.lib.lbl_line_survey_dev(self.h, lines.h, C.byref(grid), out.h))
+
+
+class Buffer:
+    """Device float64 array (lbl_buffer)."""
+
+    def __init__(self, ctx: Context, n: int):
+        self.ctx = ctx
+        self.n = int(n)
+        h = _P()
+        ctx.check(ctx.lib.lbl_buffer_create(ctx.h, self.n, C.byref(h)))
+        self.h = h
+        ctx._children.append(self)
+
+    def upload(self, data, offset: int = 0):
+        a = _as_f64(data)
+        self.ctx.check(self.ctx.lib.lbl_buffer_upload(self.h, _ptr(a), a.size, int(offset)))
+        return self
+
+    def download(self, n: int | None = None, offset: int = 0) -> np.ndarray:
+        n = self.n - offset if n is None else int(n)
+        out = np.empty(n, dtype=np.float64)
+        self.ctx.check(self.ctx.lib.lbl_buffer_download(self.h, _ptr(out), n, int(offset)))
+        return out
+
+    def fill(self, value: float):
+        self.ctx.check(self.ctx.lib.lbl_buffer_fill(self.h, float(value)))
+        return self
+
+    def devptr(self) -> int:
+        p = _P()
+        self.ctx.check(self.ctx.lib.lbl_buffer_devptr(self.h, C.byref(p)))
+        return p.value or 0
+
+    def free(self):
+        if self.h:
+            self.ctx.check(self.ctx.lib.lbl_buffer_destroy(self.h))
+            self.h = None
+            if self in self.ctx._children:
+                self.ctx._children.remove(self)
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.free()
+        except Exception:
+            pass
+
+
+class Lines:
+    """Device-resident HITRAN line list (lbl_lines).  Sorts by nu on the host if needed."""
+    ORDER = ("nu", "sw", "elower", "gamma_air", "gamma_self", "n_air", "delta_air")
+
+    def __init__(self, ctx: Context, lines: dict):
+        self.ctx = ctx
+        nu = _as_f64(lines["nu"])
+        if nu.size > 1 and np.any(np.diff(nu) < 0):
+            order = np.argsort(nu, kind="stable")
+            lines = {k: np.asarray(lines[k])[order] for k in self.ORDER}
+        arrs = [_as_f64(lines[k]) for k in self.ORDER]
+        self.n = int(arrs[0].size)
+        h = _P()
+        ctx.check(ctx.lib.lbl_lines_create(ctx.h, *[_ptr(a) for a in arrs], self.n, C.byref(h)))
+        self.h = h
+        ctx._children.append(self)
+
+    def free(self):
+        if self.h:
+            self.ctx.check(self.ctx.lib.lbl_lines_destroy(self.h))
+            self.h = None
+            if self in self.ctx._children:
+                self.ctx._children.remove(self)
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.free()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RCCL communicator over the context's device (lbl_comm), one rank per process."""
+
+    def __init__(self, ctx: Context, unique_id: bytes, world_size: int, rank: int):
+        self.ctx = ctx
+        self.world_size, self.rank = int(world_size), int(rank)
+        h = _P()
+        buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        ctx.check(ctx.lib.lbl_comm_create(ctx.h, buf, self.world_size, self.rank, C.byref(h)))
+        self.h = h
+        ctx._children.insert(0, self)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = load()
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        rc = lib.lbl_comm_unique_id(buf)
+        if rc != LBL_OK:
+            raise LblError(rc, (lib.lbl_last_error(None) or b"").decode())
+        return buf.raw
+
+    def allgather_dev(self, send: Buffer, send_offset: int, count: int, recv: Buffer):
+        self.ctx.check(self.ctx.lib.lbl_allgather_dev(self.h, send.h, int(send_offset), int(count), recv.h))
+
+    def free(self):
+        if self.h:
+            self.ctx.check(self.ctx.lib.lbl_comm_destroy(self.h))
+            self.h = None
+            if self in self.ctx._children:
+                self.ctx._children.remove(self)
+
+
+def device_count() -> int:
+    lib = load()
+    n = C.c_int()
+    rc = lib.lbl_device_count(C.byref(n))
+    return n.value if rc == LBL_OK else 0

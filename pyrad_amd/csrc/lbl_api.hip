@@ -1,0 +1,696 @@
+// C-ABI of the MI355X line-by-line engine (include/pyrad_hip.h): contexts, device objects,
+// argument checking and launch sequencing.  Kernels live in lbl_kernels.hip.
+#include "../../include/pyrad_hip.h"
+#include "lbl_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+
+using namespace lbl;
+
+// ----------------------------------------------------------------------------------------
+// objects
+// ----------------------------------------------------------------------------------------
+struct DeviceArena {      // grow-only device scratch
+    void* ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct lbl_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int n_cu = 0;
+    // scratch
+    DeviceArena recs;       // LineRec per line of the current batch
+    DeviceArena cidx;       // int32 per line
+    DeviceArena work;       // work grids that need a regrid
+    DeviceArena jobs;       // PrepJob[] + AccumJob[] + ColumnArgs
+    DeviceArena counts;     // regime counters, 3 x u64 per job
+    DeviceArena red;        // band-integral partials + result
+    void* host_stage = nullptr;   // pinned staging ring for job descriptors
+    size_t host_stage_cap = 0;
+    size_t host_stage_head = 0;
+    int last_jobs = 0;
+    // tuning knobs (lbl_set_option)
+    int accum_variant = 2;   // 0: IEEE divide + exp per point; 1: running fraction; 2: + Gaussian recurrence
+    int accum_R = 0;         // 0 = choose per launch
+    int live_objects = 0;
+};
+
+struct lbl_buffer {
+    lbl_ctx* ctx;
+    double* d;
+    int64_t n;
+};
+
+struct lbl_lines {
+    lbl_ctx* ctx;
+    double* d;        // 7 arrays of n: nu, sw, elower, gamma_air, gamma_self, n_air, delta_air
+    int64_t n;
+    const double* field(int k) const { return d + (size_t)k * (size_t)n; }
+};
+
+static thread_local std::string g_err;
+
+static int fail(lbl_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? LBL_ERR_OOM : LBL_ERR_HIP, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                \
+    } while (0)
+
+static int arena_reserve(lbl_ctx* ctx, DeviceArena& a, size_t bytes) {
+    if (bytes <= a.cap) return LBL_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (a.ptr) HIP_TRY(ctx, hipFree(a.ptr));
+    a.ptr = nullptr; a.cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(ctx, hipMalloc(&a.ptr, want));
+    a.cap = want;
+    return LBL_OK;
+}
+
+// Pinned staging for descriptors that a later hipMemcpyAsync reads: bump-allocated from a
+// ring; the stream is drained only when the ring wraps (or grows), so a slot is never
+// rewritten while an earlier copy from it may still be pending.
+static int stage_alloc(lbl_ctx* ctx, size_t bytes, void** out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes > ctx->host_stage_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->host_stage) HIP_TRY(ctx, hipHostFree(ctx->host_stage));
+        ctx->host_stage = nullptr; ctx->host_stage_cap = 0; ctx->host_stage_head = 0;
+        size_t want = std::max<size_t>(bytes * 8, (size_t)1 << 20);
+        HIP_TRY(ctx, hipHostMalloc(&ctx->host_stage, want, hipHostMallocDefault));
+        ctx->host_stage_cap = want;
+    }
+    if (ctx->host_stage_head + bytes > ctx->host_stage_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->host_stage_head = 0;
+    }
+    *out = (char*)ctx->host_stage + ctx->host_stage_head;
+    ctx->host_stage_head += bytes;
+    return LBL_OK;
+}
+
+static int check_grid(lbl_ctx* ctx, const lbl_grid* g) {
+    if (!g) return fail(ctx, LBL_ERR_BAD_ARG, "grid is NULL");
+    if (!(g->resolution > 0) || !(g->base_resolution > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "resolution must be > 0");
+    if (g->n_work < 0 || g->n_base < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative grid length");
+    if (g->window < 1) return fail(ctx, LBL_ERR_BAD_ARG, "window (len(arange(0,dfc,res))) must be >= 1: the reference raises IndexError at rightCurve[0]");
+    if (g->n_work > 1900000000LL || g->window > 100000000LL) return fail(ctx, LBL_ERR_BAD_ARG, "grid too large for int32 indexing");
+    if (!(g->range_max >= g->range_min)) return fail(ctx, LBL_ERR_BAD_ARG, "range_max < range_min");
+    if (g->shard_first < 0 || g->shard_count < 0 || g->shard_first + g->shard_count > g->n_work)
+        return fail(ctx, LBL_ERR_BAD_ARG, "shard outside the work grid");
+    if (g->shard_count > 0 && !(g->resolution == g->base_resolution && g->n_work == g->n_base))
+        return fail(ctx, LBL_ERR_BAD_ARG, "a sharded accumulate needs resolution == base_resolution (regrid after the gather)");
+    return LBL_OK;
+}
+
+static void shard_range(const lbl_grid& g, long long* first, long long* count) {
+    if (g.shard_count > 0) { *first = g.shard_first; *count = g.shard_count; }
+    else { *first = 0; *count = g.n_work; }
+}
+
+static bool needs_regrid(const lbl_grid& g) {
+    return !(g.resolution == g.base_resolution && g.n_work == g.n_base);
+}
+
+// ----------------------------------------------------------------------------------------
+// library / context
+// ----------------------------------------------------------------------------------------
+extern "C" int lbl_abi_version(void) { return LBL_ABI_VERSION; }
+
+extern "C" int lbl_device_count(int* count) {
+    if (!count) return fail(nullptr, LBL_ERR_BAD_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(nullptr, LBL_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return LBL_OK;
+}
+
+extern "C" int lbl_ctx_create(int device, lbl_ctx** out) {
+    if (!out) return fail(nullptr, LBL_ERR_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, LBL_ERR_NO_DEVICE, "no HIP device (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, LBL_ERR_NO_DEVICE, "device %d out of range [0,%d)", device, n);
+    lbl_ctx* ctx = new (std::nothrow) lbl_ctx();
+    if (!ctx) return fail(nullptr, LBL_ERR_OOM, "host allocation failed");
+    ctx->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { int rc = fail(nullptr, LBL_ERR_HIP, "context setup: %s", hipGetErrorString(e)); delete ctx; return rc; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    *out = ctx;
+    return LBL_OK;
+}
+
+extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) {
+    if (!ctx) return LBL_OK;
+    if (ctx->live_objects != 0) return fail(ctx, LBL_ERR_STATE, "%d device objects still alive", ctx->live_objects);
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    DeviceArena* arenas[] = {&ctx->recs, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->red};
+    for (DeviceArena* a : arenas) if (a->ptr) hipFree(a->ptr);
+    if (ctx->host_stage) hipHostFree(ctx->host_stage);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return LBL_OK;
+}
+
+extern "C" const char* lbl_last_error(const lbl_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+extern "C" int lbl_sync(lbl_ctx* ctx) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LBL_OK;
+}
+
+extern "C" int lbl_ctx_stream(lbl_ctx* ctx, void** stream) {
+    if (!ctx || !stream) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    *stream = (void*)ctx->stream;
+    return LBL_OK;
+}
+
+extern "C" int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s %s", prop.name, prop.gcnArchName);
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return LBL_OK;
+}
+
+// Tuning knobs for benchmarking and A/B parity runs (not part of the reference surface):
+//   "accum_variant" 0 | 1 | 2,  "accum_points_per_lane" 0 (auto) | 1 | 2 | 4 | 8
+extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) {
+    if (!ctx || !key) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    if (!strcmp(key, "accum_variant")) {
+        if (value < 0 || value > 2) return fail(ctx, LBL_ERR_BAD_ARG, "accum_variant must be 0..2");
+        ctx->accum_variant = value;
+    } else if (!strcmp(key, "accum_points_per_lane")) {
+        if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
+            return fail(ctx, LBL_ERR_BAD_ARG, "accum_points_per_lane must be 0, 1, 2, 4 or 8");
+        ctx->accum_R = value;
+    } else {
+        return fail(ctx, LBL_ERR_BAD_ARG, "unknown option '%s'", key);
+    }
+    return LBL_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// buffers
+// ----------------------------------------------------------------------------------------
+extern "C" int lbl_buffer_create(lbl_ctx* ctx, int64_t n, lbl_buffer** out) {
+    if (!ctx || !out) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative length");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, (size_t)std::max<int64_t>(n, 1) * sizeof(double)));
+    lbl_buffer* b = new (std::nothrow) lbl_buffer{ctx, d, n};
+    if (!b) { hipFree(d); return fail(ctx, LBL_ERR_OOM, "host allocation failed"); }
+    ctx->live_objects++;
+    *out = b;
+    return LBL_OK;
+}
+
+extern "C" int lbl_buffer_destroy(lbl_buffer* buf) {
+    if (!buf) return LBL_OK;
+    lbl_ctx* ctx = buf->ctx;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(buf->d));
+    ctx->live_objects--;
+    delete buf;
+    return LBL_OK;
+}
+
+extern "C" int lbl_buffer_size(const lbl_buffer* buf, int64_t* n) {
+    if (!buf || !n) return fail(nullptr, LBL_ERR_BAD_ARG, "NULL argument");
+    *n = buf->n;
+    return LBL_OK;
+}
+
+extern "C" int lbl_buffer_upload(lbl_buffer* buf, const double* host, int64_t n, int64_t dst_offset) {
+    if (!buf) return fail(nullptr, LBL_ERR_BAD_ARG, "buf is NULL");
+    lbl_ctx* ctx = buf->ctx;
+    if (n < 0 || dst_offset < 0 || dst_offset + n > buf->n) return fail(ctx, LBL_ERR_BAD_ARG, "upload range out of bounds");
+    if (n == 0) return LBL_OK;
+    if (!host) return fail(ctx, LBL_ERR_BAD_ARG, "host is NULL");
+    HIP_TRY(ctx, hipMemcpyAsync(buf->d + dst_offset, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the host pointer is not kept past return
+    return LBL_OK;
+}
+
+extern "C" int lbl_buffer_download(lbl_buffer* buf, double* host, int64_t n, int64_t src_offset) {
+    if (!buf) return fail(nullptr, LBL_ERR_BAD_ARG, "buf is NULL");
+    lbl_ctx* ctx = buf->ctx;
+    if (n < 0 || src_offset < 0 || src_offset + n > buf->n) return fail(ctx, LBL_ERR_BAD_ARG, "download range out of bounds");
+    if (n == 0) return LBL_OK;
+    if (!host) return fail(ctx, LBL_ERR_BAD_ARG, "host is NULL");
+    HIP_TRY(ctx, hipMemcpyAsync(host, buf->d + src_offset, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LBL_OK;
+}
+
+extern "C" int lbl_buffer_fill(lbl_buffer* buf, double value) {
+    if (!buf) return fail(nullptr, LBL_ERR_BAD_ARG, "buf is NULL");
+    lbl_ctx* ctx = buf->ctx;
+    if (buf->n == 0) return LBL_OK;
+    if (value == 0.0) {
+        HIP_TRY(ctx, hipMemsetAsync(buf->d, 0, (size_t)buf->n * sizeof(double), ctx->stream));
+    } else {
+        uint64_t bits;
+        memcpy(&bits, &value, 8);
+        // hipMemsetD32 cannot express a 64-bit pattern with different halves; stage through the host
+        std::vector<double> tmp((size_t)buf->n, value);
+        HIP_TRY(ctx, hipMemcpyAsync(buf->d, tmp.data(), (size_t)buf->n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return LBL_OK;
+}
+
+extern "C" int lbl_buffer_devptr(lbl_buffer* buf, void** devptr) {
+    if (!buf || !devptr) return fail(nullptr, LBL_ERR_BAD_ARG, "NULL argument");
+    *devptr = (void*)buf->d;
+    return LBL_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// line lists
+// ----------------------------------------------------------------------------------------
+extern "C" int lbl_lines_create(lbl_ctx* ctx, const double* nu, const double* sw, const double* elower,
+                                const double* gamma_air, const double* gamma_self, const double* n_air,
+                                const double* delta_air, int64_t n_lines, lbl_lines** out) {
+    if (!ctx || !out) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    if (n_lines < 0 || n_lines > 2000000000LL) return fail(ctx, LBL_ERR_BAD_ARG, "bad line count");
+    const double* src[7] = {nu, sw, elower, gamma_air, gamma_self, n_air, delta_air};
+    if (n_lines > 0)
+        for (const double* p : src) if (!p) return fail(ctx, LBL_ERR_BAD_ARG, "NULL line field");
+    for (int64_t i = 1; i < n_lines; ++i)
+        if (!(nu[i] >= nu[i - 1])) return fail(ctx, LBL_ERR_BAD_ARG, "nu must be non-decreasing (line %lld)", (long long)i);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, (size_t)std::max<int64_t>(n_lines, 1) * 7 * sizeof(double)));
+    for (int k = 0; k < 7 && n_lines > 0; ++k) {
+        hipError_t e = hipMemcpyAsync(d + (size_t)k * n_lines, src[k], (size_t)n_lines * sizeof(double),
+                                      hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { hipFree(d); return fail(ctx, LBL_ERR_HIP, "line upload: %s", hipGetErrorString(e)); }
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { hipFree(d); return fail(ctx, LBL_ERR_HIP, "line upload: %s", hipGetErrorString(e)); }
+    lbl_lines* L = new (std::nothrow) lbl_lines{ctx, d, n_lines};
+    if (!L) { hipFree(d); return fail(ctx, LBL_ERR_OOM, "host allocation failed"); }
+    ctx->live_objects++;
+    *out = L;
+    return LBL_OK;
+}
+
+extern "C" int lbl_lines_destroy(lbl_lines* lines) {
+    if (!lines) return LBL_OK;
+    lbl_ctx* ctx = lines->ctx;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(lines->d));
+    ctx->live_objects--;
+    delete lines;
+    return LBL_OK;
+}
+
+extern "C" int lbl_lines_count(const lbl_lines* lines, int64_t* n) {
+    if (!lines || !n) return fail(nullptr, LBL_ERR_BAD_ARG, "NULL argument");
+    *n = lines->n;
+    return LBL_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// the hot path
+// ----------------------------------------------------------------------------------------
+static int choose_R(const lbl_ctx* ctx, long long total_points, long long min_H) {
+    if (ctx->accum_R) return ctx->accum_R;
+    // enough wavefronts to cover every SIMD about 4 times (256 CUs x 4 SIMDs), and no
+    // more points per wave than a line's support is wide
+    const long long simds = 4LL * (ctx->n_cu > 0 ? ctx->n_cu : 256);
+    int R = 8;
+    while (R > 1 && total_points / (64LL * R) < 3 * simds) R >>= 1;
+    while (R > 1 && 64LL * R > 2 * min_H + 1) R >>= 1;
+    return R;
+}
+
+struct DbgOut { long long* index; double* lhw; double* ghw; double* inten; int32_t* regime; };
+
+static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines, const lbl_iso_params* iso,
+                              const lbl_grid* grid, double* const* out_dev, const DbgOut* dbg, bool prep_only) {
+    if (n_jobs <= 0) return LBL_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // layout of the scratch arenas
+    std::vector<size_t> line_off(n_jobs), work_off(n_jobs);
+    size_t tot_lines = 0, tot_work = 0;
+    long long total_points = 0, min_H = 1LL << 40;
+    int max_lines = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!lines[j] || lines[j]->ctx != ctx) return fail(ctx, LBL_ERR_STATE, "job %d: line list missing or from another context", j);
+        int rc = check_grid(ctx, &grid[j]);
+        if (rc) return rc;
+        if (!(iso[j].T > 0) || !(iso[j].P > 0) || !(iso[j].molmass > 0) || !(iso[j].Q_T > 0))
+            return fail(ctx, LBL_ERR_BAD_ARG, "job %d: T, P, molmass and Q_T must be > 0", j);
+        line_off[j] = tot_lines;
+        tot_lines += (size_t)lines[j]->n;
+        work_off[j] = tot_work;
+        if (needs_regrid(grid[j])) tot_work += (size_t)grid[j].n_work;
+        { long long f, c; shard_range(grid[j], &f, &c); total_points += c; }
+        min_H = std::min<long long>(min_H, std::max<long long>(grid[j].window - 2, 0));
+        max_lines = std::max<int>(max_lines, (int)lines[j]->n);
+    }
+    int rc;
+    if ((rc = arena_reserve(ctx, ctx->recs, std::max<size_t>(tot_lines, 1) * sizeof(LineRec)))) return rc;
+    if ((rc = arena_reserve(ctx, ctx->cidx, std::max<size_t>(tot_lines, 1) * sizeof(int32_t)))) return rc;
+    if ((rc = arena_reserve(ctx, ctx->work, std::max<size_t>(tot_work, 1) * sizeof(double)))) return rc;
+    if ((rc = arena_reserve(ctx, ctx->counts, (size_t)n_jobs * 3 * sizeof(unsigned long long)))) return rc;
+    const size_t prep_bytes = (size_t)n_jobs * sizeof(PrepJob), acc_bytes = (size_t)n_jobs * sizeof(AccumJob);
+    if ((rc = arena_reserve(ctx, ctx->jobs, prep_bytes + acc_bytes))) return rc;
+    void* stage = nullptr;
+    if ((rc = stage_alloc(ctx, prep_bytes + acc_bytes, &stage))) return rc;
+
+    const int R = choose_R(ctx, total_points, min_H);
+    PrepJob* hp = (PrepJob*)stage;
+    AccumJob* ha = (AccumJob*)((char*)stage + prep_bytes);
+    int max_tiles = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const lbl_lines* L = lines[j];
+        PrepJob& p = hp[j];
+        memset(&p, 0, sizeof p);
+        p.nu = L->field(0); p.sw = L->field(1); p.elower = L->field(2); p.gamma_air = L->field(3);
+        p.gamma_self = L->field(4); p.n_air = L->field(5); p.delta_air = L->field(6);
+        p.recs = (LineRec*)ctx->recs.ptr + line_off[j];
+        p.cidx = (int32_t*)ctx->cidx.ptr + line_off[j];
+        p.regime_counts = (unsigned long long*)ctx->counts.ptr + 3 * (size_t)j;
+        if (dbg) { p.dbg_index = dbg->index; p.dbg_lhw = dbg->lhw; p.dbg_ghw = dbg->ghw; p.dbg_intensity = dbg->inten; p.dbg_regime = dbg->regime; }
+        p.T = iso[j].T; p.P = iso[j].P; p.q_frac = iso[j].q_frac; p.molmass = iso[j].molmass;
+        p.Q_T = iso[j].Q_T; p.Q_296 = iso[j].Q_296;
+        p.range_min = grid[j].range_min; p.resolution = grid[j].resolution;
+        p.n_lines = (int32_t)L->n;
+        AccumJob& a = ha[j];
+        memset(&a, 0, sizeof a);
+        a.recs = p.recs; a.cidx = p.cidx;
+        a.out = needs_regrid(grid[j]) ? (double*)ctx->work.ptr + work_off[j] : out_dev[j];
+        a.n_lines = (int32_t)L->n;
+        a.n_work = (int32_t)grid[j].n_work;
+        a.H = (int32_t)std::max<long long>(grid[j].window - 2, 0);
+        long long sf, sc;
+        shard_range(grid[j], &sf, &sc);
+        a.p_begin = (int32_t)sf;
+        a.p_end = (int32_t)(sf + sc);
+        a.n_tiles = (int32_t)((sc + 256LL * R - 1) / (256LL * R));
+        max_tiles = std::max(max_tiles, a.n_tiles);
+    }
+    PrepJob* dp = (PrepJob*)ctx->jobs.ptr;
+    AccumJob* da = (AccumJob*)((char*)ctx->jobs.ptr + prep_bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->jobs.ptr, stage, prep_bytes + acc_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counts.ptr, 0, (size_t)n_jobs * 3 * sizeof(unsigned long long), ctx->stream));
+    launch_line_prep(dp, n_jobs, max_lines, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->last_jobs = n_jobs;
+    if (prep_only) return LBL_OK;
+    launch_accumulate(da, n_jobs, max_tiles, R, ctx->accum_variant, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!needs_regrid(grid[j])) continue;
+        launch_regrid((const double*)ctx->work.ptr + work_off[j], grid[j].n_work, out_dev[j], grid[j].n_base,
+                      grid[j].range_min, grid[j].range_max, ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return LBL_OK;
+}
+
+extern "C" int lbl_xsec_accumulate_dev(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines, const lbl_iso_params* iso,
+                                       const lbl_grid* grid, lbl_buffer* const* out) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (n_jobs < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative job count");
+    if (n_jobs == 0) return LBL_OK;
+    if (!lines || !iso || !grid || !out) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    std::vector<double*> outs(n_jobs);
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!out[j] || out[j]->ctx != ctx) return fail(ctx, LBL_ERR_STATE, "job %d: output buffer missing or from another context", j);
+        if (out[j]->n < grid[j].n_base) return fail(ctx, LBL_ERR_BAD_ARG, "job %d: output buffer shorter than n_base", j);
+        outs[j] = out[j]->d;
+    }
+    return enqueue_accumulate(ctx, n_jobs, lines, iso, grid, outs.data(), nullptr, false);
+}
+
+extern "C" int lbl_last_regime_counts(lbl_ctx* ctx, int n_jobs, int64_t* counts) {
+    if (!ctx || !counts) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    if (n_jobs < 0 || n_jobs > ctx->last_jobs) return fail(ctx, LBL_ERR_BAD_ARG, "n_jobs exceeds the last batch (%d)", ctx->last_jobs);
+    if (n_jobs == 0) return LBL_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(counts, ctx->counts.ptr, (size_t)n_jobs * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LBL_OK;
+}
+
+extern "C" int lbl_xsec_accumulate(lbl_ctx* ctx, const double* nu, const double* sw, const double* elower,
+                                   const double* gamma_air, const double* gamma_self, const double* n_air,
+                                   const double* delta_air, int64_t n_lines, const lbl_iso_params* iso,
+                                   const lbl_grid* grid, double* xsec_out, int64_t regime_counts[3]) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (!iso || !grid || !xsec_out) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    int rc = check_grid(ctx, grid);
+    if (rc) return rc;
+    lbl_lines* L = nullptr;
+    lbl_buffer* B = nullptr;
+    rc = lbl_lines_create(ctx, nu, sw, elower, gamma_air, gamma_self, n_air, delta_air, n_lines, &L);
+    if (rc) return rc;
+    rc = lbl_buffer_create(ctx, grid->n_base, &B);
+    if (!rc) rc = lbl_xsec_accumulate_dev(ctx, 1, &L, iso, grid, &B);
+    if (!rc) rc = lbl_buffer_download(B, xsec_out, grid->n_base, 0);
+    if (!rc && regime_counts) rc = lbl_last_regime_counts(ctx, 1, regime_counts);
+    std::string keep = ctx->err;
+    lbl_buffer_destroy(B);
+    lbl_lines_destroy(L);
+    if (rc) ctx->err = keep;
+    return rc;
+}
+
+extern "C" int lbl_line_quantities(lbl_ctx* ctx, lbl_lines* lines, const lbl_iso_params* iso, const lbl_grid* grid,
+                                   int64_t* index, double* lorentz_hw, double* gauss_hw, double* intensity,
+                                   int32_t* regime) {
+    if (!ctx || !lines || !iso || !grid) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    const size_t n = (size_t)lines->n;
+    if (n == 0) return LBL_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    char* d = nullptr;
+    const size_t bytes = n * (8 + 8 + 8 + 8 + 4);
+    HIP_TRY(ctx, hipMalloc((void**)&d, bytes));
+    DbgOut dbg;
+    dbg.index = (long long*)d;
+    dbg.lhw = (double*)(d + 8 * n);
+    dbg.ghw = (double*)(d + 16 * n);
+    dbg.inten = (double*)(d + 24 * n);
+    dbg.regime = (int32_t*)(d + 32 * n);
+    double* no_out = nullptr;
+    int rc = enqueue_accumulate(ctx, 1, &lines, iso, grid, &no_out, &dbg, true);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        if (index) e = hipMemcpyAsync(index, dbg.index, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && lorentz_hw) e = hipMemcpyAsync(lorentz_hw, dbg.lhw, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && gauss_hw) e = hipMemcpyAsync(gauss_hw, dbg.ghw, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && intensity) e = hipMemcpyAsync(intensity, dbg.inten, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && regime) e = hipMemcpyAsync(regime, dbg.regime, 4 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    } else {
+        hipStreamSynchronize(ctx->stream);
+    }
+    hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, LBL_ERR_HIP, "line_quantities: %s", hipGetErrorString(e));
+    return LBL_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// sweeps
+// ----------------------------------------------------------------------------------------
+static void planck_constants(double* pa, double* pb) {
+    *pa = 2E8 * hPlanck * (cLight * cLight);      // 2E8 * h * c**2   (pyradPlanck.py:41)
+    *pb = 100 * hPlanck * cLight;                 // 100 * h * c      (pyradPlanck.py:42)
+}
+
+static double axis_step(double lo, double hi, int64_t n) { return n > 1 ? (hi - lo) / (double)(n - 1) : 0.0; }
+
+static int check_buf(lbl_ctx* ctx, const lbl_buffer* b, int64_t n, const char* what, bool required) {
+    if (!b) return required ? fail(ctx, LBL_ERR_BAD_ARG, "%s is NULL", what) : LBL_OK;
+    if (b->ctx != ctx) return fail(ctx, LBL_ERR_STATE, "%s belongs to another context", what);
+    if (b->n < n) return fail(ctx, LBL_ERR_BAD_ARG, "%s shorter than n", what);
+    return LBL_OK;
+}
+
+extern "C" int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* xsec, const int32_t* iso_mol, int n_mol,
+                                   const double* conc, double P, double T, double depth, double range_min,
+                                   double range_max, int64_t n, int64_t first, int64_t count, lbl_buffer* I_in,
+                                   double surface_T, lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (n_iso < 0 || n_iso > kMaxIso || n_mol < 0 || n_mol > kMaxIso) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d isotopologues per sweep", kMaxIso);
+    if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
+    if (first < 0 || count < 0 || first + count > n) return fail(ctx, LBL_ERR_BAD_ARG, "swept range outside [0, n)");
+    if (count == 0) { first = 0; count = n; }
+    if (n_iso > 0 && (!xsec || !iso_mol)) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    if (n_mol > 0 && !conc) return fail(ctx, LBL_ERR_BAD_ARG, "conc is NULL");
+    if (!(T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "T must be > 0");
+    SweepArgs a;
+    memset(&a, 0, sizeof a);
+    int rc;
+    for (int i = 0; i < n_iso; ++i) {
+        if ((rc = check_buf(ctx, xsec[i], n, "xsec", true))) return rc;
+        if (iso_mol[i] < 0 || iso_mol[i] >= n_mol || (i > 0 && iso_mol[i] < iso_mol[i - 1]))
+            return fail(ctx, LBL_ERR_BAD_ARG, "iso_mol must be non-decreasing and < n_mol");
+        a.xsec[i] = xsec[i]->d;
+        a.iso_mol[i] = iso_mol[i];
+    }
+    for (int m = 0; m < n_mol; ++m) a.conc[m] = conc[m];
+    if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
+    if ((rc = check_buf(ctx, abs_coef, n, "abs_coef", false))) return rc;
+    if ((rc = check_buf(ctx, trans, n, "trans", false))) return rc;
+    if ((rc = check_buf(ctx, I_out, n, "I_out", false))) return rc;
+    if (I_out && !I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "I_out needs I_in or surface_T > 0");
+    a.n_iso = n_iso; a.n_mol = n_mol; a.P = P; a.T = T; a.depth = depth;
+    a.start = range_min; a.stop = range_max; a.step = axis_step(range_min, range_max, n);
+    planck_constants(&a.pa, &a.pb);
+    a.surface_T = surface_T;
+    a.I_in = I_in ? I_in->d : nullptr;
+    a.abs_coef = abs_coef ? abs_coef->d : nullptr;
+    a.trans = trans ? trans->d : nullptr;
+    a.I_out = I_out ? I_out->d : nullptr;
+    a.n = n; a.first = first; a.count = count;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    launch_layer_sweep(a, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBL_OK;
+}
+
+extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const* trans, const double* layer_T,
+                                    double range_min, double range_max, int64_t n, int64_t first, int64_t count,
+                                    lbl_buffer* I_in, double surface_T, lbl_buffer* I_out) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (n_layers < 0 || n_layers > kMaxLayers) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d layers", kMaxLayers);
+    if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
+    if (first < 0 || count < 0 || first + count > n) return fail(ctx, LBL_ERR_BAD_ARG, "swept range outside [0, n)");
+    if (count == 0) { first = 0; count = n; }
+    if (n_layers > 0 && (!trans || !layer_T)) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    int rc;
+    if ((rc = check_buf(ctx, I_out, n, "I_out", true))) return rc;
+    if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
+    if (!I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "need I_in or surface_T > 0");
+    void* stage = nullptr;
+    if ((rc = stage_alloc(ctx, sizeof(ColumnArgs), &stage))) return rc;
+    if ((rc = arena_reserve(ctx, ctx->jobs, sizeof(ColumnArgs)))) return rc;
+    ColumnArgs* a = (ColumnArgs*)stage;
+    memset(a, 0, sizeof *a);
+    for (int l = 0; l < n_layers; ++l) {
+        if ((rc = check_buf(ctx, trans[l], n, "trans", true))) return rc;
+        if (!(layer_T[l] > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "layer_T must be > 0");
+        a->trans[l] = trans[l]->d;
+        a->layer_T[l] = layer_T[l];
+    }
+    a->n_layers = n_layers;
+    a->start = range_min; a->stop = range_max; a->step = axis_step(range_min, range_max, n);
+    planck_constants(&a->pa, &a->pb);
+    a->surface_T = surface_T;
+    a->I_in = I_in ? I_in->d : nullptr;
+    a->I_out = I_out->d;
+    a->n = n; a->first = first; a->count = count;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->jobs.ptr, a, sizeof(ColumnArgs), hipMemcpyHostToDevice, ctx->stream));
+    launch_column_sweep((const ColumnArgs*)ctx->jobs.ptr, count, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBL_OK;
+}
+
+extern "C" int lbl_optical_dev(lbl_ctx* ctx, lbl_buffer* trans, int64_t n, int kind, lbl_buffer* out) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
+    if (kind < 0 || kind > 2) return fail(ctx, LBL_ERR_BAD_ARG, "kind must be 0 (emissivity), 1 (absorbance) or 2 (optical depth)");
+    int rc;
+    if ((rc = check_buf(ctx, trans, n, "trans", true))) return rc;
+    if ((rc = check_buf(ctx, out, n, "out", true))) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    launch_optical(trans->d, n, kind, out->d, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBL_OK;
+}
+
+extern "C" int lbl_planck_dev(lbl_ctx* ctx, double range_min, double range_max, int64_t n, double T, lbl_buffer* out) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    int rc;
+    if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
+    if ((rc = check_buf(ctx, out, n, "out", true))) return rc;
+    double pa, pb;
+    planck_constants(&pa, &pb);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    launch_planck(out->d, n, range_min, range_max, T, pa, pb, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBL_OK;
+}
+
+extern "C" int lbl_band_integral(lbl_ctx* ctx, lbl_buffer* spectrum, int64_t n, double unit_angle, double res,
+                                 double* result) {
+    if (!ctx || !result) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    int rc;
+    if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
+    if ((rc = check_buf(ctx, spectrum, n, "spectrum", true))) return rc;
+    if (n == 0) { *result = 0.0 * unit_angle * res; return LBL_OK; }
+    const int nb = band_partial_count(n);
+    if ((rc = arena_reserve(ctx, ctx->red, (size_t)(nb + 1) * sizeof(double)))) return rc;
+    double* partial = (double*)ctx->red.ptr;
+    double* dres = partial + nb;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    launch_band_integral(spectrum->d, n, partial, dres, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    double s = 0.0;
+    HIP_TRY(ctx, hipMemcpyAsync(&s, dres, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *result = s * unit_angle * res;              // value * unitAngle * res (pyradClasses.py:28)
+    return LBL_OK;
+}
+
+extern "C" int lbl_line_survey_dev(lbl_ctx* ctx, lbl_lines* lines, const lbl_grid* grid, lbl_buffer* out) {
+    if (!ctx || !lines || !grid) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    if (lines->ctx != ctx) return fail(ctx, LBL_ERR_STATE, "line list belongs to another context");
+    int rc;
+    if ((rc = check_grid(ctx, grid))) return rc;
+    if ((rc = check_buf(ctx, out, grid->n_base, "out", true))) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (grid->n_base > 0) HIP_TRY(ctx, hipMemsetAsync(out->d, 0, (size_t)grid->n_base * sizeof(double), ctx->stream));
+    launch_line_survey(lines->field(0), lines->field(1), (int)lines->n, grid->range_min, grid->resolution, out->d,
+                       grid->n_base, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBL_OK;
+}
+
+// hooks for lbl_comm.hip (kept out of the public header)
+namespace lbl {
+int comm_fail(lbl_ctx* ctx, int code, const char* msg) { return fail(ctx, code, "%s", msg); }
+int ctx_device(lbl_ctx* ctx) { return ctx->device; }
+}  // namespace lbl

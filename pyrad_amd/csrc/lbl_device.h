@@ -1,0 +1,107 @@
+// Shared host/device structures of the MI355X line-by-line engine (internal; the public
+// boundary is include/pyrad_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lbl {
+
+// physical constants exactly as the reference spells them (pyradClasses.py:15-23,
+// pyradLineshape.py:14-19, pyradIntensity.py:3-13, pyradPlanck.py:4-9)
+constexpr double kB = 1.38064852E-23;
+constexpr double cLight = 299792458.0;
+constexpr double hPlanck = 6.62607004e-34;
+constexpr double kPi = 3.141592653589793;
+constexpr double t0 = 296.0;
+constexpr double p0 = 1013.25;
+constexpr double avo = 6.022140857E23;
+
+// One prepared spectral line, in work-grid units (64 B, one s_load_dwordx16).
+// The contribution of the line to the grid point at integer offset d from its centre is
+//     KL / (d*d + a2)  +  KG * exp(-b*d*d)          for |d| <= H = window-2,
+// which restates pyradLineshape.py:39 (Gaussian), :52 (Lorentz) and :72-74 (pseudo-Voigt)
+// times the corrected intensity of pyradIntensity.py:30-32 with x = d*resolution.
+struct __attribute__((aligned(64))) LineRec {
+    double cf;     // centre index (pyradClasses.py:390) as a double
+    double a2;     // (hw / res)^2
+    double KL;     // Lorentz amplitude / res^2   (0 for a pure Gaussian line)
+    double KG;     // Gaussian amplitude           (0 for a pure Lorentz line)
+    double b;      // (res / hw)^2
+    double q2;     // exp(-2 b): ratio step of the Gaussian recurrence; < 0: evaluate directly
+    int32_t ci;    // centre index
+    int32_t dgi;   // |d| >= dgi: the Gaussian term cannot change the fp64 value of the sum
+    int32_t flags; // bit 0: Lorentz denominator out of the running-fraction range -> direct divide
+    int32_t pad;
+};
+static_assert(sizeof(LineRec) == 64, "LineRec must be 64 bytes");
+
+enum : int32_t { REC_DIRECT_DIV = 1 };
+
+// One accumulate job = one isotopologue of one layer (Isotope.createCrossSection).
+struct AccumJob {
+    const LineRec* recs;
+    const int32_t* cidx;   // centre indices, non-decreasing
+    double* out;           // work grid, n_work doubles
+    int32_t n_lines;
+    int32_t n_work;
+    int32_t H;             // wing support in points = max(window-2, 0)
+    int32_t n_tiles;
+    int32_t p_begin;       // shard of the work grid computed by this job: [p_begin, p_end)
+    int32_t p_end;
+};
+
+struct PrepJob {
+    const double* nu; const double* sw; const double* elower; const double* gamma_air;
+    const double* gamma_self; const double* n_air; const double* delta_air;
+    LineRec* recs; int32_t* cidx;
+    unsigned long long* regime_counts;    // [3]
+    // optional debug outputs
+    long long* dbg_index; double* dbg_lhw; double* dbg_ghw; double* dbg_intensity; int32_t* dbg_regime;
+    double T, P, q_frac, molmass, Q_T, Q_296;
+    double range_min, resolution;
+    int32_t n_lines;
+    int32_t pad;
+};
+
+// ---- fused sweep arguments (passed by value / by pointer to the sweep kernels) ----------
+constexpr int kMaxIso = 48;
+struct SweepArgs {
+    const double* xsec[kMaxIso];
+    int32_t iso_mol[kMaxIso];
+    double conc[kMaxIso];
+    int32_t n_iso, n_mol;
+    double P, T, depth;
+    double start, stop, step;       // xAxis = linspace(start, stop, n)
+    double pa, pb;                  // Planck constants 2E8*h*c**2 and 100*h*c
+    double surface_T;               // used when I_in == nullptr
+    const double* I_in;
+    double* abs_coef; double* trans; double* I_out;
+    long long n;
+    long long first, count;         // swept sub-range
+};
+constexpr int kMaxLayers = 128;
+struct ColumnArgs {
+    const double* trans[kMaxLayers];
+    double layer_T[kMaxLayers];
+    int32_t n_layers;
+    double start, stop, step, pa, pb, surface_T;
+    const double* I_in; double* I_out;
+    long long n;
+    long long first, count;
+};
+
+// ---- launchers (lbl_kernels.hip) ---------------------------------------------------------
+void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStream_t s);
+void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int variant, hipStream_t s);
+void launch_regrid(const double* work, long long n_work, double* out, long long n_base, double start, double stop,
+                   hipStream_t s);
+void launch_layer_sweep(const SweepArgs& a, hipStream_t s);
+void launch_column_sweep(const ColumnArgs* d_args, long long n, hipStream_t s);
+void launch_planck(double* out, long long n, double start, double stop, double T, double pa, double pb, hipStream_t s);
+int band_partial_count(long long n);
+void launch_band_integral(const double* y, long long n, double* partial, double* result, hipStream_t s);
+void launch_optical(const double* trans, long long n, int kind, double* out, hipStream_t s);
+void launch_line_survey(const double* nu, const double* sw, int n_lines, double range_min, double resolution,
+                        double* out, long long n_base, hipStream_t s);
+
+}  // namespace lbl

@@ -1,0 +1,220 @@
+"""Host-side engine: the layer grid of the reference computed with the reference's own
+expressions, and device-resident gas cells / columns that keep line lists and spectra in
+HBM and only enqueue kernels (``lbl_*_dev`` entry points of include/pyrad_hip.h).
+
+This is product code: it never imports ``oracle`` and it raises if the HIP library or a
+GPU is missing.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native as nat
+from . import settings
+
+K_BOLTZMANN = 1.38064852E-23     # pyradClasses.py:16
+PI = 3.141592653589793           # pyradClasses.py:19
+
+
+# ----------------------------------------------------------------------------------------
+# Layer grid definition (pyradClasses.py:648-676, 698-705, 745-752)
+# ----------------------------------------------------------------------------------------
+def layer_grid(P, range_min, range_max, base_resolution=None, dynamic_resolution=True) -> dict:
+    """Scalars of Layer.__init__ / changePressure with the reference's expressions, so that
+    every int() truncation and the arange length agree with PyRad bit for bit."""
+    if base_resolution is None:
+        base_resolution = settings.BASE_RESOLUTION
+    dfc = P / 1013.25 * 5                                              # cls:655
+    eff_min = max(range_min - dfc, 0)                                  # cls:656
+    eff_max = range_max + dfc                                          # cls:657
+    if not dynamic_resolution:
+        res = base_resolution                                          # cls:660
+    else:
+        res = max(10**int(np.log10((P / 1013.25))) * .01, base_resolution)   # cls:662
+    n_base = int((range_max - range_min) / base_resolution)            # cls:672
+    n_work = int((range_max - range_min) / res)                        # cls:700
+    W = len(np.arange(0, dfc, res))                                    # cls:377
+    return dict(dfc=dfc, eff_min=eff_min, eff_max=eff_max, resolution=res, base_resolution=base_resolution,
+                n_base=n_base, n_work=n_work, W=W, range_min=range_min, range_max=range_max)
+
+
+def native_grid(g: dict, shard=None) -> nat.Grid:
+    first, count = (0, 0) if shard is None else shard
+    return nat.Grid(float(g["range_min"]), float(g["range_max"]), float(g["resolution"]),
+                    float(g["base_resolution"]), int(g["n_work"]), int(g["n_base"]), int(g["W"]),
+                    int(first), int(count))
+
+
+def x_axis(range_min, range_max, base_resolution=None) -> np.ndarray:
+    """Layer.xAxis (cls:702-705) with the float ``num`` truncated as pre-1.18 NumPy did."""
+    if base_resolution is None:
+        base_resolution = settings.BASE_RESOLUTION
+    return np.linspace(range_min, range_max, int((range_max - range_min) / base_resolution), endpoint=True)
+
+
+def select_window(lines: dict, lo: float, hi: float) -> dict:
+    """Strict lo < nu < hi of readHitranOnlineFile (ut:437-438)."""
+    nu = np.asarray(lines["nu"])
+    m = (nu > lo) & (nu < hi)
+    if m.all():
+        return lines
+    return {k: np.asarray(v)[m] for k, v in lines.items()}
+
+
+def eval_count(nu, range_min, resolution, W, n_work, shard=None) -> int:
+    """Exact number of (line, grid point) contributions of the scatter loop cls:392-400
+    restricted to grid points [first, first+count) (SURVEY.md §8d unit of work)."""
+    idx = ((np.asarray(nu, dtype=np.float64) - range_min) / resolution).astype(np.int64)   # cls:390
+    H = max(int(W) - 2, 0)
+    first, count = (0, n_work) if shard is None or shard[1] == 0 else shard
+    lo = np.maximum(idx - H, first)
+    hi = np.minimum(idx + H, first + count - 1)
+    return int(np.maximum(hi - lo + 1, 0).sum())
+
+
+# ----------------------------------------------------------------------------------------
+# the engine singleton
+# ----------------------------------------------------------------------------------------
+_engine = None
+
+
+class Engine:
+    """One context on one GPU.  Raises nat.NoDeviceError when there is no GPU."""
+
+    def __init__(self, device: int = 0):
+        self.ctx = nat.Context(device)
+
+    def close(self):
+        self.ctx.close()
+
+
+def get_engine(device: int | None = None) -> Engine:
+    global _engine
+    if _engine is None or _engine.ctx.h is None:
+        _engine = Engine(settings.DEVICE if device is None else device)
+    return _engine
+
+
+def shutdown():
+    global _engine
+    if _engine is not None:
+        _engine.close()
+        _engine = None
+
+
+# ----------------------------------------------------------------------------------------
+# device-resident gas cell / column (what bench.py and the sharded path drive)
+# ----------------------------------------------------------------------------------------
+def shard_bounds(n: int, world_size: int, rank: int):
+    """Contiguous equal shards of a grid of n points padded to world_size*S:
+    rank r owns [r*S, min((r+1)*S, n)).  Returns (S, first, count)."""
+    S = -(-int(n) // int(world_size))
+    first = min(rank * S, n)
+    count = max(min((rank + 1) * S, n) - first, 0)
+    return S, first, count
+
+
+class ResidentLayer:
+    """One layer (gas cell) whose line lists, cross sections and spectra live in HBM.
+
+    ``molecules``: list of dict(species params) each with
+        conc (volume fraction), isotopologues = [dict(lines=SoA, molmass, q_T, q296), ...]
+    The layer's scalars follow Layer.__init__ (cls:648-676).  ``shard=(world, rank)`` keeps only
+    this rank's contiguous range of the grid (lines are pre-selected with the halo they need).
+    """
+
+    def __init__(self, ctx: nat.Context, depth, T, P, range_min, range_max, molecules,
+                 base_resolution=None, dynamic_resolution=True, shard=None, keep_host_lines=False):
+        self.ctx = ctx
+        self.depth, self.T, self.P = depth, T, P
+        self.range_min, self.range_max = range_min, range_max
+        self.g = layer_grid(P, range_min, range_max, base_resolution, dynamic_resolution)
+        g = self.g
+        n = g["n_base"]
+        self.n = n
+        if shard is not None and shard[0] > 1:
+            self.world, self.rank = shard
+            self.S, self.first, self.count = shard_bounds(g["n_work"], self.world, self.rank)
+        else:
+            self.world, self.rank = 1, 0
+            self.S, self.first, self.count = n, 0, 0          # count 0 == whole grid
+        self.padded_n = self.S * self.world if self.world > 1 else n
+        self.jobs = []
+        self.iso_mol, self.conc = [], []
+        self.evals = 0
+        self.n_lines = 0
+        self._keep = []
+        sh = None if self.world == 1 else (self.first, self.count)
+        self.grid_native = native_grid(g, sh)
+        for m, mol in enumerate(molecules):
+            self.conc.append(float(mol["conc"]))
+            for iso in mol["isotopologues"]:
+                lines = select_window(iso["lines"], g["eff_min"], g["eff_max"])
+                if self.world > 1:
+                    lines = self._halo_select(lines)
+                dev_lines = ctx.lines(lines)
+                out = ctx.buffer(max(self.padded_n, 1))
+                out.fill(0.0)
+                ip = nat.IsoParams(float(T), float(P), float(mol["conc"]), float(iso["molmass"]),
+                                   float(iso["q_T"]), float(iso["q296"]))
+                self.jobs.append((dev_lines, ip, self.grid_native, out))
+                self.iso_mol.append(m)
+                self.n_lines += dev_lines.n
+                self.evals += eval_count(lines["nu"], g["range_min"], g["resolution"], g["W"], g["n_work"], sh)
+                if keep_host_lines:
+                    self._keep.append(lines)
+        self.abs_coef = ctx.buffer(max(self.padded_n, 1))
+        self.trans = ctx.buffer(max(self.padded_n, 1))
+        self.I_out = ctx.buffer(max(self.padded_n, 1))
+        for b in (self.abs_coef, self.trans, self.I_out):
+            b.fill(0.0)
+
+    def _halo_select(self, lines):
+        """Lines whose support can reach this rank's grid range: centre index within
+        W-2 points of [first, first+count) — selected by wavenumber with one extra grid
+        step of slack so that index rounding can never drop a contributing line."""
+        g = self.g
+        res = g["resolution"]
+        H = max(g["W"] - 2, 0)
+        lo = g["range_min"] + (self.first - H - 2) * res
+        hi = g["range_min"] + (self.first + self.count + H + 2) * res
+        nu = np.asarray(lines["nu"])
+        m = (nu > lo) & (nu < hi)
+        return {k: np.asarray(v)[m] for k, v in lines.items()}
+
+    # -- enqueue ------------------------------------------------------------------------
+    def enqueue_xsec(self):
+        self.ctx.xsec_accumulate_dev(self.jobs)
+
+    def enqueue_sweep(self, I_in=None, surface_T=0.0, want_I=True):
+        first, count = (0, 0) if self.world == 1 else (self.first, self.count)
+        if self.world > 1 and self.count == 0:
+            return
+        self.ctx.layer_sweep_dev([j[3] for j in self.jobs], self.iso_mol, self.conc, self.P, self.T, self.depth,
+                                 self.range_min, self.range_max, self.n, I_in=I_in, surface_T=surface_T,
+                                 abs_coef=self.abs_coef, trans=self.trans,
+                                 I_out=self.I_out if want_I else None, first=first, count=count)
+
+    def enqueue(self, surface_T=288.0, I_in=None):
+        self.enqueue_xsec()
+        self.enqueue_sweep(I_in=I_in, surface_T=surface_T)
+
+    def enqueue_allgather(self, comm: nat.Comm, buffers=None):
+        """The single RCCL all-gather of the path, in place on the padded buffers."""
+        for b in (buffers if buffers is not None else (self.abs_coef,)):
+            comm.allgather_dev(b, self.rank * self.S, self.S, b)
+
+    # -- results ------------------------------------------------------------------------
+    def xsec_host(self, i=0):
+        return self.jobs[i][3].download(self.n)
+
+    def results(self):
+        return dict(abs_coef=self.abs_coef.download(self.n), transmittance=self.trans.download(self.n),
+                    transmission=self.I_out.download(self.n))
+
+    def free(self):
+        for j in self.jobs:
+            j[0].free(); j[3].free()
+        for b in (self.abs_coef, self.trans, self.I_out):
+            b.free()
+        self.jobs = []

@@ -1,0 +1,303 @@
+"""GPU parity: the HIP path called through the C ABI versus the committed golden vectors
+(captured from the real reference) and the CPU oracle on the same seeded inputs.
+
+Tolerances: the reference is fp64 and so is the device path.  north_star asks for <= 1e-6
+relative on the absorption coefficient; the device differs from NumPy only by summation
+association and libm-vs-ocml last-bit effects, so these tests hold it to RTOL = 1e-11.
+Centre indices (integer work) must be bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, unpack_lines, rel_err
+from pyrad_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-11
+# values this far below the largest value of an array are compared with an absolute floor:
+# they are sums of ~1e-300-scale Gaussian tails whose last bits depend on denormal rounding
+FLOOR_REL = 1e-250
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyrad_amd import _native as nat
+    c = nat.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pyrad_oracle
+    return pyrad_oracle
+
+
+def device_xsec(ctx, lines, species, conc, T, P, rmin, rmax, base, dyn, variant=None, R=None):
+    from pyrad_amd import _native as nat, engine
+    g = engine.layer_grid(P, rmin, rmax, base, dyn)
+    sel = engine.select_window(lines, g["eff_min"], g["eff_max"])
+    sp = synthetic.SPECIES[species]
+    iso = nat.IsoParams(float(T), float(P), float(conc), sp["molmass"], synthetic.q_value(species, T), sp["q296"])
+    if variant is not None:
+        ctx.set_option("accum_variant", variant)
+    if R is not None:
+        ctx.set_option("accum_points_per_lane", R)
+    try:
+        xs, counts = ctx.xsec_accumulate(sel, iso, engine.native_grid(g))
+    finally:
+        ctx.set_option("accum_variant", 2)
+        ctx.set_option("accum_points_per_lane", 0)
+    return xs, counts, g, sel, iso
+
+
+def check(a, b, tol=RTOL):
+    floor = float(np.max(np.abs(b))) * FLOOR_REL if b.size else 0.0
+    e = rel_err(a, b, floor=floor) if floor > 0 else rel_err(a, b)
+    assert e <= tol, e
+
+
+def test_device_is_mi355x(ctx):
+    info = ctx.device_info()
+    assert "gfx950" in info["name"], info
+    assert info["n_cu"] == 256
+
+
+@pytest.mark.parametrize("T", [296, 250])
+def test_g1_line_quantities_bit_exact_index(ctx, T):
+    from pyrad_amd import _native as nat, engine
+    z = load_golden("G1_c1_cell")
+    lines = unpack_lines(z, "lines")
+    g = engine.layer_grid(1013.25, 600, 700, .01, True)
+    sel = engine.select_window(lines, g["eff_min"], g["eff_max"])
+    sp = synthetic.SPECIES["co2"]
+    iso = nat.IsoParams(float(T), 1013.25, 400 * 10**-6, sp["molmass"], synthetic.q_value("co2", T), sp["q296"])
+    L = ctx.lines(sel)
+    q = ctx.line_quantities(L, iso, engine.native_grid(g))
+    p = "T%d." % T
+    assert np.array_equal(q["index"], z[p + "line_index"])          # integer work: bit exact
+    assert rel_err(q["lhw"], z[p + "line_lhw"]) <= 1e-15
+    assert rel_err(q["ghw"], z[p + "line_ghw"]) <= 1e-15
+    L.free()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("T", [296, 250])
+def test_g1_cell_all_variants(ctx, T, variant):
+    z = load_golden("G1_c1_cell")
+    lines = unpack_lines(z, "lines")
+    xs, counts, g, _, _ = device_xsec(ctx, lines, "co2", 400 * 10**-6, T, 1013.25, 600, 700, .01, True, variant)
+    check(xs, z["T%d.xsec" % T])
+    assert sum(counts) == 2000 and counts[0] == 0
+
+
+@pytest.mark.parametrize("R", [1, 2, 4, 8])
+def test_g1_points_per_lane(ctx, R):
+    z = load_golden("G1_c1_cell")
+    xs, _, _, _, _ = device_xsec(ctx, unpack_lines(z, "lines"), "co2", 4e-4, 296, 1013.25, 600, 700, .01, True, 2, R)
+    check(xs, z["T296.xsec"])
+
+
+def test_g0_single_line_known_answer(ctx):
+    z = load_golden("G0_functions")
+    xs, counts, g, _, _ = device_xsec(ctx, unpack_lines(z, "one.lines"), "co2", 4e-4, 296, 1013.25, 600, 700, .01, True)
+    check(xs, z["one.xsec"])
+    nz = np.nonzero(xs)[0]
+    assert (nz[0], nz[-1]) == (4502, 5498)          # support = centre +- (W-2), cls:394
+    assert counts == (0, 0, 1)
+    assert xs[5000] == pytest.approx(4.5462648814858876e-20, rel=1e-14)
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+def test_g2_edges(ctx, variant):
+    z = load_golden("G2_edges")
+    lines = unpack_lines(z, "lines")
+    xs, _, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, 600, 700, .01, True, variant)
+    check(xs, z["xsec"])
+    for i in range(len(lines["nu"])):
+        one = {k: v[i:i + 1] for k, v in lines.items()}
+        x1, _, _, _, _ = device_xsec(ctx, one, "co2", 4e-4, 296, 1013.25, 600, 700, .01, True, variant)
+        ref = z["single_xsec"][i]
+        assert np.array_equal(x1 != 0, ref != 0), i          # identical support, incl. clipped wings
+        check(x1, ref)
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+def test_g3_pressure_ladder_with_regrid(ctx, variant):
+    z = load_golden("G3_pressure_ladder")
+    for j, P in enumerate(z["P_list"]):
+        p = "P%d." % j
+        xs, _, g, _, _ = device_xsec(ctx, unpack_lines(z, p + "lines"), "co2", 4e-4, 260, float(P), 640, 660, .01, True,
+                                     variant)
+        assert (g["W"], g["n_work"]) == (int(z[p + "W"]), int(z[p + "n_work"]))
+        check(xs, z[p + "xsec"])
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_g4_regimes(ctx, variant):
+    z = load_golden("G4_regimes")
+    xs, counts, _, _, _ = device_xsec(ctx, unpack_lines(z, "a.lines"), "co2", 4e-4, 296, 1013.25, 645, 655, .01, True, variant)
+    assert counts[1] > 20 and counts[2] > 20
+    check(xs, z["a.xsec"])
+    xs, counts, g, _, _ = device_xsec(ctx, unpack_lines(z, "b.lines"), "co2", 4e-4, 220, 0.05, 650.0, 650.05, 1e-5, False, variant)
+    assert counts[0] > 5 and counts[2] > 5 and g["W"] == int(z["b.W"])
+    check(xs, z["b.xsec"])
+    xs, counts, g, _, _ = device_xsec(ctx, unpack_lines(z, "c.lines"), "co2", 4e-4, 220, 2.0, 650.0, 650.05, 1e-5, False, variant)
+    assert g["W"] == int(z["c.W"])
+    check(xs, z["c.xsec"])
+
+
+@pytest.mark.parametrize("tag,dyn", [("native", False), ("dynamic", True)])
+@pytest.mark.parametrize("variant", [0, 2])
+def test_g5_native_0p001_and_interp(ctx, tag, dyn, variant):
+    z = load_golden("G5_native_0p001")
+    xs, _, g, _, _ = device_xsec(ctx, unpack_lines(z, "lines"), "co2", 4e-4, 296, 1013.25, 650, 660, .001, dyn, variant)
+    assert g["W"] == int(z[tag + ".W"])
+    check(xs, z[tag + ".xsec"])
+
+
+def run_layer(ctx, cfg, orc, surface_T):
+    from pyrad_amd import engine
+    mols = []
+    for mol in cfg["molecules"]:
+        sp = synthetic.SPECIES[mol["species"]]
+        isos = [dict(lines=mol["lines"], molmass=sp["molmass"], q_T=synthetic.q_value(mol["species"], cfg["T"]),
+                     q296=sp["q296"])]
+        if "lines2" in mol:
+            sp2 = synthetic.SPECIES[mol["species"] + "_636"]
+            isos.append(dict(lines=mol["lines2"], molmass=sp2["molmass"],
+                             q_T=synthetic.q_value(mol["species"] + "_636", cfg["T"]), q296=sp2["q296"]))
+        mols.append(dict(conc=orc.concentration(**mol["conc"]), isotopologues=isos))
+    L = engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"], mols,
+                             cfg["base_resolution"], cfg.get("dynamic_resolution", True))
+    L.enqueue(surface_T=surface_T)
+    return L
+
+
+def test_g6_composition_fused_sweep(ctx, orc):
+    z = load_golden("G6_composition")
+    cfg = dict(depth=float(z["depth"]), T=int(z["T"]), P=float(z["P"]), range_min=1000, range_max=1040,
+               base_resolution=.01, dynamic_resolution=True,
+               molecules=[dict(species="co2", conc=dict(ppm=400), lines=unpack_lines(z, "co2.lines"),
+                               lines2=unpack_lines(z, "co2_636.lines")),
+                          dict(species="h2o", conc={"%": 1.5}, lines=unpack_lines(z, "h2o.lines")),
+                          dict(species="ch4", conc=dict(ppb=1800), lines=unpack_lines(z, "ch4.lines"))])
+    L = run_layer(ctx, cfg, orc, 290)
+    r = L.results()
+    check(L.xsec_host(0), z["co2.iso0.xsec"]); check(L.xsec_host(1), z["co2.iso1.xsec"])
+    check(L.xsec_host(2), z["h2o.xsec"]); check(L.xsec_host(3), z["ch4.xsec"])
+    check(r["abs_coef"], z["abs_coef"])
+    check(r["transmittance"], z["transmittance"])
+    check(r["transmission"], z["transmission"])
+    bi = ctx.band_integral(L.I_out, L.n, np.pi, .01)
+    assert bi == pytest.approx(float(z["band_integral"]), rel=1e-12)
+    L.free()
+
+
+def test_g1_sweep_optical_properties_and_planck(ctx, orc):
+    z = load_golden("G1_c1_cell")
+    cfg = dict(depth=float(z["depth"]), T=296, P=1013.25, range_min=600, range_max=700, base_resolution=.01,
+               molecules=[dict(species="co2", conc=dict(ppm=400), lines=unpack_lines(z, "lines"))])
+    L = run_layer(ctx, cfg, orc, 288)
+    r = L.results()
+    check(r["abs_coef"], z["T296.abs_coef"]); check(r["transmittance"], z["T296.transmittance"])
+    check(r["transmission"], z["T296.transmission"])
+    pl = ctx.buffer(L.n)
+    ctx.planck_dev(600, 700, L.n, 288, pl)
+    check(pl.download(), z["planck_surface"], 1e-14)
+    out = ctx.buffer(L.n)
+    ctx.optical_dev(L.trans, L.n, 1, out)
+    assert rel_err(out.download(), z["absorbance"], floor=1e-300) <= 1e-9
+    ctx.optical_dev(L.trans, L.n, 2, out)
+    assert rel_err(out.download(), z["optical_depth"], floor=1e-300) <= 1e-9
+    ctx.optical_dev(L.trans, L.n, 0, out)
+    assert np.array_equal(out.download(), 1 - r["transmittance"])
+    L.free()
+
+
+def test_g7_column_fold(ctx, orc):
+    z = load_golden("G7_column")
+    co2, h2o = unpack_lines(z, "co2.lines"), unpack_lines(z, "h2o.lines")
+    layers = []
+    for i in range(3):
+        cfg = dict(depth=float(z["layer_depth"][i]), T=int(z["layer_T"][i]), P=float(z["layer_P"][i]), range_min=660,
+                   range_max=680, base_resolution=.01, dynamic_resolution=True,
+                   molecules=[dict(species="co2", conc=dict(ppm=400), lines=co2),
+                              dict(species="h2o", conc=dict(percentage=float(z["h2o_perc"][i])), lines=h2o)])
+        layers.append(run_layer(ctx, cfg, orc, 290))
+        check(layers[-1].results()["transmittance"], z["L%d.transmittance" % i])
+    n = layers[0].n
+    out = ctx.buffer(n)
+    ctx.column_sweep_dev([L.trans for L in layers], [L.T for L in layers], 660, 680, n, out, surface_T=290)
+    check(out.download(), z["L2.spectrum"])
+    # chaining single-layer sweeps gives the same thing
+    I = None
+    for i, L in enumerate(layers):
+        L.enqueue_sweep(I_in=I, surface_T=290 if I is None else 0.0)
+        I = L.I_out
+        check(I.download(n), z["L%d.spectrum" % i])
+    assert ctx.band_integral(I, n, np.pi, .01) == pytest.approx(float(z["toa_band_integral"]), rel=1e-12)
+    for L in layers:
+        L.free()
+
+
+def test_oracle_vs_device_c2_slice_and_determinism(ctx, orc):
+    """A slice of the bench workload (C2 shape: 0.001 grid, W = 5000) against the oracle, twice."""
+    cfg = synthetic.config_c2(n_lines=3000, range_min=640, range_max=700, seed=12)
+    mol = cfg["molecules"][0]
+    xs, _, g, sel, _ = device_xsec(ctx, mol["lines"], "co2", 4e-4, 296, 1013.25, 640, 700, .001, False)
+    sp = synthetic.SPECIES["co2"]
+    ref, _ = orc.create_cross_section(sel, 296, 1013.25, 4e-4, sp["molmass"], synthetic.q_value("co2", 296), sp["q296"],
+                                      orc.layer_grid(1013.25, 640, 700, .001, False))
+    check(xs, ref)
+    xs2, _, _, _, _ = device_xsec(ctx, mol["lines"], "co2", 4e-4, 296, 1013.25, 640, 700, .001, False)
+    assert np.array_equal(xs, xs2)          # fixed summation order: bit-identical reruns
+
+
+def test_sharded_equals_unsharded(ctx, orc):
+    """Grid sharded by contiguous range (world 4, every rank on this one GPU): the shards tile
+    the unsharded spectrum bit for bit."""
+    from pyrad_amd import engine
+    cfg = synthetic.config_c2(n_lines=2500, range_min=640, range_max=690, seed=13)
+    mol = cfg["molecules"][0]
+    sp = synthetic.SPECIES["co2"]
+    mols = [dict(conc=4e-4, isotopologues=[dict(lines=mol["lines"], molmass=sp["molmass"],
+                                                q_T=synthetic.q_value("co2", 296), q296=sp["q296"])])]
+    full = engine.ResidentLayer(ctx, 10.0, 296, 1013.25, 640, 690, mols, .001, False)
+    full.enqueue(surface_T=288)
+    ref = full.results()
+    n = full.n
+    got = {k: np.zeros(n) for k in ref}
+    evals = 0
+    for rank in range(4):
+        part = engine.ResidentLayer(ctx, 10.0, 296, 1013.25, 640, 690, mols, .001, False, shard=(4, rank))
+        part.enqueue(surface_T=288)
+        r = part.results()
+        sl = slice(part.first, part.first + part.count)
+        for k in got:
+            got[k][sl] = r[k][sl]
+        evals += part.evals
+        part.free()
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+    assert evals == full.evals
+    full.free()
+
+
+def test_error_paths(ctx):
+    from pyrad_amd import _native as nat, engine
+    g = engine.layer_grid(1013.25, 600, 700, .01, True)
+    lines = synthetic.make_lines(1, 10, 595, 705)
+    bad = dict(lines); bad["nu"] = bad["nu"][::-1].copy()
+    with pytest.raises(nat.LblError) as e:
+        arrs = [np.ascontiguousarray(bad[k]) for k in nat.Lines.ORDER]
+        h = nat._P()
+        ctx.check(ctx.lib.lbl_lines_create(ctx.h, *[nat._ptr(a) for a in arrs], 10, nat.C.byref(h)))
+    assert e.value.code == -1 and "non-decreasing" in str(e.value)
+    iso = nat.IsoParams(296.0, 1013.25, 4e-4, 44.0, 286.0, 286.0)
+    gz = engine.native_grid(dict(g, W=0))
+    with pytest.raises(nat.LblError):
+        ctx.xsec_accumulate(lines, iso, gz)          # W = 0: the reference raises IndexError (cls:393)
+    xs, counts = ctx.xsec_accumulate({k: v[:0] for k, v in lines.items()}, iso, engine.native_grid(g))
+    assert xs.shape == (g["n_base"],) and not xs.any() and counts == (0, 0, 0)   # empty line list
