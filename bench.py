@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""bench.py — line x grid-point evaluations per second of the MI355X line-by-line engine.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path over one batch of synthetic input already resident in
+HBM: per-line preparation (K1), owner-computes accumulation of every line onto the
+wavenumber grid (K2), the fused absorption-coefficient / transmittance / Planck-emission
+sweep (K4) and, for N > 1, the single RCCL all-gather of the per-rank spectrum shards.
+
+Workload at N = 1: BASELINE.json configs[1] — CO2, 500-900 cm^-1 at 0.001 cm^-1 (4e5 grid
+points, W = 5000), 65,536 seeded synthetic lines, 1013.25 mbar, 296 K (SURVEY.md §8d "C2").
+For N > 1 the wavenumber grid is sharded by contiguous range and grows with N (weak
+scaling): N x 400 cm^-1, N x 65,536 lines, every rank owns 4e5 grid points.
+
+Rank 0 prints ONE JSON line.  `value` = exact (line, grid-point) contributions of the
+reference's scatter loop (pyradClasses.py:392-400) summed over all ranks and steps / the
+max-over-ranks wall time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_VALU_PEAK_INSTR = 256 * 4 * 16 * 2.4e9     # fp64 lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz
+FP64_INSTR_PER_EVAL = 5.0        # running-fraction Lorentz inner loop: add, fma, mul, fma, mul
+
+
+def build_workload(workload: str, world: int):
+    from pyrad_amd import synthetic
+    if workload == "C2":
+        rmin, rmax = 500, 500 + 400 * world
+        cfg = synthetic.config_c2(n_lines=65536 * world, range_min=rmin, range_max=rmax, seed=2)
+        desc = "CO2 %d-%d cm^-1 @0.001, %d lines, 1013.25 mbar, 296 K, 10 cm (C2 shape%s)" % (
+            rmin, rmax, 65536 * world, "" if world == 1 else ", grid sharded x%d" % world)
+    elif workload == "C3":
+        rmin, rmax = 100, 100 + 2400 * world
+        cfg = synthetic.config_c3(n_lines=131072 * world, range_min=rmin, range_max=rmax)
+        desc = "CO2+H2O+CH4 %d-%d cm^-1 @0.001, 3x%d lines, 1013.25 mbar, 296 K (C3 shape)" % (rmin, rmax, 131072 * world)
+    elif workload == "C1":
+        cfg = synthetic.config_c1()
+        desc = "CO2 600-700 cm^-1 @0.01, 4096 lines (C1, the reference's own CPU-runnable case)"
+    else:
+        raise SystemExit("unknown workload %s" % workload)
+    return cfg, desc
+
+
+def molecules_of(cfg):
+    """config dict -> ResidentLayer molecule descriptions (host logic only)."""
+    from pyrad_amd import synthetic
+    from pyrad_amd.model import concentration_from_kwargs
+    mols = []
+    for mol in cfg["molecules"]:
+        sp = synthetic.SPECIES[mol["species"]]
+        mols.append(dict(conc=concentration_from_kwargs(**mol["conc"]),
+                         isotopologues=[dict(lines=mol["lines"], molmass=sp["molmass"],
+                                             q_T=synthetic.q_value(mol["species"], cfg["T"]), q296=sp["q296"])]))
+    return mols
+
+
+def cpu_baseline(cfg, seconds_target=15.0):
+    """Time the faithful scalar restatement of the reference's hot loop (oracle, kind 'port')
+    on one host core, on a bounded sample of the same workload; plus the plain-C oracle."""
+    from oracle import pyrad_oracle as orc
+    from oracle import c_oracle
+    from pyrad_amd import synthetic
+    mol = cfg["molecules"][0]
+    sp = synthetic.SPECIES[mol["species"]]
+    grid = orc.layer_grid(cfg["P"], cfg["range_min"], cfg["range_max"], cfg["base_resolution"],
+                          cfg.get("dynamic_resolution", True))
+    conc = orc.concentration(**mol["conc"])
+    lines = orc.select_window(mol["lines"], grid["eff_min"], grid["eff_max"])
+    qT = synthetic.q_value(mol["species"], cfg["T"])
+    # calibrate on a handful of lines, then size the sample for ~seconds_target
+    rng = np.random.default_rng(0)
+    pick = np.sort(rng.choice(len(lines["nu"]), size=min(40, len(lines["nu"])), replace=False))
+    sub = {k: v[pick] for k, v in lines.items()}
+    t0 = time.perf_counter()
+    orc.create_cross_section_scalar(sub, cfg["T"], cfg["P"], conc, sp["molmass"], qT, sp["q296"], grid, regrid=False)
+    dt = time.perf_counter() - t0
+    n_sample = int(max(40, min(len(lines["nu"]), len(pick) * seconds_target / max(dt, 1e-6))))
+    pick = np.sort(rng.choice(len(lines["nu"]), size=n_sample, replace=False))
+    sub = {k: v[pick] for k, v in lines.items()}
+    lq = orc.line_quantities(sub, cfg["T"], cfg["P"], conc, sp["molmass"], grid["range_min"], grid["resolution"])
+    evals = orc.eval_count(lq["index"], grid["W"], grid["n_work"])
+    t0 = time.perf_counter()
+    xs_py, _ = orc.create_cross_section_scalar(sub, cfg["T"], cfg["P"], conc, sp["molmass"], qT, sp["q296"], grid,
+                                               regrid=False)
+    t_py = time.perf_counter() - t0
+    # plain C port of the same loop on a larger sample (about 2 s)
+    n_c = int(min(len(lines["nu"]), max(n_sample, 4000)))
+    pick_c = np.sort(rng.choice(len(lines["nu"]), size=n_c, replace=False))
+    sub_c = {k: v[pick_c] for k, v in lines.items()}
+    t0 = time.perf_counter()
+    _, _, evals_c = c_oracle.create_cross_section_work(sub_c, cfg["T"], cfg["P"], conc, sp["molmass"], qT, sp["q296"], grid)
+    t_c = time.perf_counter() - t0
+    return {
+        "value": evals / t_py, "unit": "line*gridpoint evals/s", "cores": 1, "kind": "port",
+        "sample": "%d of %d lines drawn uniformly (seed 0) from the bench workload, %d evals in %.1f s; faithful "
+                  "Python/NumPy scalar restatement of pyradClasses.py:361-400 (oracle.create_cross_section_scalar); "
+                  "host has %d logical cores, 1 used (the reference is single-threaded)" % (
+                      n_sample, len(lines["nu"]), evals, t_py, os.cpu_count() or 0),
+        "c_port_value": evals_c / t_c,
+        "c_port_sample": "plain-C restatement (oracle/lbl_oracle.c, gcc -O2, 1 core): %d lines, %d evals in %.2f s" % (
+            n_c, evals_c, t_c),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3"])
+    ap.add_argument("--variant", type=int, default=None, help="accumulate kernel variant 0|1|2 (default: library default)")
+    ap.add_argument("--points-per-lane", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--gather", default="abs_coef", choices=["abs_coef", "all"])
+    ap.add_argument("--check", action="store_true", help="also compare one shard against the oracle (slow)")
+    args = ap.parse_args()
+
+    from pyrad_amd import _native as nat, engine, dist
+    rank, local_rank, world = dist.env_world()
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d"
+                  % (args.gpus, world, args.gpus), file=sys.stderr)
+        if world == 1:
+            raise SystemExit(2)
+    ndev = nat.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
+    ctx = nat.Context(local_rank if local_rank < ndev else 0)
+    info = ctx.device_info()
+    if args.variant is not None:
+        ctx.set_option("accum_variant", args.variant)
+    if args.points_per_lane is not None:
+        ctx.set_option("accum_points_per_lane", args.points_per_lane)
+
+    comm = None
+    rdzv = None
+    if world > 1:
+        rdzv = dist.FileRendezvous(rank, world)
+        uid = rdzv.broadcast("rccl_unique_id", nat.Comm.unique_id() if rank == 0 else None)
+        comm = nat.Comm(ctx, uid, world, rank)
+
+    cfg, desc = build_workload(args.workload, world)
+    t_setup = time.perf_counter()
+    layer = engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"],
+                                 molecules_of(cfg), cfg["base_resolution"], cfg.get("dynamic_resolution", True),
+                                 shard=(world, rank) if world > 1 else None)
+    ctx.sync()
+    t_setup = time.perf_counter() - t_setup
+
+    # small device buffers for the RCCL barrier / max-over-ranks reduction
+    red = ctx.buffer(max(world, 1))
+    gather_bufs = (layer.abs_coef,) if args.gather == "abs_coef" else (layer.abs_coef, layer.trans, layer.I_out)
+
+    def barrier():
+        if comm is not None:
+            comm.allgather_dev(red, rank, 1, red)
+        ctx.sync()
+
+    def step():
+        layer.enqueue(surface_T=288.0)
+        if comm is not None:
+            layer.enqueue_allgather(comm, gather_bufs)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+
+    # max over ranks of the elapsed time, sum over ranks of the evals — through the one comm
+    evals_local = float(layer.evals)
+    if comm is not None:
+        red.upload(np.array([elapsed], dtype=np.float64), offset=rank)
+        comm.allgather_dev(red, rank, 1, red)
+        times = red.download(world)
+        red.upload(np.array([evals_local], dtype=np.float64), offset=rank)
+        comm.allgather_dev(red, rank, 1, red)
+        evals_all = red.download(world)
+        elapsed_max = float(times.max())
+        evals_total = float(evals_all.sum())
+    else:
+        elapsed_max, evals_total = elapsed, evals_local
+
+    result = None
+    if rank == 0:
+        value = evals_total * args.steps / elapsed_max
+        n_acc, ms_acc = prof["xsec_accumulate"]
+        n_sw, ms_sw = prof["layer_sweep"]
+        n_prep, ms_prep = prof["line_prep"]
+        n_ag, ms_ag = prof["allgather"]
+        g = layer.g
+        pts = layer.count if world > 1 else g["n_work"]
+        # algorithmic bytes per launch of the dominant kernel: every line's 7 fp64
+        # HITRAN fields once + every grid point written once
+        balg_acc = 56.0 * layer.n_lines + 8.0 * pts
+        t_acc = (ms_acc / max(n_acc, 1)) * 1e-3
+        achieved = balg_acc / t_acc / 1e9 if t_acc > 0 else 0.0
+        n_mol_arrays = len(layer.jobs)
+        balg_sw = 8.0 * pts * (n_mol_arrays + 3)           # M xsec reads + k, T, I_out writes (I_in computed in-kernel)
+        t_sw = (ms_sw / max(n_sw, 1)) * 1e-3
+        pmc = load_pmc_traffic()
+        result = {
+            "metric": "line*gridpoint evals/sec (whole job)", "value": value, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "grid_points_per_gpu": int(pts), "lines_per_gpu": int(layer.n_lines),
+                       "window_W": int(g["W"]), "evals_per_step": evals_total, "parallelism": "grid-range x%d" % world,
+                       "gathered": args.gather, "device": info["name"]},
+            "roofline": {"bound": "hbm", "kernel": "xsec_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc.get("xsec_accumulate_kernel"),
+                         "algorithmic_bytes_per_launch": balg_acc, "avg_launch_ms": t_acc * 1e3, "launches": n_acc,
+                         "note": "compulsory traffic only (56 B/line + 8 B/grid point): this kernel is fp64-VALU "
+                                 "bound by construction (SURVEY.md §8d), see valu_f64"},
+            "valu_f64": {"instr_per_eval": FP64_INSTR_PER_EVAL,
+                         "achieved_lane_instr_per_s": FP64_INSTR_PER_EVAL * evals_local / t_acc if t_acc > 0 else 0.0,
+                         "peak_lane_instr_per_s": FP64_VALU_PEAK_INSTR,
+                         "frac": (FP64_INSTR_PER_EVAL * evals_local / t_acc / FP64_VALU_PEAK_INSTR) if t_acc > 0 else 0.0,
+                         "kernel_evals_per_s": evals_local / t_acc if t_acc > 0 else 0.0},
+            "roofline_sweep": {"bound": "hbm", "kernel": "layer_sweep_kernel",
+                               "achieved": balg_sw / t_sw / 1e9 if t_sw > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": (balg_sw / t_sw / 1e9 / HBM_PEAK_GBS) if t_sw > 0 else 0.0,
+                               "traffic": pmc.get("layer_sweep_kernel"),
+                               "algorithmic_bytes_per_launch": balg_sw, "avg_launch_ms": t_sw * 1e3, "launches": n_sw},
+            "kernel_ms_per_step": {"line_prep": ms_prep / args.steps, "xsec_accumulate": ms_acc / args.steps,
+                                   "layer_sweep": ms_sw / args.steps, "allgather": ms_ag / args.steps},
+            "setup_s": t_setup,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        if args.check:
+            result["check"] = oracle_check(layer, cfg)
+    if rdzv is not None:
+        rdzv.arrive("done")
+        rdzv.cleanup()
+    if comm is not None:
+        comm.free()
+    layer.free()
+    red.free()
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json,
+    produced by profiles/collect.sh on the GPU box; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950).  Missing file -> traffic null."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if not os.path.isfile(path):
+        return {}
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch", {})
+    except (OSError, ValueError):
+        return {}
+
+
+def oracle_check(layer, cfg):
+    from oracle import pyrad_oracle as orc
+    ref = orc.layer_properties(cfg)
+    got = layer.results()
+    first, count = (layer.first, layer.count) if layer.world > 1 else (0, layer.n)
+    sl = slice(first, first + count)
+    a, b = got["abs_coef"][sl], ref["abs_coef"][sl]
+    return {"max_rel_err_abs_coef": float(np.max(np.abs(a - b) / np.abs(b)))}
+
+
+if __name__ == "__main__":
+    main()

@@ -100,6 +100,15 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "accum_points_per_lane"  0 (auto) | 1 | 2 | 4 | 8 */
 int lbl_set_option(lbl_ctx* ctx, const char* key, int value);
 
+/* Kernel timing with HIP events recorded on the context stream around every launch of a
+ * kernel class (the stream the kernels run on; torch.cuda.Event would not see it).
+ * kind: 0 line_prep, 1 xsec_accumulate, 2 regrid, 3 layer_sweep, 4 column_sweep, 5 all-gather.
+ * lbl_profile_read drains the stream, returns the number of launches recorded since the last
+ * reset and their summed duration in milliseconds. */
+int lbl_profile_enable(lbl_ctx* ctx, int on);
+int lbl_profile_read(lbl_ctx* ctx, int kind, int64_t* launches, double* total_ms);
+int lbl_profile_reset(lbl_ctx* ctx);
+
 /* ---- device buffers (float64) ------------------------------------------------------- */
 int lbl_buffer_create(lbl_ctx* ctx, int64_t n, lbl_buffer** out);
 int lbl_buffer_destroy(lbl_buffer* buf);
@@ -175,6 +184,10 @@ int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const* trans, c
  * 596-606, 718-732): kind 0 emissivity/emittance = 1 - T; 1 absorbance = log10(1/T);
  * 2 optical depth = -ln T. */
 int lbl_optical_dev(lbl_ctx* ctx, lbl_buffer* trans, int64_t n, int kind, lbl_buffer* out);
+
+/* out[j] = 0 + in[0][j] + in[1][j] + ... in list order: the aggregation of
+ * Molecule.createCrossSection / Layer.createCrossSection (pyradClasses.py:566-571, 684-689). */
+int lbl_sum_dev(lbl_ctx* ctx, int n_in, lbl_buffer* const* in, int64_t n, lbl_buffer* out);
 
 /* Planck radiance on the layer axis (pyradPlanck.py:38-44 via pyradClasses.py:781-782). */
 int lbl_planck_dev(lbl_ctx* ctx, double range_min, double range_max, int64_t n, double T,

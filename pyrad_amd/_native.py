@@ -59,6 +59,9 @@ SIGNATURES = {
     "lbl_ctx_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "lbl_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "lbl_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "lbl_profile_enable": (C.c_int, [_P, C.c_int]),
+    "lbl_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), _D]),
+    "lbl_profile_reset": (C.c_int, [_P]),
     "lbl_buffer_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "lbl_buffer_destroy": (C.c_int, [_P]),
     "lbl_buffer_size": (C.c_int, [_P, C.POINTER(C.c_int64)]),
@@ -81,6 +84,7 @@ SIGNATURES = {
     "lbl_column_sweep_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), _D, C.c_double, C.c_double, C.c_int64,
                                        C.c_int64, C.c_int64, _P, C.c_double, _P]),
     "lbl_optical_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "lbl_sum_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.c_int64, _P]),
     "lbl_planck_dev": (C.c_int, [_P, C.c_double, C.c_double, C.c_int64, C.c_double, _P]),
     "lbl_band_integral": (C.c_int, [_P, _P, C.c_int64, C.c_double, C.c_double, _D]),
     "lbl_line_survey_dev": (C.c_int, [_P, _P, C.POINTER(Grid), _P]),
@@ -192,6 +196,25 @@ class Context:
     def set_option(self, key: str, value: int):
         self.check(self.lib.lbl_set_option(self.h, key.encode(), int(value)))
 
+    PROFILE_KINDS = {"line_prep": 0, "xsec_accumulate": 1, "regrid": 2, "layer_sweep": 3, "column_sweep": 4,
+                     "allgather": 5}
+
+    def profile_enable(self, on=True):
+        self.check(self.lib.lbl_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self.check(self.lib.lbl_profile_reset(self.h))
+
+    def profile_read(self) -> dict:
+        """{kernel class: (launches, total_ms)} measured with HIP events on the context stream."""
+        out = {}
+        for name, kind in self.PROFILE_KINDS.items():
+            n = C.c_int64()
+            ms = C.c_double()
+            self.check(self.lib.lbl_profile_read(self.h, kind, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out
+
     # -- objects -------------------------------------------------------------------------
     def buffer(self, n: int, data=None) -> "Buffer":
         b = Buffer(self, n)
@@ -204,7 +227,12 @@ class Context:
 
     # -- hot path ------------------------------------------------------------------------
     def xsec_accumulate(self, lines: dict, iso: IsoParams, grid: Grid):
-        """One-shot host in / host out (lbl_xsec_accumulate). Returns (xsec, regime_counts)."""
+        """One-shot host in / host out (lbl_xsec_accumulate). Returns (xsec, regime_counts).
+        The C entry point wants nu non-decreasing; an unsorted list is sorted here (stable)."""
+        nu = _as_f64(lines["nu"])
+        if nu.size > 1 and np.any(np.diff(nu) < 0):
+            order = np.argsort(nu, kind="stable")
+            lines = {k: np.asarray(lines[k])[order] for k in Lines.ORDER}
         arrs = [_as_f64(lines[k]) for k in Lines.ORDER]
         out = np.empty(int(grid.n_base), dtype=np.float64)
         counts = (C.c_int64 * 3)()
@@ -256,6 +284,11 @@ class Context:
         self.check(self.lib.lbl_column_sweep_dev(self.h, nl, Tb, TT, float(range_min), float(range_max), int(n),
                                                  int(first), int(count),
                                                  I_in.h if I_in is not None else None, float(surface_T), I_out.h))
+
+    def sum_dev(self, bufs, n, out):
+        k = len(bufs)
+        B = (_P * max(k, 1))(*[b.h for b in bufs])
+        self.check(self.lib.lbl_sum_dev(self.h, k, B, int(n), out.h))
 
     def optical_dev(self, trans, n, kind, out):
         self.check(self.lib.lbl_optical_dev(self.h, trans.h, int(n), int(kind), out.h))

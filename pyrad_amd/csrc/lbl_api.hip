@@ -19,6 +19,9 @@ using namespace lbl;
 // ----------------------------------------------------------------------------------------
 // objects
 // ----------------------------------------------------------------------------------------
+constexpr int kProfileKinds = 6;
+enum { PROF_PREP = 0, PROF_ACCUM = 1, PROF_REGRID = 2, PROF_SWEEP = 3, PROF_COLUMN = 4, PROF_GATHER = 5 };
+
 struct DeviceArena {      // grow-only device scratch
     void* ptr = nullptr;
     size_t cap = 0;
@@ -44,6 +47,10 @@ struct lbl_ctx {
     int accum_variant = 2;   // 0: IEEE divide + exp per point; 1: running fraction; 2: + Gaussian recurrence
     int accum_R = 0;         // 0 = choose per launch
     int live_objects = 0;
+    // event timing (lbl_profile_*)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;                       // idle events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_rec[kProfileKinds];
 };
 
 struct lbl_buffer {
@@ -88,6 +95,27 @@ static int arena_reserve(lbl_ctx* ctx, DeviceArena& a, size_t bytes) {
     HIP_TRY(ctx, hipMalloc(&a.ptr, want));
     a.cap = want;
     return LBL_OK;
+}
+
+// RAII-free scoped timer: prof_begin records the start event, prof_end the stop event.
+static hipEvent_t prof_event(lbl_ctx* ctx) {
+    hipEvent_t e = nullptr;
+    if (!ctx->ev_pool.empty()) { e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+static hipEvent_t prof_begin(lbl_ctx* ctx) {
+    if (!ctx->profiling) return nullptr;
+    hipEvent_t e = prof_event(ctx);
+    if (e) (void)hipEventRecord(e, ctx->stream);
+    return e;
+}
+static void prof_end(lbl_ctx* ctx, int kind, hipEvent_t start) {
+    if (!start) return;
+    hipEvent_t e = prof_event(ctx);
+    if (!e) { ctx->ev_pool.push_back(start); return; }
+    (void)hipEventRecord(e, ctx->stream);
+    ctx->ev_rec[kind].emplace_back(start, e);
 }
 
 // Pinned staging for descriptors that a later hipMemcpyAsync reads: bump-allocated from a
@@ -172,12 +200,14 @@ extern "C" int lbl_ctx_create(int device, lbl_ctx** out) {
 extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) {
     if (!ctx) return LBL_OK;
     if (ctx->live_objects != 0) return fail(ctx, LBL_ERR_STATE, "%d device objects still alive", ctx->live_objects);
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& v : ctx->ev_rec) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     DeviceArena* arenas[] = {&ctx->recs, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->red};
-    for (DeviceArena* a : arenas) if (a->ptr) hipFree(a->ptr);
-    if (ctx->host_stage) hipHostFree(ctx->host_stage);
-    hipStreamDestroy(ctx->stream);
+    for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
+    if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return LBL_OK;
 }
@@ -205,6 +235,43 @@ extern "C" int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
     return LBL_OK;
 }
+
+extern "C" int lbl_profile_enable(lbl_ctx* ctx, int on) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    ctx->profiling = on != 0;
+    return LBL_OK;
+}
+
+extern "C" int lbl_profile_reset(lbl_ctx* ctx) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& v : ctx->ev_rec) {
+        for (auto& p : v) { ctx->ev_pool.push_back(p.first); ctx->ev_pool.push_back(p.second); }
+        v.clear();
+    }
+    return LBL_OK;
+}
+
+extern "C" int lbl_profile_read(lbl_ctx* ctx, int kind, int64_t* launches, double* total_ms) {
+    if (!ctx || !launches || !total_ms) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    if (kind < 0 || kind >= kProfileKinds) return fail(ctx, LBL_ERR_BAD_ARG, "kind out of range");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (auto& p : ctx->ev_rec[kind]) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, p.first, p.second));
+        tot += ms;
+    }
+    *launches = (int64_t)ctx->ev_rec[kind].size();
+    *total_ms = tot;
+    return LBL_OK;
+}
+
+// hook for lbl_comm.hip: time the all-gather like any other kernel class
+namespace lbl {
+void* comm_prof_begin(lbl_ctx* ctx) { return (void*)prof_begin(ctx); }
+void comm_prof_end(lbl_ctx* ctx, void* start) { prof_end(ctx, PROF_GATHER, (hipEvent_t)start); }
+}  // namespace lbl
 
 // Tuning knobs for benchmarking and A/B parity runs (not part of the reference surface):
 //   "accum_variant" 0 | 1 | 2,  "accum_points_per_lane" 0 (auto) | 1 | 2 | 4 | 8
@@ -234,7 +301,7 @@ extern "C" int lbl_buffer_create(lbl_ctx* ctx, int64_t n, lbl_buffer** out) {
     double* d = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d, (size_t)std::max<int64_t>(n, 1) * sizeof(double)));
     lbl_buffer* b = new (std::nothrow) lbl_buffer{ctx, d, n};
-    if (!b) { hipFree(d); return fail(ctx, LBL_ERR_OOM, "host allocation failed"); }
+    if (!b) { (void)hipFree(d); return fail(ctx, LBL_ERR_OOM, "host allocation failed"); }
     ctx->live_objects++;
     *out = b;
     return LBL_OK;
@@ -321,12 +388,12 @@ extern "C" int lbl_lines_create(lbl_ctx* ctx, const double* nu, const double* sw
     for (int k = 0; k < 7 && n_lines > 0; ++k) {
         hipError_t e = hipMemcpyAsync(d + (size_t)k * n_lines, src[k], (size_t)n_lines * sizeof(double),
                                       hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) { hipFree(d); return fail(ctx, LBL_ERR_HIP, "line upload: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, LBL_ERR_HIP, "line upload: %s", hipGetErrorString(e)); }
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { hipFree(d); return fail(ctx, LBL_ERR_HIP, "line upload: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, LBL_ERR_HIP, "line upload: %s", hipGetErrorString(e)); }
     lbl_lines* L = new (std::nothrow) lbl_lines{ctx, d, n_lines};
-    if (!L) { hipFree(d); return fail(ctx, LBL_ERR_OOM, "host allocation failed"); }
+    if (!L) { (void)hipFree(d); return fail(ctx, LBL_ERR_OOM, "host allocation failed"); }
     ctx->live_objects++;
     *out = L;
     return LBL_OK;
@@ -433,16 +500,22 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     AccumJob* da = (AccumJob*)((char*)ctx->jobs.ptr + prep_bytes);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->jobs.ptr, stage, prep_bytes + acc_bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->counts.ptr, 0, (size_t)n_jobs * 3 * sizeof(unsigned long long), ctx->stream));
+    hipEvent_t ev = prof_begin(ctx);
     launch_line_prep(dp, n_jobs, max_lines, ctx->stream);
+    prof_end(ctx, PROF_PREP, ev);
     HIP_TRY(ctx, hipGetLastError());
     ctx->last_jobs = n_jobs;
     if (prep_only) return LBL_OK;
+    ev = prof_begin(ctx);
     launch_accumulate(da, n_jobs, max_tiles, R, ctx->accum_variant, ctx->stream);
+    prof_end(ctx, PROF_ACCUM, ev);
     HIP_TRY(ctx, hipGetLastError());
     for (int j = 0; j < n_jobs; ++j) {
         if (!needs_regrid(grid[j])) continue;
+        ev = prof_begin(ctx);
         launch_regrid((const double*)ctx->work.ptr + work_off[j], grid[j].n_work, out_dev[j], grid[j].n_base,
                       grid[j].range_min, grid[j].range_max, ctx->stream);
+        prof_end(ctx, PROF_REGRID, ev);
         HIP_TRY(ctx, hipGetLastError());
     }
     return LBL_OK;
@@ -522,9 +595,9 @@ extern "C" int lbl_line_quantities(lbl_ctx* ctx, lbl_lines* lines, const lbl_iso
         if (e == hipSuccess && regime) e = hipMemcpyAsync(regime, dbg.regime, 4 * n, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     } else {
-        hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
     }
-    hipFree(d);
+    (void)hipFree(d);
     if (rc) return rc;
     if (e != hipSuccess) return fail(ctx, LBL_ERR_HIP, "line_quantities: %s", hipGetErrorString(e));
     return LBL_OK;
@@ -585,7 +658,9 @@ extern "C" int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* x
     a.I_out = I_out ? I_out->d : nullptr;
     a.n = n; a.first = first; a.count = count;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipEvent_t ev = prof_begin(ctx);
     launch_layer_sweep(a, ctx->stream);
+    prof_end(ctx, PROF_SWEEP, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
 }
@@ -623,7 +698,29 @@ extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* cons
     a->n = n; a->first = first; a->count = count;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->jobs.ptr, a, sizeof(ColumnArgs), hipMemcpyHostToDevice, ctx->stream));
+    hipEvent_t ev = prof_begin(ctx);
     launch_column_sweep((const ColumnArgs*)ctx->jobs.ptr, count, ctx->stream);
+    prof_end(ctx, PROF_COLUMN, ev);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBL_OK;
+}
+
+extern "C" int lbl_sum_dev(lbl_ctx* ctx, int n_in, lbl_buffer* const* in, int64_t n, lbl_buffer* out) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (n_in < 0 || n_in > kMaxIso) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d inputs", kMaxIso);
+    if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
+    if (n_in > 0 && !in) return fail(ctx, LBL_ERR_BAD_ARG, "in is NULL");
+    int rc;
+    if ((rc = check_buf(ctx, out, n, "out", true))) return rc;
+    SumArgs a;
+    memset(&a, 0, sizeof a);
+    for (int i = 0; i < n_in; ++i) {
+        if ((rc = check_buf(ctx, in[i], n, "in", true))) return rc;
+        a.in[i] = in[i]->d;
+    }
+    a.n_in = n_in; a.out = out->d; a.n = n;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    launch_sum(a, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
 }

@@ -15,7 +15,12 @@
 extern "C" int lbl_ctx_stream(lbl_ctx* ctx, void** stream);
 extern "C" int lbl_buffer_devptr(lbl_buffer* buf, void** devptr);
 extern "C" int lbl_buffer_size(const lbl_buffer* buf, int64_t* n);
-namespace lbl { int comm_fail(lbl_ctx* ctx, int code, const char* msg); int ctx_device(lbl_ctx* ctx); }
+namespace lbl {
+int comm_fail(lbl_ctx* ctx, int code, const char* msg);
+int ctx_device(lbl_ctx* ctx);
+void* comm_prof_begin(lbl_ctx* ctx);
+void comm_prof_end(lbl_ctx* ctx, void* start);
+}
 
 struct lbl_comm {
     lbl_ctx* ctx;
@@ -56,7 +61,7 @@ extern "C" int lbl_comm_destroy(lbl_comm* comm) {
     if (!comm) return LBL_OK;
     void* s = nullptr;
     lbl_ctx_stream(comm->ctx, &s);
-    hipStreamSynchronize((hipStream_t)s);
+    (void)hipStreamSynchronize((hipStream_t)s);
     ncclCommDestroy(comm->comm);
     delete comm;
     return LBL_OK;
@@ -75,7 +80,9 @@ extern "C" int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_
     lbl_buffer_devptr(send, &ps);
     lbl_buffer_devptr(recv, &pr);
     lbl_ctx_stream(ctx, &s);
+    void* ev = lbl::comm_prof_begin(ctx);
     ncclResult_t r = ncclAllGather((const double*)ps + send_offset, pr, (size_t)count, ncclDouble, comm->comm, (hipStream_t)s);
+    lbl::comm_prof_end(ctx, ev);
     if (r != ncclSuccess) return lbl::comm_fail(ctx, LBL_ERR_RCCL, ncclGetErrorString(r));
     return LBL_OK;
 }

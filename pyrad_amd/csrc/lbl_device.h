@@ -100,6 +100,8 @@ void launch_column_sweep(const ColumnArgs* d_args, long long n, hipStream_t s);
 void launch_planck(double* out, long long n, double start, double stop, double T, double pa, double pb, hipStream_t s);
 int band_partial_count(long long n);
 void launch_band_integral(const double* y, long long n, double* partial, double* result, hipStream_t s);
+struct SumArgs { const double* in[kMaxIso]; int32_t n_in; double* out; long long n; };
+void launch_sum(const SumArgs& a, hipStream_t s);
 void launch_optical(const double* trans, long long n, int kind, double* out, hipStream_t s);
 void launch_line_survey(const double* nu, const double* sw, int n_lines, double range_min, double resolution,
                         double* out, long long n_base, hipStream_t s);

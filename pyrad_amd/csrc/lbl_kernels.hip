@@ -583,6 +583,21 @@ __global__ __launch_bounds__(256) void optical_kernel(const double* __restrict__
     }
 }
 
+// zeros + in[0] + in[1] + ... (pyradClasses.py:566-571, 684-689)
+__global__ __launch_bounds__(256) void sum_kernel(const SumArgs A) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < A.n; j += stride) {
+        double s = 0.0;
+        for (int i = 0; i < A.n_in; ++i) s += A.in[i][j];
+        A.out[j] = s;
+    }
+}
+
+void launch_sum(const SumArgs& a, hipStream_t s) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(sum_kernel, dim3(sweep_blocks(a.n)), dim3(256), 0, s, a);
+}
+
 void launch_optical(const double* trans, long long n, int kind, double* out, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(optical_kernel, dim3(sweep_blocks(n)), dim3(256), 0, s, trans, n, kind, out);

@@ -1,0 +1,193 @@
+"""Line-list sources: where ``Isotope.getData`` gets its HITRAN lines, partition sums and
+molecule parameters from (the role of pyradUtilities.gatherData / getQData / readMolParams,
+ut:173-197, 421-477).  No network code: the reference's HTTP download is out of scope.
+
+Two sources:
+  * ``MemorySource``   — in-memory line lists (synthetic or user supplied);
+  * ``PyradDataDir``   — reader of PyRad's own on-disk cache ``data/<globalIso>/<seg>.pyr``,
+                         ``q<iso>.txt`` and ``params.pyr``, so an
+                         existing PyRad ``data/`` tree is usable as is.
+Lines are handed over as a structure of arrays sorted by wavenumber.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+FIELDS = ("nu", "sw", "a", "elower", "gamma_air", "gamma_self", "delta_air", "n_air")
+NULL_TAG = '#/null/#'          # ut:842 sentinel of a failed download
+
+
+def _empty():
+    return {f: np.zeros(0, dtype=np.float64) for f in FIELDS}
+
+
+class MemorySource:
+    """{global_iso: lines / q table / params} held in memory."""
+
+    def __init__(self):
+        self._lines, self._q, self._params = {}, {}, {}
+
+    def register(self, global_iso: int, lines: dict, q: dict, params: list):
+        order = np.argsort(np.asarray(lines["nu"]), kind="stable")
+        self._lines[global_iso] = {f: np.ascontiguousarray(np.asarray(lines[f], dtype=np.float64)[order])
+                                   for f in FIELDS if f in lines}
+        if "a" not in self._lines[global_iso]:
+            self._lines[global_iso]["a"] = np.zeros_like(self._lines[global_iso]["nu"])
+        self._q[global_iso] = q
+        self._params[global_iso] = list(params)
+
+    def readMolParams(self, global_iso):
+        return list(self._params[global_iso])
+
+    def getQData(self, global_iso):
+        return self._q[global_iso]
+
+    def gatherData(self, global_iso, range_min, range_max):
+        lines = self._lines[global_iso]
+        nu = lines["nu"]
+        m = (nu > range_min) & (nu < range_max)          # strict, ut:437-438
+        sel = {f: v[m] for f, v in lines.items()}
+        return _dedupe_last_wins(sel)
+
+
+def _dedupe_last_wins(lines):
+    """The reference keys its line dict by wavenumber, so a duplicated nu keeps the LAST row's
+    values at the FIRST row's position (ut:447).  Input is sorted by nu (stable)."""
+    nu = lines["nu"]
+    if nu.size < 2 or not np.any(np.diff(nu) == 0):
+        return lines
+    first = np.ones(nu.size, dtype=bool)
+    first[1:] = np.diff(nu) != 0
+    last = np.ones(nu.size, dtype=bool)
+    last[:-1] = np.diff(nu) != 0
+    return {f: v[last] if f != "nu" else v[first] for f, v in lines.items()}
+
+
+class PyradDataDir:
+    """Reader of PyRad's on-disk inputs under ``<root>`` (the reference's ``./data``).
+
+    * ``<root>/<iso>/<seg>.pyr``: CSV rows ``molec_id,local_iso_id,nu,sw,a,elower,gamma_air,
+      gamma_self,delta_air,n_air`` (request_params of ut:369-374; column indices ut:422-430),
+      one file per 100 cm^-1 segment named by its lower edge (ut:175-184); leading ``#`` lines
+      are skipped and a file whose first line carries NULL_TAG is empty (ut:96-101).
+    * ``<root>/<iso>/q<iso>.txt``: whitespace ``T Q`` rows (ut:451-461).
+    * ``<root>/<iso>/params.pyr``: comment lines then one CSV row
+      ``globalIso,shortName,molNum,isoN,abundance,Q296,gj,molMass`` (ut:464-477).
+    A missing segment file is an error here (the reference would try to download it).
+    """
+
+    def __init__(self, root: str):
+        self.root = root
+
+    @staticmethod
+    def _rows(path):
+        """openReturnLines (ut:90-101)."""
+        if not os.path.isfile(path):
+            return None
+        with open(path) as f:
+            rows = f.readlines()
+        if not rows or NULL_TAG in rows[0]:
+            return []
+        while rows[0][0] == '#' and len(rows) > 1:
+            rows.pop(0)
+        return rows
+
+    def readMolParams(self, global_iso):
+        rows = self._rows('%s/%s/params.pyr' % (self.root, global_iso))
+        if not rows:
+            raise FileNotFoundError('%s/%s/params.pyr' % (self.root, global_iso))
+        c = rows[0].split(',')
+        return [int(c[0]), c[1], int(c[2]), int(c[3]), float(c[4]), float(c[5]), int(c[6]), float(c[7])]
+
+    def getQData(self, global_iso):
+        q = {}
+        with open('%s/%s/q%s.txt' % (self.root, global_iso, global_iso)) as f:
+            for row in f:
+                cell = row.split()
+                if cell:
+                    q[int(cell[0])] = float(cell[1])
+        return q
+
+    @staticmethod
+    def segments(range_min, range_max):
+        """Segment lower edges visited by gatherData (ut:175-180)."""
+        out = []
+        segment = int(range_min / 100) * 100
+        while segment < range_max:
+            out.append(segment)
+            segment += 100
+        return out
+
+    def gatherData(self, global_iso, range_min, range_max):
+        info = {}            # nu -> row, insertion ordered, later rows override (ut:447, dict.update ut:187)
+        for segment in self.segments(range_min, range_max):
+            path = '%s/%s/%s.pyr' % (self.root, global_iso, segment)
+            rows = self._rows(path)
+            if rows is None:
+                raise FileNotFoundError("%s (PyRad would download it; this build has no network code)" % path)
+            for row in rows:
+                cell = row.split(',')
+                if len(cell) < 10:
+                    continue
+                nu = float(cell[2])
+                if range_min < nu and nu < range_max:          # ut:437-438
+                    info[nu] = (float(cell[3]), float(cell[4]), float(cell[5]), float(cell[6]), float(cell[7]),
+                                float(cell[8]), float(cell[9]))
+        if not info:
+            return _empty()
+        nu = np.fromiter(info.keys(), dtype=np.float64, count=len(info))
+        vals = np.array(list(info.values()), dtype=np.float64).reshape(len(info), 7)
+        out = {"nu": nu, "sw": vals[:, 0], "a": vals[:, 1], "elower": vals[:, 2], "gamma_air": vals[:, 3],
+               "gamma_self": vals[:, 4], "delta_air": vals[:, 5], "n_air": vals[:, 6]}
+        order = np.argsort(nu, kind="stable")
+        return {k: np.ascontiguousarray(v[order]) for k, v in out.items()}
+
+    # -- writer, so tests and users can materialise a tree in PyRad's format ----------------
+    @staticmethod
+    def write_tree(root, global_iso, lines, q, params, mol_id=0, local_iso=1):
+        d = '%s/%s' % (root, global_iso)
+        os.makedirs(d, exist_ok=True)
+        nu = np.asarray(lines["nu"])
+        if nu.size:
+            for seg in range(int(nu.min() / 100) * 100, int(nu.max()) + 100, 100):
+                m = (nu >= seg) & (nu < seg + 100)
+                with open('%s/%s.pyr' % (d, seg), 'w') as f:
+                    for i in np.nonzero(m)[0]:
+                        f.write('%d,%d,%r,%r,%r,%r,%r,%r,%r,%r\n' % (
+                            mol_id, local_iso, float(nu[i]), float(lines["sw"][i]), float(lines["a"][i]),
+                            float(lines["elower"][i]), float(lines["gamma_air"][i]), float(lines["gamma_self"][i]),
+                            float(lines["delta_air"][i]), float(lines["n_air"][i])))
+        with open('%s/q%s.txt' % (d, global_iso), 'w') as f:
+            for T in sorted(q):
+                f.write('%d %r\n' % (T, float(q[T])))
+        with open('%s/params.pyr' % d, 'w') as f:
+            f.write("#\t#\t#\n# Molecule params for pyrad\n#\t#\t#\n")
+            f.write(','.join(str(x) for x in params) + '\n')
+
+
+_source = None
+
+
+def set_source(source):
+    global _source
+    _source = source
+    return source
+
+
+def get_source():
+    if _source is None:
+        raise RuntimeError("no line-list source: call pyrad_amd.data.set_source(PyradDataDir('data')) "
+                           "or set_source(MemorySource()) first (there is no HITRAN download in this build)")
+    return _source
+
+
+def synthetic_source(species_lines: dict):
+    """MemorySource filled from {species name: lines SoA} using pyrad_amd.synthetic tables."""
+    from . import synthetic
+    src = MemorySource()
+    for species, lines in species_lines.items():
+        sp = synthetic.SPECIES[species]
+        src.register(sp["global_iso"], lines, synthetic.q_table(species), synthetic.mol_params(species))
+    return src

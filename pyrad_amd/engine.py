@@ -11,6 +11,7 @@ import numpy as np
 
 from . import _native as nat
 from . import settings
+from .dist import shard_bounds, halo_select
 
 K_BOLTZMANN = 1.38064852E-23     # pyradClasses.py:16
 PI = 3.141592653589793           # pyradClasses.py:19
@@ -105,15 +106,6 @@ def shutdown():
 # ----------------------------------------------------------------------------------------
 # device-resident gas cell / column (what bench.py and the sharded path drive)
 # ----------------------------------------------------------------------------------------
-def shard_bounds(n: int, world_size: int, rank: int):
-    """Contiguous equal shards of a grid of n points padded to world_size*S:
-    rank r owns [r*S, min((r+1)*S, n)).  Returns (S, first, count)."""
-    S = -(-int(n) // int(world_size))
-    first = min(rank * S, n)
-    count = max(min((rank + 1) * S, n) - first, 0)
-    return S, first, count
-
-
 class ResidentLayer:
     """One layer (gas cell) whose line lists, cross sections and spectra live in HBM.
 
@@ -170,17 +162,8 @@ class ResidentLayer:
             b.fill(0.0)
 
     def _halo_select(self, lines):
-        """Lines whose support can reach this rank's grid range: centre index within
-        W-2 points of [first, first+count) — selected by wavenumber with one extra grid
-        step of slack so that index rounding can never drop a contributing line."""
         g = self.g
-        res = g["resolution"]
-        H = max(g["W"] - 2, 0)
-        lo = g["range_min"] + (self.first - H - 2) * res
-        hi = g["range_min"] + (self.first + self.count + H + 2) * res
-        nu = np.asarray(lines["nu"])
-        m = (nu > lo) & (nu < hi)
-        return {k: np.asarray(v)[m] for k, v in lines.items()}
+        return halo_select(lines, g["range_min"], g["resolution"], g["W"], self.first, self.count)
 
     # -- enqueue ------------------------------------------------------------------------
     def enqueue_xsec(self):

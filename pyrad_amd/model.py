@@ -1,0 +1,902 @@
+"""The Layer / Molecule / Isotope / Line / Atmosphere object model of pyradClasses, kept so
+that PyRad-style drivers (pyradInteractive, main.py) run unchanged on top of the MI355X
+engine.  Names, argument meaning, units, the lazy ``progressCrossSection`` protocol and the
+error behaviour follow the reference; every number comes from the HIP kernels behind
+include/pyrad_hip.h.  There is no CPU fallback: without libpyrad_hip.so or without a GPU the
+first computation raises.
+
+Reference map (cls = pyradClasses.py):
+    Line cls:237-263 · Isotope cls:266-442 · Molecule cls:445-642 · Layer cls:645-787 ·
+    Atmosphere cls:790-821 · getters cls:32-88 · reset protocol cls:38-58 ·
+    converters cls:121-156 · integrateSpectrum cls:26-29 · returnPlot cls:824-839.
+Not carried over (out of scope): measured cross-section ("xsc") molecules,
+the HITRAN download, the curve cache, the interactive menu.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _native as nat
+from . import data as _data
+from . import engine as _engine
+from . import settings
+
+utils = settings          # the reference spells it utils.BASE_RESOLUTION
+
+c = 299792458.0
+k = 1.38064852E-23
+h = 6.62607004e-34
+pi = 3.141592653589793
+t0 = 296
+p0 = 1013.25
+avo = 6.022140857E23
+
+VERSION = settings.VERSION
+VERBOSE = False           # the reference prints progress bars; set True to see the regime line
+
+
+def _say(*a, **kw):
+    if VERBOSE:
+        print(*a, **kw)
+
+
+# ----------------------------------------------------------------------------------------
+# tables (content of cls:951-1022 stored compactly)
+# ----------------------------------------------------------------------------------------
+_MOLECULES = ("h2o co2 o3 n2o co ch4 o2 no so2 no2 nh3 hno3 oh hf hcl hbr hi clo ocs h2co hocl n2 hcn ch3cl "
+              "h2o2 c2h2 c2h6 ph3 cof2 sf6 h2s hcooh ho2 o clono2 no+ hobr c2h4 ch3oh ch3br ch3cn cf4 c4h2 hc3n "
+              "h2 cs so3 c2n2 cocl2").split()
+MOLECULE_ID = {name: i + 1 for i, name in enumerate(_MOLECULES)}
+
+_GLOBAL_ISO_ROWS = (
+    "1 2 3 4 5 6 129|7 8 9 10 11 12 13 14 121 15 120 122|16 17 18 19 20|21 22 23 24 25|26 27 28 29 30 31|"
+    "32 33 34 35|36 37 38|39 40 41|42 43|44|45 46|47 117|48 49 50|51 110|52 53 107 108|19 11 111 112|56 113|"
+    "57 58|59 60 61 62 63|64 65 66|67 68|69 118|70 71 72|73 74|75|76 77 105|78 106|79|80 119|126|81 82 83|84|85|"
+    "86|127 128|87|88 89|90 91|92|93 94|95|96|116|109|103 115|97 98 99 100|114|123|124 125")
+HITRAN_GLOBAL_ISO = {m + 1: {i + 1: int(g) for i, g in enumerate(row.split())}
+                     for m, row in enumerate(_GLOBAL_ISO_ROWS.split("|"))}
+
+COLOR_LIST = ['xkcd:white', 'xkcd:bright orange', 'xkcd:seafoam green', 'xkcd:bright blue', 'xkcd:salmon',
+              'xkcd:light violet', 'xkcd:green yellow']
+EXOTIC_IDS = {}
+
+
+# ----------------------------------------------------------------------------------------
+# module-level helpers (cls:26-162)
+# ----------------------------------------------------------------------------------------
+def _ctx() -> nat.Context:
+    return _engine.get_engine().ctx
+
+
+def integrateSpectrum(spectrum, unitAngle=pi, res=settings.BASE_RESOLUTION):
+    """cls:26-29 on the device (K6): sum(nan_to_num(spectrum)) * unitAngle * res.  Like the
+    reference, the default ``res`` is frozen at import time."""
+    spectrum = np.ascontiguousarray(spectrum, dtype=np.float64)
+    ctx = _ctx()
+    buf = ctx.buffer(max(spectrum.size, 1))
+    try:
+        buf.upload(spectrum)
+        return ctx.band_integral(buf, spectrum.size, unitAngle, res)
+    finally:
+        buf.free()
+
+
+def getCrossSection(obj):
+    if not obj.progressCrossSection:
+        obj.createCrossSection()
+    return obj.crossSection
+
+
+def resetCrossSection(obj):
+    """cls:38-45: marks every Isotope/Molecule below ``obj`` dirty (a Layer itself is skipped)."""
+    if not isinstance(obj, Layer):
+        if not obj.exotic:
+            obj.crossSection = np.zeros(int((obj.rangeMax - obj.rangeMin) / utils.BASE_RESOLUTION))
+            obj.progressCrossSection = False
+    for child in obj:
+        if not isinstance(child, Line):
+            resetCrossSection(child)
+
+
+def resetData(obj):
+    """cls:48-58: drop and reload the line data below ``obj`` (range or pressure changed)."""
+    for child in obj:
+        if isinstance(child, Isotope):
+            child.clear_lines()
+            child.getData()
+        else:
+            resetData(child)
+    resetCrossSection(obj)
+
+
+def getAbsCoef(obj):
+    if not obj.progressCrossSection:
+        obj.createCrossSection()
+    return obj.absCoef
+
+
+def getTransmittance(obj):
+    if not obj.progressCrossSection:
+        obj.createCrossSection()
+    return obj.transmittance
+
+
+def getOpticalDepth(obj):
+    if not obj.progressCrossSection:
+        obj.createCrossSection()
+    return _optical(obj.transmittance, 2)          # -log(transmittance), cls:76
+
+
+def getAbsorbance(obj):
+    if not obj.progressCrossSection:
+        obj.createCrossSection()
+    return obj.absorbance
+
+
+def getEmissivity(obj):
+    if not obj.progressCrossSection:
+        obj.createCrossSection()
+    return obj.emissivity
+
+
+def getGlobalIsotope(ID, isotopeDepth):
+    return [HITRAN_GLOBAL_ISO[ID][i] for i in range(1, isotopeDepth + 1)]
+
+
+def totalConcentration(layer):
+    total = 0
+    for molecule in layer:
+        total += molecule.concentration
+    return total
+
+
+def totalLineList(obj):
+    if isinstance(obj, Isotope):
+        return obj.linelist()
+    fullList = []
+    for item in obj:
+        fullList += totalLineList(item)
+    return fullList
+
+
+def convertLength(value, units):
+    if units == 'cm':
+        return value
+    if units in ['m', 'meter']:
+        return value * 100
+    if units in ['ft', 'feet']:
+        return value * 30.48
+    if units in ['in', 'inch']:
+        return value * 2.54
+
+
+def convertPressure(value, units):
+    if units == 'mbar':
+        return value
+    if units in ['atm', 'atmospheres', 'atmosphere']:
+        return value * 1013.25
+    if units in ['b', 'bar']:
+        return value * 1000
+    if units in ['pa', 'pascal', 'pascals']:
+        return value / 100
+
+
+def convertRange(value, units):
+    if units == 'cm-1':
+        return value
+    if units in ['um', 'micrometers', 'micrometer']:
+        return 10000 / value
+
+
+def convertTemperature(value, units):
+    u = units[0].upper()
+    if u == 'K':
+        return value
+    if u == 'C':
+        return value + 273            # 273, not 273.15 (cls:154)
+    if u == 'F':
+        return (value - 32) * 5 / 9 + 273
+
+
+def interpolateArray(hiResXAxis, loResXAxis, loResYValues):
+    """cls:159-162 (used by the reference only inside createCrossSection, where the device
+    regrid kernel replaces it; kept for callers)."""
+    return np.interp(hiResXAxis, loResXAxis, loResYValues)
+
+
+def isBetween(test, minValue, maxValue):
+    return minValue <= test <= maxValue
+
+
+def concentration_from_kwargs(**abundance):
+    """The volume fraction Molecule.__init__ derives from its keyword (cls:453-463, 543-560),
+    including ppb -> x1e-8 (cls:554)."""
+    conc = 0
+    for key, v in abundance.items():
+        if key == 'ppm':
+            conc = v * 10**-6
+        elif key == 'ppb':
+            conc = v * 10**-8
+        elif key in ('percentage', 'perc', '%'):
+            conc = v / 100
+        elif key == 'concentration':
+            conc = (v * 1E6) * 10**-6
+        else:
+            print('Invalid concentration type. Use ppm, ppb, percentage, or concentration.')
+    return conc
+
+
+# ----------------------------------------------------------------------------------------
+# device helpers
+# ----------------------------------------------------------------------------------------
+def _optical(trans, kind):
+    """emissivity (0) / absorbance (1) / optical depth (2) of a host transmittance array, on the device."""
+    trans = np.ascontiguousarray(trans, dtype=np.float64)
+    ctx = _ctx()
+    a = ctx.buffer(max(trans.size, 1)); b = ctx.buffer(max(trans.size, 1))
+    try:
+        a.upload(trans)
+        ctx.optical_dev(a, trans.size, kind, b)
+        return b.download(trans.size)
+    finally:
+        a.free(); b.free()
+
+
+def _compute_cross_sections(isotopes):
+    """Batched Isotope.createCrossSection (cls:361-407) for every dirty isotopologue in the
+    list: one prep launch + one accumulate launch for all of them."""
+    dirty = [i for i in isotopes if not i.progressCrossSection and not i.exotic]
+    if not dirty:
+        return
+    ctx = _ctx()
+    jobs = []
+    for iso in dirty:
+        layer = iso.layer
+        g = layer._grid()
+        if g["W"] < 1:
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0")     # rightCurve[0], cls:393
+        q_T = iso.q[layer.T]                       # KeyError for a non-integer temperature, as cls:389
+        ip = nat.IsoParams(float(layer.T), float(layer.P), float(iso.molecule.concentration), float(iso.molmass),
+                           float(q_T), float(iso.q296))
+        jobs.append((iso._device_lines(ctx), ip, _engine.native_grid(g), iso._device_xsec(ctx, g["n_base"])))
+    ctx.xsec_accumulate_dev(jobs)
+    counts = ctx.last_regime_counts(len(jobs))
+    for iso, job, cnt in zip(dirty, jobs, counts):
+        iso.crossSection = job[3].download(iso.layer._grid()["n_base"])
+        iso.regimeCounts = tuple(int(x) for x in cnt)
+        _say('\ngaussian only: %s\t lorentz only: %s\t voigt: %s\n' % iso.regimeCounts, end='\r')
+        iso.progressCrossSection = True
+
+
+def _sweep(layer, isotopes_by_molecule, concentrations, I_in=None, want=("abs_coef",)):
+    """Fused sweep (K4) over the given isotopologues; returns the requested host arrays."""
+    ctx = _ctx()
+    g = layer._grid()
+    n = g["n_base"]
+    xs, iso_mol = [], []
+    for m, isos in enumerate(isotopes_by_molecule):
+        for iso in isos:
+            xs.append(iso._device_xsec_current(ctx, n))
+            iso_mol.append(m)
+    bufs = {name: ctx.buffer(max(n, 1)) for name in want}
+    tmp_in = None
+    try:
+        if I_in is not None:
+            I_in = np.ascontiguousarray(I_in, dtype=np.float64)
+            if I_in.shape != (n,):
+                raise ValueError("operands could not be broadcast together with shapes (%d,) %s" % (n, I_in.shape))
+            tmp_in = ctx.buffer(max(n, 1)).upload(I_in)
+        ctx.layer_sweep_dev(xs, iso_mol, concentrations, layer.P, layer.T, layer.depth, layer.rangeMin,
+                            layer.rangeMax, n, I_in=tmp_in, surface_T=0.0,
+                            abs_coef=bufs.get("abs_coef"), trans=bufs.get("trans"), I_out=bufs.get("I_out"))
+        return {name: b.download(n) for name, b in bufs.items()}
+    finally:
+        for b in bufs.values():
+            b.free()
+        if tmp_in is not None:
+            tmp_in.free()
+
+
+class _OpticalMixin:
+    """The property chain shared by Isotope, Molecule and Layer (cls:322-340, 581-606, 707-732,
+    784-787).  ``_sweep_members`` says which isotopologues and concentrations take part."""
+
+    def _sweep_members(self):
+        raise NotImplementedError
+
+    @property
+    def absCoef(self):
+        isos, conc = self._sweep_members()
+        return _sweep(self._layer(), isos, conc, want=("abs_coef",))["abs_coef"]
+
+    @property
+    def transmittance(self):
+        isos, conc = self._sweep_members()
+        return _sweep(self._layer(), isos, conc, want=("trans",))["trans"]
+
+    @property
+    def emissivity(self):
+        return _optical(self.transmittance, 0)
+
+    @property
+    def emittance(self):
+        return self.emissivity
+
+    @property
+    def absorbance(self):
+        return _optical(self.transmittance, 1)
+
+    def planck(self, temperature):
+        return self._layer().planck(temperature)
+
+    def transmission(self, surfaceSpectrum):
+        """transmittance * surfaceSpectrum + emittance * planck(T)  (cls:784-787)."""
+        isos, conc = self._sweep_members()
+        return _sweep(self._layer(), isos, conc, I_in=surfaceSpectrum, want=("I_out",))["I_out"]
+
+
+# ----------------------------------------------------------------------------------------
+# Line (cls:237-263)
+# ----------------------------------------------------------------------------------------
+class Line:
+    def __init__(self, wavenumber, intensity, einsteinA, airHalfWidth,
+                 selfHalfWidth, lowerEnergy, tempExponent, pressureShift, parent):
+        self.isotope = parent
+        self.molecule = self.isotope.molecule
+        self.layer = self.molecule.layer
+        self.wavenumber = wavenumber
+        self.intensity = intensity
+        self.einsteinA = einsteinA
+        self.airHalfWidth = airHalfWidth
+        self.selfHalfWidth = selfHalfWidth
+        self.lowerEnergy = lowerEnergy
+        self.tempExponent = tempExponent
+        self.pressureShift = pressureShift
+
+    # introspection only: the device computes these per line in K1 (lbl_line_quantities)
+    @property
+    def broadenedLine(self):
+        return self.wavenumber + self.pressureShift * self.layer.P / p0
+
+    @property
+    def lorentzHW(self):
+        return (float((1 - self.molecule.concentration) * self.airHalfWidth + self.molecule.concentration
+                      * self.selfHalfWidth) * (self.layer.P / p0) * (t0 / self.layer.T) ** self.tempExponent)
+
+    @property
+    def gaussianHW(self):
+        return self.broadenedLine * math.sqrt(2 * k * self.layer.T / self.isotope.molMass / c ** 2)
+
+
+# ----------------------------------------------------------------------------------------
+# Isotope (cls:266-442): a list of Line, stored as a structure of arrays
+# ----------------------------------------------------------------------------------------
+class Isotope(_OpticalMixin, list):
+    _FIELDS = ("nu", "sw", "a", "gamma_air", "gamma_self", "elower", "n_air", "delta_air")
+
+    def __init__(self, number, molecule):
+        super().__init__()
+        self.molecule = molecule
+        self.layer = self.molecule.layer
+        self.crossSection = np.copy(self.layer.crossSection)
+        self.exotic = molecule.exotic
+        self._lines = {f: np.zeros(0) for f in self._FIELDS}
+        self._dev_lines = None
+        self._dev_xsec = None
+        self._dev_xsec_valid = False
+        self.regimeCounts = (0, 0, 0)
+        if number not in EXOTIC_IDS:
+            params = _data.get_source().readMolParams(number)
+            self.globalIsoNumber = params[0]
+            self.shortName = params[1]
+            self.name = 'Isotope %s' % self.globalIsoNumber
+            self.molNum = params[2]
+            self.isoN = params[3]
+            self.abundance = params[4]
+            self.q296 = params[5]
+            self.gj = params[6]
+            self.molmass = params[7]
+            self.q = {}
+            self.lineSurvey = np.zeros(int((self.layer.rangeMax - self.layer.rangeMin) / utils.BASE_RESOLUTION))
+            self.progressCrossSection = False
+
+    # -- list protocol over the SoA ------------------------------------------------------
+    def __len__(self):
+        return int(self._lines["nu"].size)
+
+    def __bool__(self):
+        return True
+
+    def _line(self, i):
+        L = self._lines
+        return Line(float(L["nu"][i]), float(L["sw"][i]), float(L["a"][i]), float(L["gamma_air"][i]),
+                    float(L["gamma_self"][i]), float(L["elower"][i]), float(L["n_air"][i]),
+                    float(L["delta_air"][i]), self)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self._line(i)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._line(j) for j in range(*i.indices(len(self)))]
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("list index out of range")
+        return self._line(i)
+
+    def append(self, line):
+        vals = (line.wavenumber, line.intensity, line.einsteinA, line.airHalfWidth, line.selfHalfWidth,
+                line.lowerEnergy, line.tempExponent, line.pressureShift)
+        for f, v in zip(self._FIELDS, vals):
+            self._lines[f] = np.append(self._lines[f], float(v))
+        self._invalidate_lines()
+
+    def pop(self, index=-1):
+        line = self[index]
+        n = len(self)
+        keep = np.ones(n, dtype=bool)
+        keep[index] = False
+        self._lines = {f: v[keep] for f, v in self._lines.items()}
+        self._invalidate_lines()
+        return line
+
+    def clear_lines(self):
+        self._lines = {f: np.zeros(0) for f in self._FIELDS}
+        self._invalidate_lines()
+
+    def set_lines(self, lines: dict):
+        """Install a structure-of-arrays line list (nu, sw, a, elower, gamma_air, gamma_self, n_air, delta_air)."""
+        self._lines = {f: np.ascontiguousarray(lines[f], dtype=np.float64) if f in lines
+                       else np.zeros(len(lines["nu"])) for f in self._FIELDS}
+        self._invalidate_lines()
+
+    def _invalidate_lines(self):
+        if self._dev_lines is not None:
+            self._dev_lines.free()
+            self._dev_lines = None
+        self.progressCrossSection = False
+
+    # -- device residency ----------------------------------------------------------------
+    def _device_lines(self, ctx):
+        if self._dev_lines is None or self._dev_lines.h is None:
+            self._dev_lines = ctx.lines(self._lines)
+        return self._dev_lines
+
+    def _device_xsec(self, ctx, n):
+        if self._dev_xsec is None or self._dev_xsec.h is None or self._dev_xsec.n < n:
+            if self._dev_xsec is not None and self._dev_xsec.h is not None:
+                self._dev_xsec.free()
+            self._dev_xsec = ctx.buffer(max(n, 1))
+        self._dev_xsec_valid = True
+        return self._dev_xsec
+
+    def _device_xsec_current(self, ctx, n):
+        """Device copy of self.crossSection (re-uploaded if the host array was replaced)."""
+        xs = np.ascontiguousarray(self.crossSection, dtype=np.float64)
+        if xs.shape != (n,):
+            raise ValueError("cross section has %s points, layer grid has %d" % (xs.shape, n))
+        if not (self.progressCrossSection and self._dev_xsec_valid and self._dev_xsec is not None
+                and self._dev_xsec.h is not None):
+            buf = self._device_xsec(ctx, n)
+            buf.upload(xs)
+            self._dev_xsec_valid = self.progressCrossSection
+        return self._dev_xsec
+
+    # -- reference surface ---------------------------------------------------------------
+    def _layer(self):
+        return self.layer
+
+    def _sweep_members(self):
+        return [[self]], [self.molecule.concentration]          # cls:324 uses the molecule's concentration
+
+    P = property(lambda self: self.layer.P)
+    T = property(lambda self: self.layer.T)
+    depth = property(lambda self: self.layer.depth)
+    rangeMin = property(lambda self: self.layer.rangeMin)
+    rangeMax = property(lambda self: self.layer.rangeMax)
+    resolution = property(lambda self: self.layer.resolution)
+    distanceFromCenter = property(lambda self: self.layer.distanceFromCenter)
+    yAxis = property(lambda self: np.copy(self.layer.yAxis))
+    xAxis = property(lambda self: np.copy(self.layer.xAxis))
+
+    @property
+    def molMass(self):
+        return self.molmass / 1000 / avo
+
+    def getData(self):
+        _say('Getting data for %s, isotope %s' % (self.molecule.name, self.globalIsoNumber))
+        src = _data.get_source()
+        lines = src.gatherData(self.globalIsoNumber, self.layer.effectiveRangeMin, self.layer.effectiveRangeMax)
+        self.q = src.getQData(self.globalIsoNumber)
+        self.set_lines(lines)
+        self.createLineSurvey()
+
+    def createCrossSection(self):
+        """cls:361-407 on the device: K1 line prep, K2 owner-computes accumulate, K3 regrid."""
+        self.progressCrossSection = False
+        _compute_cross_sections([self])
+
+    def createLineSurvey(self):
+        """cls:409-428 on the device (K7)."""
+        ctx = _ctx()
+        g = self.layer._grid()
+        n = int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION)
+        out = ctx.buffer(max(n, 1))
+        try:
+            grid = _engine.native_grid(dict(g, n_base=n, W=max(g["W"], 1)))
+            ctx.line_survey_dev(self._device_lines(ctx), grid, out)
+            self.lineSurvey = out.download(n)
+        finally:
+            out.free()
+        return self.lineSurvey
+
+    def linelist(self):
+        return list(self)
+
+
+# ----------------------------------------------------------------------------------------
+# Molecule (cls:445-642)
+# ----------------------------------------------------------------------------------------
+class Molecule(_OpticalMixin, list):
+    def __init__(self, shortNameOrMolNum, layer, isotopeDepth=1, **abundance):
+        super().__init__()
+        self.layer = layer
+        self.concText = ''
+        self.concentration = 0
+        self.exotic = False
+        for key in abundance:
+            if key == 'ppm':
+                self.setPPM(abundance[key])
+            elif key == 'ppb':
+                self.setPPB(abundance[key])
+            elif key == 'percentage' or key == 'perc' or key == '%':
+                self.setPercentage(abundance[key])
+            elif key == 'concentration':
+                self.setConcentration(abundance[key])
+            else:
+                print('Invalid concentration type. Use ppm, ppb, percentage, or concentration.')
+        if type(shortNameOrMolNum) is dict:
+            raise NotImplementedError("measured cross-section ('xsc') molecules (cls:466-505) are outside the "
+                                      "hot path this build covers (SURVEY.md §8f rank 4)")
+        self.isotopeDepth = isotopeDepth
+        self.crossSection = np.copy(layer.crossSection)
+        try:
+            int(shortNameOrMolNum)
+            self.ID = int(shortNameOrMolNum)
+            self.name = False
+            self._by_number = True
+        except ValueError:
+            self.name = shortNameOrMolNum
+            self.ID = MOLECULE_ID[self.name]
+            self._by_number = False
+        for isotope in getGlobalIsotope(self.ID, isotopeDepth):
+            isoClass = Isotope(isotope, self)
+            self.append(isoClass)
+            if not self.name:
+                self.name = isoClass.shortName
+        self.progressCrossSection = False
+        self.exotic = False
+
+    def __str__(self):
+        return '%s: %s' % (self.name, self.concText)
+
+    def __bool__(self):
+        return True
+
+    def _layer(self):
+        return self.layer
+
+    def _sweep_members(self):
+        return [list(self)], [self.concentration]
+
+    def returnCopy(self, layer=None):
+        valueUnit = self.concText.split()
+        tempDict = {valueUnit[1]: float(valueUnit[0])}
+        # a molecule made from its HITRAN number carries the upper-case short name, which is not
+        # a MOLECULE_ID key (the reference's copy raises KeyError there): copy by number instead
+        newMolecule = Molecule(self.ID if self._by_number else self.name, layer if layer is not None else self.layer,
+                               isotopeDepth=int(self.isotopeDepth), **tempDict)
+        newMolecule.getData()
+        return newMolecule
+
+    def setPercentage(self, percentage):
+        self.concentration = percentage / 100
+        self.concText = '%s %%' % percentage
+        resetCrossSection(self)
+
+    def setPPM(self, ppm):
+        self.concentration = ppm * 10**-6
+        self.concText = '%s ppm' % ppm
+        resetCrossSection(self)
+
+    def setPPB(self, ppb):
+        self.concentration = ppb * 10**-8          # sic (cls:554)
+        self.concText = '%s ppb' % ppb
+        resetCrossSection(self)
+
+    def setConcentration(self, concentration):
+        self.setPPM(concentration * 1E6)
+        resetCrossSection(self)
+
+    def getData(self):
+        for isotope in self:
+            isotope.getData()
+
+    def createCrossSection(self):
+        """cls:566-571: sum of the isotopologue cross sections (no abundance weighting)."""
+        _compute_cross_sections(list(self))
+        ctx = _ctx()
+        n = int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION)
+        bufs = [iso._device_xsec_current(ctx, n) for iso in self]
+        self.crossSection = _sum_on_device(ctx, bufs, n)
+        self.progressCrossSection = True
+
+    @property
+    def lineSurvey(self):
+        tempAxis = np.zeros(int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION))
+        for isotope in self:
+            tempAxis += isotope.lineSurvey
+        return tempAxis
+
+    P = property(lambda self: self.layer.P)
+    T = property(lambda self: self.layer.T)
+    depth = property(lambda self: self.layer.depth)
+    rangeMin = property(lambda self: self.layer.rangeMin)
+    rangeMax = property(lambda self: self.layer.rangeMax)
+    resolution = property(lambda self: self.layer.resolution)
+    distanceFromCenter = property(lambda self: self.layer.distanceFromCenter)
+    yAxis = property(lambda self: np.copy(self.layer.yAxis))
+    xAxis = property(lambda self: np.copy(self.layer.xAxis))
+
+
+def _sum_on_device(ctx, bufs, n):
+    """zeros + b0 + b1 + ... in list order (cls:567-569, 685-687), on the device."""
+    out = ctx.buffer(max(n, 1))
+    try:
+        ctx.sum_dev(bufs, n, out)
+        return out.download(n)
+    finally:
+        out.free()
+
+
+# ----------------------------------------------------------------------------------------
+# Layer (cls:645-787)
+# ----------------------------------------------------------------------------------------
+class Layer(_OpticalMixin, list):
+    hasAtmosphere = False
+
+    def __init__(self, depth, T, P, rangeMin, rangeMax, atmosphere=None, name='', dynamicResolution=True):
+        super().__init__()
+        self.rangeMin = rangeMin
+        self.rangeMax = rangeMax
+        self.T = T
+        self.P = P
+        self.depth = depth
+        self.distanceFromCenter = self.P / 1013.25 * 5
+        self.effectiveRangeMin = max(self.rangeMin - self.distanceFromCenter, 0)
+        self.effectiveRangeMax = self.rangeMax + self.distanceFromCenter
+        self.dynamicResolution = dynamicResolution
+        self._set_resolution()
+        if not atmosphere:
+            if not Layer.hasAtmosphere:
+                self.atmosphere = Atmosphere('generic')
+                Layer.hasAtmosphere = self.atmosphere
+            else:
+                self.atmosphere = Layer.hasAtmosphere
+        else:
+            self.atmosphere = atmosphere
+            self.hasAtmosphere = atmosphere
+        self.crossSection = np.zeros(int((rangeMax - rangeMin) / utils.BASE_RESOLUTION))
+        self.progressCrossSection = False
+        if not name:
+            name = 'layer %s' % self.atmosphere.nextLayerName()
+        self.name = name
+        self.exotic = False
+
+    def _set_resolution(self):
+        if not self.dynamicResolution:
+            self.resolution = utils.BASE_RESOLUTION
+        else:
+            self.resolution = max(10**int(np.log10((self.P / 1013.25))) * .01, utils.BASE_RESOLUTION)
+
+    def _grid(self):
+        """Grid scalars for the C ABI from the layer's CURRENT attributes (cls:672, 700, 377)."""
+        base = utils.BASE_RESOLUTION
+        return dict(dfc=self.distanceFromCenter, eff_min=self.effectiveRangeMin, eff_max=self.effectiveRangeMax,
+                    resolution=self.resolution, base_resolution=base,
+                    n_base=int((self.rangeMax - self.rangeMin) / base),
+                    n_work=int((self.rangeMax - self.rangeMin) / self.resolution),
+                    W=len(np.arange(0, self.distanceFromCenter, self.resolution)),
+                    range_min=self.rangeMin, range_max=self.rangeMax)
+
+    def __str__(self):
+        return '%s; %s' % (self.name, '; '.join(str(m) for m in self))
+
+    def __bool__(self):
+        return True
+
+    def _layer(self):
+        return self
+
+    def _sweep_members(self):
+        # Layer.absCoef (cls:707-712) recomputes dirty molecules through getAbsCoef
+        _compute_cross_sections([iso for m in self for iso in m])
+        for m in self:
+            if not m.progressCrossSection:
+                m.createCrossSection()
+        return [list(m) for m in self], [m.concentration for m in self]
+
+    def createCrossSection(self):
+        """cls:684-689: sum of the molecule cross sections."""
+        _compute_cross_sections([iso for m in self for iso in m])
+        ctx = _ctx()
+        n = int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION)
+        tmp = []
+        try:
+            for molecule in self:
+                tmp.append(ctx.buffer(max(n, 1)).upload(getCrossSection(molecule)))
+            self.crossSection = _sum_on_device(ctx, tmp, n)
+        finally:
+            for b in tmp:
+                b.free()
+        self.progressCrossSection = True
+
+    @property
+    def lineSurvey(self):
+        tempAxis = np.zeros(int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION))
+        for molecule in self:
+            tempAxis += molecule.lineSurvey
+        return tempAxis
+
+    @property
+    def yAxis(self):
+        return np.zeros(int((self.rangeMax - self.rangeMin) / self.resolution))
+
+    @property
+    def xAxis(self):
+        return np.linspace(self.rangeMin, self.rangeMax, int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION),
+                           endpoint=True)
+
+    @property
+    def title(self):
+        return '%s\nP: %smBars; T: %sK; depth: %scm' % (str(self), self.P, self.T, self.depth)
+
+    def changeRange(self, rangeMin, rangeMax):
+        self.rangeMin = rangeMin
+        self.rangeMax = rangeMax
+        self.effectiveRangeMax = self.rangeMax + self.distanceFromCenter
+        self.effectiveRangeMin = max(self.rangeMin - self.distanceFromCenter, 0)
+        resetData(self)
+
+    def changeTemperature(self, temperature):
+        self.T = temperature
+        resetCrossSection(self)
+
+    def changePressure(self, pressure):
+        self.P = pressure
+        self.distanceFromCenter = self.P / 1013.25 * 5
+        self._set_resolution()
+        resetData(self)
+
+    def changeDepth(self, depth):
+        self.depth = depth
+
+    def addMolecule(self, name, isotopeDepth=1, **abundance):
+        molecule = Molecule(name, self, isotopeDepth, **abundance)
+        self.append(molecule)
+        if totalConcentration(self) > 1:
+            print('**Warning : Concentrations exceed 1.')
+        if not molecule.exotic:
+            molecule.getData()
+        return molecule
+
+    def returnCopy(self):
+        newCopy = Layer(self.depth, self.T, self.P, self.rangeMin, self.rangeMax,
+                        self.atmosphere, name=self.atmosphere.nextLayerName(), dynamicResolution=self.dynamicResolution)
+        for molecule in self:
+            newCopy.append(molecule.returnCopy(newCopy))      # bound to the NEW layer (the reference binds to the old one)
+        return newCopy
+
+    def returnMoleculeObjects(self):
+        return list(self)
+
+    def planck(self, temperature):
+        """pyradPlanck.planckWavenumber(self.xAxis, temperature) (cls:781-782, pl:38-44), on the device."""
+        ctx = _ctx()
+        n = int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION)
+        out = ctx.buffer(max(n, 1))
+        try:
+            ctx.planck_dev(self.rangeMin, self.rangeMax, n, float(temperature), out)
+            return out.download(n)
+        finally:
+            out.free()
+
+
+# ----------------------------------------------------------------------------------------
+# Atmosphere (cls:790-821) + the column fold this build defines on it
+# ----------------------------------------------------------------------------------------
+class Atmosphere(list):
+    def __init__(self, name):
+        super().__init__()
+        self.name = name
+
+    def __str__(self):
+        return self.name
+
+    def __bool__(self):
+        return True
+
+    def addLayer(self, depth, T, P, rangeMin, rangeMax, name=None, dynamicResolution=True):
+        if not name:
+            name = self.nextLayerName()
+        newLayer = Layer(depth, T, P, rangeMin, rangeMax, atmosphere=self, name=name,
+                         dynamicResolution=dynamicResolution)
+        self.append(newLayer)
+        return newLayer
+
+    def nextLayerName(self):
+        return 'Layer %s' % (len(self) + 1)
+
+    def returnLayerNames(self):
+        return [layer.name for layer in self]
+
+    def returnLayerObjects(self):
+        return list(self)
+
+    def transmission(self, surfaceSpectrum=None, surfaceTemperature=None):
+        """Fold Layer.transmission bottom to top over the layers in list order:
+        I <- T_i I + (1 - T_i) B(nu, T_i), I_0 = surfaceSpectrum or B(nu, surfaceTemperature).
+        (The reference announces an atmosphere path but ships no driver; this is the fold of
+        cls:784-787, computed by one column-sweep kernel.)"""
+        layers = list(self)
+        if not layers:
+            raise ValueError("atmosphere has no layers")
+        first = layers[0]
+        for L in layers[1:]:
+            if (L.rangeMin, L.rangeMax) != (first.rangeMin, first.rangeMax):
+                raise ValueError("all layers of a column must share one wavenumber range")
+        ctx = _ctx()
+        n = int((first.rangeMax - first.rangeMin) / utils.BASE_RESOLUTION)
+        _compute_cross_sections([iso for L in layers for m in L for iso in m])
+        trans, tmp = [], []
+        try:
+            for L in layers:
+                t = ctx.buffer(max(n, 1)).upload(L.transmittance)
+                trans.append(t); tmp.append(t)
+            out = ctx.buffer(max(n, 1)); tmp.append(out)
+            I_in = None
+            if surfaceSpectrum is not None:
+                I_in = ctx.buffer(max(n, 1)).upload(np.ascontiguousarray(surfaceSpectrum, dtype=np.float64))
+                tmp.append(I_in)
+            elif surfaceTemperature is None:
+                raise ValueError("give surfaceSpectrum or surfaceTemperature")
+            ctx.column_sweep_dev(trans, [L.T for L in layers], first.rangeMin, first.rangeMax, n, out, I_in=I_in,
+                                 surface_T=float(surfaceTemperature or 0.0))
+            return out.download(n)
+        finally:
+            for b in tmp:
+                b.free()
+
+
+# ----------------------------------------------------------------------------------------
+# plot-type dispatch (cls:824-839).  The matplotlib figures themselves are out of scope.
+# ----------------------------------------------------------------------------------------
+def returnPlot(obj, propertyToPlot):
+    if propertyToPlot == "transmittance":
+        return getTransmittance(obj), 1
+    if propertyToPlot == 'absorption coefficient':
+        return getAbsCoef(obj), 0
+    if propertyToPlot == 'cross section':
+        return getCrossSection(obj), 0
+    if propertyToPlot == 'absorbance':
+        return getAbsorbance(obj), 0
+    if propertyToPlot == 'optical depth':
+        return getOpticalDepth(obj), 0
+    if propertyToPlot == 'line survey':
+        return obj.lineSurvey, 0
+    return False

@@ -1,0 +1,168 @@
+"""GPU: the pyradClasses-shaped object model (pyrad_amd.model) against the golden vectors
+captured from the reference's own Layer/Molecule objects."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, unpack_lines, rel_err
+from pyrad_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-11
+
+
+@pytest.fixture()
+def pyrad():
+    from pyrad_amd import model, data, settings, engine
+    model.Layer.hasAtmosphere = False
+    settings.set_resolution_multiplier(1)
+    yield model
+    settings.set_resolution_multiplier(1)
+    data.set_source(None)
+
+
+def source(**species_lines):
+    from pyrad_amd import data
+    return data.set_source(data.synthetic_source(species_lines))
+
+
+def test_g1_layer_getters(pyrad):
+    z = load_golden("G1_c1_cell")
+    source(co2=unpack_lines(z, "lines"))
+    layer = pyrad.Layer(float(z["depth"]), 296, 1013.25, 600, 700)
+    mol = layer.addMolecule('co2', ppm=400)
+    assert (layer.resolution, layer.distanceFromCenter) == (0.01, 5.0)
+    assert len(mol[0]) == 2000 and mol.concText == '400 ppm'
+    assert rel_err(pyrad.getCrossSection(mol), z["T296.xsec"]) <= RTOL
+    assert rel_err(pyrad.getAbsCoef(layer), z["T296.abs_coef"]) <= RTOL
+    assert rel_err(pyrad.getTransmittance(layer), z["T296.transmittance"]) <= RTOL
+    assert rel_err(pyrad.getAbsorbance(layer), z["absorbance"], floor=1e-300) <= 1e-9
+    assert rel_err(pyrad.getOpticalDepth(layer), z["optical_depth"], floor=1e-300) <= 1e-9
+    assert np.array_equal(layer.xAxis, z["x_axis"])
+    surf = layer.planck(288)
+    assert rel_err(surf, z["planck_surface"]) <= 1e-14
+    spec = layer.transmission(surf)
+    assert rel_err(spec, z["T296.transmission"]) <= RTOL
+    assert pyrad.integrateSpectrum(spec, pyrad.pi) == pytest.approx(float(z["T296.band_integral"]), rel=1e-12)
+    # dirty-flag protocol: temperature change -> recompute (cls:741-743), depth change -> nothing (cls:754)
+    layer.changeTemperature(250)
+    assert not mol.progressCrossSection and not mol[0].progressCrossSection
+    assert rel_err(pyrad.getAbsCoef(layer), z["T250.abs_coef"]) <= RTOL
+    assert mol.progressCrossSection
+    layer.changeDepth(20.0)
+    assert mol.progressCrossSection
+    assert rel_err(pyrad.getTransmittance(layer), z["T250.transmittance"] ** 2) <= 1e-9
+    with pytest.raises(KeyError):               # Q[T] needs an integer-K temperature (cls:389)
+        layer.changeTemperature(296.5)
+        pyrad.getAbsCoef(layer)
+
+
+def test_g6_composition_objects(pyrad):
+    z = load_golden("G6_composition")
+    source(co2=unpack_lines(z, "co2.lines"), co2_636=unpack_lines(z, "co2_636.lines"),
+           h2o=unpack_lines(z, "h2o.lines"), ch4=unpack_lines(z, "ch4.lines"))
+    layer = pyrad.Layer(float(z["depth"]), int(z["T"]), float(z["P"]), 1000, 1040)
+    co2 = layer.addMolecule('co2', isotopeDepth=2, ppm=400)
+    h2o = layer.addMolecule('h2o', **{'%': 1.5})
+    ch4 = layer.addMolecule(6, ppb=1800)
+    assert ch4.name == 'CH4' and ch4.concentration == 1800 * 10**-8
+    assert [m.concentration for m in layer] == list(z["concentration"])
+    assert rel_err(pyrad.getAbsCoef(layer), z["abs_coef"]) <= RTOL
+    assert rel_err(pyrad.getCrossSection(co2), z["co2.xsec"]) <= RTOL
+    assert rel_err(pyrad.getCrossSection(co2[1]), z["co2.iso1.xsec"]) <= RTOL
+    for m, name in ((co2, "co2"), (h2o, "h2o"), (ch4, "ch4")):
+        assert rel_err(pyrad.getAbsCoef(m), z[name + ".abs_coef"]) <= RTOL
+    assert rel_err(layer.transmission(layer.planck(290)), z["transmission"]) <= RTOL
+    assert rel_err(pyrad.getCrossSection(layer), z["co2.xsec"] + z["h2o.xsec"] + z["ch4.xsec"]) <= 1e-13
+    assert pyrad.returnPlot(layer, 'absorption coefficient')[1] == 0
+    assert pyrad.returnPlot(layer, 'nonsense') is False
+    copy = layer.returnCopy()
+    assert isinstance(copy, pyrad.Layer) and [m.name for m in copy] == [m.name for m in layer]
+    assert [m.concentration for m in copy] == [m.concentration for m in layer]
+    assert all(m.layer is copy for m in copy)
+    assert rel_err(pyrad.getAbsCoef(copy), z["abs_coef"]) <= RTOL
+
+
+def test_g5_native_resolution_via_settings(pyrad):
+    from pyrad_amd import settings
+    z = load_golden("G5_native_0p001")
+    source(co2=unpack_lines(z, "lines"))
+    settings.set_resolution_multiplier(0.1)
+    assert settings.BASE_RESOLUTION == pytest.approx(0.001)
+    for tag, dyn in (("native", False), ("dynamic", True)):
+        layer = pyrad.Layer(10.0, 296, 1013.25, 650, 660, dynamicResolution=dyn)
+        layer.addMolecule('co2', ppm=400)
+        assert layer.resolution == float(z[tag + ".resolution"])
+        assert rel_err(pyrad.getAbsCoef(layer), z[tag + ".abs_coef"]) <= RTOL
+        assert rel_err(layer.transmission(layer.planck(288)), z[tag + ".transmission"]) <= RTOL
+
+
+def test_g3_change_pressure_reloads_window(pyrad):
+    z = load_golden("G3_pressure_ladder")
+    P = z["P_list"]
+    source(co2=unpack_lines(z, "P0.lines"))
+    layer = pyrad.Layer(100.0, 260, float(P[0]), 640, 660)
+    layer.addMolecule('co2', ppm=400)
+    assert rel_err(pyrad.getAbsCoef(layer), z["P0.abs_coef"]) <= RTOL
+    source(co2=unpack_lines(z, "P5.lines"))
+    fresh = pyrad.Layer(100.0, 260, float(P[5]), 640, 660)      # 10132.5 mbar -> resolution 0.1, regrid path
+    fresh.addMolecule('co2', ppm=400)
+    assert fresh.resolution == pytest.approx(0.1) and fresh.distanceFromCenter == pytest.approx(50.0)
+    assert rel_err(pyrad.getAbsCoef(fresh), z["P5.abs_coef"]) <= RTOL
+    # changePressure re-reads the lines (resetData, cls:752) but, like the reference, keeps the
+    # effective range computed at construction (only changeRange updates it, cls:737-738)
+    layer.changePressure(float(P[5]))
+    assert layer.resolution == pytest.approx(0.1) and layer.distanceFromCenter == pytest.approx(50.0)
+    assert (layer.effectiveRangeMin, layer.effectiveRangeMax) == (635.0, 665.0)
+    assert not layer[0].progressCrossSection
+    k_stale = pyrad.getAbsCoef(layer)
+    assert k_stale.shape == (2000,) and np.all(k_stale <= z["P5.abs_coef"] * (1 + 1e-12))
+
+
+def test_g7_atmosphere_column(pyrad):
+    z = load_golden("G7_column")
+    source(co2=unpack_lines(z, "co2.lines"), h2o=unpack_lines(z, "h2o.lines"))
+    atm = pyrad.Atmosphere('column')
+    for i in range(3):
+        layer = atm.addLayer(float(z["layer_depth"][i]), int(z["layer_T"][i]), float(z["layer_P"][i]), 660, 680)
+        layer.addMolecule('co2', ppm=400)
+        layer.addMolecule('h2o', percentage=float(z["h2o_perc"][i]))
+    assert atm.returnLayerNames() == ['Layer 1', 'Layer 2', 'Layer 3']
+    toa = atm.transmission(surfaceTemperature=290)
+    assert rel_err(toa, z["L2.spectrum"]) <= RTOL
+    spec = atm[0].planck(290)
+    for layer in atm:
+        spec = layer.transmission(spec)
+    assert rel_err(spec, z["L2.spectrum"]) <= RTOL
+
+
+def test_line_survey_and_line_views(pyrad):
+    z = load_golden("G2_edges")
+    lines = unpack_lines(z, "lines")
+    source(co2=lines)
+    layer = pyrad.Layer(10.0, 296, 1013.25, 600, 700)
+    mol = layer.addMolecule('co2', ppm=400)
+    iso = mol[0]
+    sel = np.sort(lines["nu"][(lines["nu"] > 595) & (lines["nu"] < 705)])
+    assert [ln.wavenumber for ln in iso] == list(sel)
+    survey = np.zeros(10000)
+    order = np.argsort(lines["nu"], kind="stable")
+    for i in order:
+        if 595 < lines["nu"][i] < 705:
+            idx = int((lines["nu"][i] - 600) / 0.01)
+            if 0 <= idx <= 9999:
+                survey[idx] = survey[idx] + lines["sw"][i]
+    assert np.array_equal(layer.lineSurvey, survey)
+    ln = iso[3]
+    assert ln.lorentzHW > 0 and ln.gaussianHW > 0 and ln.broadenedLine < ln.wavenumber
+    assert len(pyrad.totalLineList(layer)) == len(sel)
+
+
+def test_no_source_and_xsc_are_loud(pyrad):
+    from pyrad_amd import data
+    data.set_source(None)
+    layer = pyrad.Layer(10.0, 296, 1013.25, 600, 700)
+    with pytest.raises(RuntimeError):
+        layer.addMolecule('co2', ppm=400)
+    source(co2=synthetic.make_lines(1, 10, 595, 705))
+    with pytest.raises(NotImplementedError):
+        layer.addMolecule({'CFC-11': 'file.txt'}, ppb=1)

@@ -257,7 +257,8 @@ def test_oracle_vs_device_c2_slice_and_determinism(ctx, orc):
 
 def test_sharded_equals_unsharded(ctx, orc):
     """Grid sharded by contiguous range (world 4, every rank on this one GPU): the shards tile
-    the unsharded spectrum bit for bit."""
+    the unsharded spectrum.  Tile boundaries (and with them the 16-line blocks of the running
+    fraction) move with the shard origin, so agreement is to rounding, not bitwise."""
     from pyrad_amd import engine
     cfg = synthetic.config_c2(n_lines=2500, range_min=640, range_max=690, seed=13)
     mol = cfg["molecules"][0]
@@ -280,7 +281,7 @@ def test_sharded_equals_unsharded(ctx, orc):
         evals += part.evals
         part.free()
     for k in ref:
-        assert np.array_equal(got[k], ref[k]), k
+        assert rel_err(got[k], ref[k]) <= 1e-13, k
     assert evals == full.evals
     full.free()
 

@@ -246,3 +246,26 @@ def test_eval_count_matches_loop():
             for dx in range(1, W - 1):
                 brute += (0 <= c + dx <= n - 1) + (0 <= c - dx <= n - 1)
         assert orc.eval_count(idx, W, n) == brute
+
+
+def test_c_oracle_matches_numpy_oracle_and_golden():
+    from oracle import c_oracle
+    z = load_golden("G1_c1_cell")
+    lines = unpack_lines(z, "lines")
+    grid = orc.layer_grid(1013.25, 600, 700, .01, True)
+    sel = orc.select_window(lines, grid["eff_min"], grid["eff_max"])
+    sp = synthetic.SPECIES["co2"]
+    for T in (296, 250):
+        work, counts, evals = c_oracle.create_cross_section_work(sel, T, 1013.25, 4e-4, sp["molmass"],
+                                                                 synthetic.q_value("co2", T), sp["q296"], grid)
+        assert rel_err(work, z["T%d.xsec" % T]) <= TOL
+        lq = orc.line_quantities(sel, T, 1013.25, 4e-4, sp["molmass"], 600, .01)
+        assert evals == orc.eval_count(lq["index"], grid["W"], grid["n_work"])
+        assert sum(counts) == len(sel["nu"])
+    z5 = load_golden("G4_regimes")
+    b = unpack_lines(z5, "b.lines")
+    grid = orc.layer_grid(0.05, 650.0, 650.05, 1e-5, False)
+    selb = orc.select_window(b, grid["eff_min"], grid["eff_max"])
+    work, counts, _ = c_oracle.create_cross_section_work(selb, 220, 0.05, 4e-4, sp["molmass"],
+                                                         synthetic.q_value("co2", 220), sp["q296"], grid)
+    assert counts[0] > 5 and rel_err(work, z5["b.xsec"]) <= TOL
