@@ -33,7 +33,8 @@ struct lbl_ctx {
     std::string err;
     int n_cu = 0;
     // scratch
-    DeviceArena recs;       // LineRec per line of the current batch
+    DeviceArena recs;       // HotRec per line of the current batch
+    DeviceArena cold;       // ColdRec per line
     DeviceArena cidx;       // int32 per line
     DeviceArena work;       // work grids that need a regrid
     DeviceArena jobs;       // PrepJob[] + AccumJob[] + ColumnArgs
@@ -44,8 +45,10 @@ struct lbl_ctx {
     size_t host_stage_head = 0;
     int last_jobs = 0;
     // tuning knobs (lbl_set_option)
-    int accum_variant = 2;   // 0: IEEE divide + exp per point; 1: running fraction; 2: + Gaussian recurrence
-    int accum_R = 0;         // 0 = choose per launch
+    int accum_variant = 3;   // 0: IEEE divide + exp per pair; 1: running fraction; 2: + Gaussian recurrence
+                             // (0-2 fetch records through the scalar cache); 3: 2 with wave-private LDS staging
+    int accum_R = 0;         // points per lane, 0 = choose per launch
+    int accum_LS = 0;        // waves sharing one span of points (line split), 0 = choose per launch
     int live_objects = 0;
     // event timing (lbl_profile_*)
     bool profiling = false;
@@ -204,7 +207,7 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& v : ctx->ev_rec) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    DeviceArena* arenas[] = {&ctx->recs, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->red};
+    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->red};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     (void)hipStreamDestroy(ctx->stream);
@@ -278,12 +281,16 @@ void comm_prof_end(lbl_ctx* ctx, void* start) { prof_end(ctx, PROF_GATHER, (hipE
 extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     if (!strcmp(key, "accum_variant")) {
-        if (value < 0 || value > 2) return fail(ctx, LBL_ERR_BAD_ARG, "accum_variant must be 0..2");
+        if (value < 0 || value > 3) return fail(ctx, LBL_ERR_BAD_ARG, "accum_variant must be 0..3");
         ctx->accum_variant = value;
     } else if (!strcmp(key, "accum_points_per_lane")) {
         if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_points_per_lane must be 0, 1, 2, 4 or 8");
         ctx->accum_R = value;
+    } else if (!strcmp(key, "accum_line_split")) {
+        if (!(value == 0 || value == 1 || value == 2 || value == 4))
+            return fail(ctx, LBL_ERR_BAD_ARG, "accum_line_split must be 0, 1, 2 or 4");
+        ctx->accum_LS = value;
     } else {
         return fail(ctx, LBL_ERR_BAD_ARG, "unknown option '%s'", key);
     }
@@ -418,15 +425,24 @@ extern "C" int lbl_lines_count(const lbl_lines* lines, int64_t* n) {
 // ----------------------------------------------------------------------------------------
 // the hot path
 // ----------------------------------------------------------------------------------------
-static int choose_R(const lbl_ctx* ctx, long long total_points, long long min_H) {
-    if (ctx->accum_R) return ctx->accum_R;
-    // enough wavefronts to cover every SIMD about 4 times (256 CUs x 4 SIMDs), and no
-    // more points per wave than a line's support is wide
+// Launch shape: R grid points per lane and, for the LDS variant, LS waves sharing one span of
+// 64*R points.  Wanted: about 4 wavefronts per SIMD (256 CUs x 4 SIMDs) and no more points
+// per wave than a line's support is wide.  Small grids keep R and split the lines instead.
+static void choose_shape(const lbl_ctx* ctx, long long total_points, long long min_H, int* R_out, int* LS_out) {
     const long long simds = 4LL * (ctx->n_cu > 0 ? ctx->n_cu : 256);
-    int R = 8;
-    while (R > 1 && total_points / (64LL * R) < 3 * simds) R >>= 1;
-    while (R > 1 && 64LL * R > 2 * min_H + 1) R >>= 1;
-    return R;
+    const bool lds = ctx->accum_variant >= 3;
+    int R = ctx->accum_R, LS = lds ? ctx->accum_LS : 1;
+    if (!R) {
+        R = 8;
+        while (R > 1 && 64LL * R > 2 * min_H + 1) R >>= 1;
+        const int r_floor = lds ? (R < 4 ? R : 4) : 1;
+        while (R > r_floor && total_points / (64LL * R) * (lds ? 4 : 1) < 3 * simds) R >>= 1;
+    }
+    if (!LS) {
+        LS = 1;
+        while (LS < 4 && total_points / (64LL * R) * LS < 3 * simds) LS <<= 1;
+    }
+    *R_out = R; *LS_out = LS;
 }
 
 struct DbgOut { long long* index; double* lhw; double* ghw; double* inten; int32_t* regime; };
@@ -455,7 +471,8 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         max_lines = std::max<int>(max_lines, (int)lines[j]->n);
     }
     int rc;
-    if ((rc = arena_reserve(ctx, ctx->recs, std::max<size_t>(tot_lines, 1) * sizeof(LineRec)))) return rc;
+    if ((rc = arena_reserve(ctx, ctx->recs, std::max<size_t>(tot_lines, 1) * sizeof(HotRec)))) return rc;
+    if ((rc = arena_reserve(ctx, ctx->cold, std::max<size_t>(tot_lines, 1) * sizeof(ColdRec)))) return rc;
     if ((rc = arena_reserve(ctx, ctx->cidx, std::max<size_t>(tot_lines, 1) * sizeof(int32_t)))) return rc;
     if ((rc = arena_reserve(ctx, ctx->work, std::max<size_t>(tot_work, 1) * sizeof(double)))) return rc;
     if ((rc = arena_reserve(ctx, ctx->counts, (size_t)n_jobs * 3 * sizeof(unsigned long long)))) return rc;
@@ -464,7 +481,9 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     void* stage = nullptr;
     if ((rc = stage_alloc(ctx, prep_bytes + acc_bytes, &stage))) return rc;
 
-    const int R = choose_R(ctx, total_points, min_H);
+    int R, LS;
+    choose_shape(ctx, total_points, min_H, &R, &LS);
+    const long long tile_pts = accumulate_tile_points(R, LS, ctx->accum_variant);
     PrepJob* hp = (PrepJob*)stage;
     AccumJob* ha = (AccumJob*)((char*)stage + prep_bytes);
     int max_tiles = 0;
@@ -474,7 +493,8 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         memset(&p, 0, sizeof p);
         p.nu = L->field(0); p.sw = L->field(1); p.elower = L->field(2); p.gamma_air = L->field(3);
         p.gamma_self = L->field(4); p.n_air = L->field(5); p.delta_air = L->field(6);
-        p.recs = (LineRec*)ctx->recs.ptr + line_off[j];
+        p.hot = (HotRec*)ctx->recs.ptr + line_off[j];
+        p.cold = (ColdRec*)ctx->cold.ptr + line_off[j];
         p.cidx = (int32_t*)ctx->cidx.ptr + line_off[j];
         p.regime_counts = (unsigned long long*)ctx->counts.ptr + 3 * (size_t)j;
         if (dbg) { p.dbg_index = dbg->index; p.dbg_lhw = dbg->lhw; p.dbg_ghw = dbg->ghw; p.dbg_intensity = dbg->inten; p.dbg_regime = dbg->regime; }
@@ -484,7 +504,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         p.n_lines = (int32_t)L->n;
         AccumJob& a = ha[j];
         memset(&a, 0, sizeof a);
-        a.recs = p.recs; a.cidx = p.cidx;
+        a.hot = p.hot; a.cold = p.cold; a.cidx = p.cidx;
         a.out = needs_regrid(grid[j]) ? (double*)ctx->work.ptr + work_off[j] : out_dev[j];
         a.n_lines = (int32_t)L->n;
         a.n_work = (int32_t)grid[j].n_work;
@@ -493,7 +513,8 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         shard_range(grid[j], &sf, &sc);
         a.p_begin = (int32_t)sf;
         a.p_end = (int32_t)(sf + sc);
-        a.n_tiles = (int32_t)((sc + 256LL * R - 1) / (256LL * R));
+        a.n_tiles = (int32_t)((sc + tile_pts - 1) / tile_pts);
+        a.flush_every = (a.H + 64 * R + 1 <= 40000) ? 32 : 16;
         max_tiles = std::max(max_tiles, a.n_tiles);
     }
     PrepJob* dp = (PrepJob*)ctx->jobs.ptr;
@@ -507,7 +528,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     ctx->last_jobs = n_jobs;
     if (prep_only) return LBL_OK;
     ev = prof_begin(ctx);
-    launch_accumulate(da, n_jobs, max_tiles, R, ctx->accum_variant, ctx->stream);
+    launch_accumulate(da, n_jobs, max_tiles, R, LS, ctx->accum_variant, ctx->stream);
     prof_end(ctx, PROF_ACCUM, ev);
     HIP_TRY(ctx, hipGetLastError());
     for (int j = 0; j < n_jobs; ++j) {

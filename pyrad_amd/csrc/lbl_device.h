@@ -16,30 +16,34 @@ constexpr double t0 = 296.0;
 constexpr double p0 = 1013.25;
 constexpr double avo = 6.022140857E23;
 
-// One prepared spectral line, in work-grid units (64 B, one s_load_dwordx16).
-// The contribution of the line to the grid point at integer offset d from its centre is
+// One prepared spectral line, in work-grid units, split into the part every (wave, line)
+// pair reads (hot, 32 B) and the Gaussian part only pairs near the line centre read (cold,
+// 32 B).  The contribution of the line to the grid point at integer offset d from its centre
+// ci is
 //     KL / (d*d + a2)  +  KG * exp(-b*d*d)          for |d| <= H = window-2,
 // which restates pyradLineshape.py:39 (Gaussian), :52 (Lorentz) and :72-74 (pseudo-Voigt)
 // times the corrected intensity of pyradIntensity.py:30-32 with x = d*resolution.
-struct __attribute__((aligned(64))) LineRec {
-    double cf;     // centre index (pyradClasses.py:390) as a double
-    double a2;     // (hw / res)^2
-    double KL;     // Lorentz amplitude / res^2   (0 for a pure Gaussian line)
-    double KG;     // Gaussian amplitude           (0 for a pure Lorentz line)
-    double b;      // (res / hw)^2
-    double q2;     // exp(-2 b): ratio step of the Gaussian recurrence; < 0: evaluate directly
-    int32_t ci;    // centre index
-    int32_t dgi;   // |d| >= dgi: the Gaussian term cannot change the fp64 value of the sum
-    int32_t flags; // bit 0: Lorentz denominator out of the running-fraction range -> direct divide
-    int32_t pad;
+struct __attribute__((aligned(32))) HotRec {
+    double cf;      // centre index (pyradClasses.py:390) as a double (exact: |ci| <= 2e9)
+    double a2;      // (hw / res)^2
+    double KL;      // Lorentz amplitude / res^2   (0 for a pure Gaussian line)
+    int32_t dgi;    // |d| >= dgi: the Gaussian term cannot change the fp64 value of the sum
+    int32_t flags;  // REC_DIRECT_DIV: denominator outside the running-fraction range
 };
-static_assert(sizeof(LineRec) == 64, "LineRec must be 64 bytes");
+struct __attribute__((aligned(32))) ColdRec {
+    double KG;      // Gaussian amplitude           (0 for a pure Lorentz line)
+    double b;       // (res / hw)^2
+    double q2;      // exp(-2 b): ratio step of the Gaussian recurrence; < 0: evaluate directly
+    double KLd;     // copy of HotRec.KL for the plain-divide pass of REC_DIRECT_DIV lines
+};
+static_assert(sizeof(HotRec) == 32 && sizeof(ColdRec) == 32, "record halves must be 32 bytes");
 
 enum : int32_t { REC_DIRECT_DIV = 1 };
 
 // One accumulate job = one isotopologue of one layer (Isotope.createCrossSection).
 struct AccumJob {
-    const LineRec* recs;
+    const HotRec* hot;
+    const ColdRec* cold;
     const int32_t* cidx;   // centre indices, non-decreasing
     double* out;           // work grid, n_work doubles
     int32_t n_lines;
@@ -48,12 +52,14 @@ struct AccumJob {
     int32_t n_tiles;
     int32_t p_begin;       // shard of the work grid computed by this job: [p_begin, p_end)
     int32_t p_end;
+    int32_t flush_every;   // lines per running-fraction block: 32, or 16 for very wide windows
+    int32_t pad;
 };
 
 struct PrepJob {
     const double* nu; const double* sw; const double* elower; const double* gamma_air;
     const double* gamma_self; const double* n_air; const double* delta_air;
-    LineRec* recs; int32_t* cidx;
+    HotRec* hot; ColdRec* cold; int32_t* cidx;
     unsigned long long* regime_counts;    // [3]
     // optional debug outputs
     long long* dbg_index; double* dbg_lhw; double* dbg_ghw; double* dbg_intensity; int32_t* dbg_regime;
@@ -92,7 +98,8 @@ struct ColumnArgs {
 
 // ---- launchers (lbl_kernels.hip) ---------------------------------------------------------
 void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStream_t s);
-void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int variant, hipStream_t s);
+void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant, hipStream_t s);
+int accumulate_tile_points(int R, int LS, int variant);
 void launch_regrid(const double* work, long long n_work, double* out, long long n_base, double start, double stop,
                    hipStream_t s);
 void launch_layer_sweep(const SweepArgs& a, hipStream_t s);

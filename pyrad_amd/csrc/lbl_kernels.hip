@@ -30,20 +30,29 @@ namespace lbl {
 // ----------------------------------------------------------------------------------------
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// Line records are written by K1 and only read by K2: viewing them through the constant
-// address space tells the compiler the memory is invariant for the kernel, so a wave-uniform
-// index turns into one s_load_dwordx16 (scalar cache -> SGPRs) instead of 64 lanes of flat loads.
-typedef const double __attribute__((address_space(4)))* RecPtr;      // 8 doubles per record
-typedef const int32_t __attribute__((address_space(4)))* RecIntPtr;
-__device__ __forceinline__ RecPtr as_const_recs(const LineRec* p) {
-    return (RecPtr)(unsigned long long)p;
-}
-__device__ __forceinline__ LineRec load_rec(RecPtr recs, int i) {
-    RecPtr p = recs + (long long)i * 8;
-    RecIntPtr q = (RecIntPtr)(p + 6);
-    LineRec r;
-    r.cf = p[0]; r.a2 = p[1]; r.KL = p[2]; r.KG = p[3]; r.b = p[4]; r.q2 = p[5];
-    r.ci = q[0]; r.dgi = q[1]; r.flags = q[2]; r.pad = 0;
+// Prepared line records are written by K1 and only read by K2.  The scalar-cache variants
+// view them through the constant address space (invariant memory -> s_load with a uniform
+// index); the LDS variant streams them with coalesced vector loads.
+typedef const double __attribute__((address_space(4)))* ConstF64;
+typedef const int32_t __attribute__((address_space(4)))* ConstI32;
+
+// working copy of one line (hot + cold halves) in registers
+struct Rec {
+    double cf, a2, KL, KG, b, q2;
+    int32_t ci, dgi, flags;
+};
+
+__device__ __forceinline__ Rec load_rec_scalar(const HotRec* hot, const ColdRec* cold, int i, bool want_cold) {
+    ConstF64 h = (ConstF64)(unsigned long long)hot + (long long)i * 4;
+    ConstI32 hi = (ConstI32)(h + 3);
+    Rec r;
+    r.cf = h[0]; r.a2 = h[1]; r.KL = h[2]; r.dgi = hi[0]; r.flags = hi[1];
+    r.ci = (int32_t)r.cf;
+    r.KG = 0.0; r.b = 0.0; r.q2 = -1.0;
+    if (want_cold) {
+        ConstF64 c = (ConstF64)(unsigned long long)cold + (long long)i * 4;
+        r.KG = c[0]; r.b = c[1]; r.q2 = c[2];
+    }
     return r;
 }
 
@@ -123,18 +132,18 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
             KG = (1.0 - eta) * (A / hw / sqrt(kPi));
         }
         const double a = hw / res;
-        LineRec r;
+        HotRec r;
+        ColdRec rc;
         r.cf = (double)idx;
-        r.ci = (int32_t)idx;
         r.a2 = a * a;
         r.KL = KL / (res * res);
-        r.KG = KG;
-        r.b = 1.0 / r.a2;
+        rc.KG = KG;
+        rc.b = 1.0 / r.a2;
         r.flags = 0;
-        r.pad = 0;
-        // running-fraction accumulation multiplies up to 16 denominators (< 4.7e18 + a2):
-        // keep lines whose a2 could over/underflow that product on the plain-divide path
-        if (!(r.a2 > 1e-16 && r.a2 < 1e16)) r.flags |= REC_DIRECT_DIV;
+        // running-fraction accumulation multiplies up to 32 denominators d*d + a2 with
+        // |d| <= H + 512 <= 4e4 (else 16, see AccumJob.flush_every): keep a2 in [1e-9, 1e8] so
+        // the product stays within 1e-288 .. 1e296; anything else takes the plain-divide path
+        if (!(r.a2 > 1e-9 && r.a2 < 1e8)) r.flags |= REC_DIRECT_DIV;
         // Gaussian term: where can it still change the fp64 value of the line's sum?
         double dg = 0.0;
         if (KG != 0.0) {
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
             double u2 = u2_under;
             if (KL != 0.0) {
                 // ratio Gauss/Lorentz at offset u = d/a:  C (1+u^2) exp(-u^2);  solve = 2^-54
-                const double C = fabs(KG / (r.KL * r.b)) * 18014398509481984.0;
+                const double C = fabs(KG / (r.KL * rc.b)) * 18014398509481984.0;
                 if (C <= 1.0) {
                     u2 = 0.0;
                 } else {
@@ -156,9 +165,11 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
         r.dgi = (dg < 2.0e9) ? (int32_t)dg : 2000000000;
         // Gaussian recurrence along a lane's consecutive points needs exp(b*R^2) finite and
         // well inside the normal range; very narrow profiles take the direct exp instead
-        r.q2 = (r.b <= 8.0) ? exp(-2.0 * r.b) : -1.0;
-        J.recs[i] = r;
-        J.cidx[i] = r.ci;
+        rc.q2 = (rc.b <= 8.0) ? exp(-2.0 * rc.b) : -1.0;
+        rc.KLd = r.KL;
+        J.hot[i] = r;
+        J.cold[i] = rc;
+        J.cidx[i] = (int32_t)idx;
         if (J.dbg_index) J.dbg_index[i] = (long long)fidx;
         if (J.dbg_lhw) J.dbg_lhw[i] = lhw;
         if (J.dbg_ghw) J.dbg_ghw[i] = ghw;
@@ -185,31 +196,32 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t* __restrict__ a, in
     return lo;
 }
 
-// Gaussian part of one line for a lane's R consecutive points.
+// Gaussian part of one line for a lane's R consecutive points (d0 = offset of the lane's
+// first point from the line centre).
 //   GM == 0: one exp per point.
 //   GM == 1: two exps per lane, then g(d+1) = g(d) r(d), r(d+1) = r(d) q2 walking AWAY from
 //            the centre (lanes left of the centre are mirrored so the terms only decay).
 template <int R, bool MASKED, int GM>
-__device__ __forceinline__ void gauss_term(const LineRec& r, double d0, double Hf, double (&acc)[R]) {
-    if (GM == 0 || r.q2 < 0.0 || R < 4) {
+__device__ __forceinline__ void gauss_term(double KG, double b, double q2, double d0, double Hf, double (&acc)[R]) {
+    if (GM == 0 || q2 < 0.0 || R < 4) {
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const double d = d0 + (double)k;
-            double t = r.KG * exp(-r.b * (d * d));
+            double t = KG * exp(-b * (d * d));
             if (MASKED) t = (fabs(d) <= Hf) ? t : 0.0;
             acc[k] += t;
         }
     } else {
         const bool mirror = (2.0 * d0 + (double)(R - 1)) < 0.0;
         const double e0 = mirror ? -(d0 + (double)(R - 1)) : d0;
-        double g = r.KG * exp(-r.b * (e0 * e0));
-        double rr = exp(-r.b * (2.0 * e0 + 1.0));
+        double g = KG * exp(-b * (e0 * e0));
+        double rr = exp(-b * (2.0 * e0 + 1.0));
         double t[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             t[k] = g;
             g *= rr;
-            rr *= r.q2;
+            rr *= q2;
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -223,121 +235,101 @@ __device__ __forceinline__ void gauss_term(const LineRec& r, double d0, double H
     }
 }
 
-// Lines [i0, i1) against this lane's R points.  MASKED: test |d| <= H per point (lines whose
-// support ends inside the wave's span); otherwise every point of the wave is inside.
-//   DIV == 0: one IEEE divide per pair.
-//   DIV == 2: running fraction N/D over blocks of 16 lines (N <- N den + K D, D <- D den),
-//             one divide per point and block.
-template <int R, bool MASKED, int DIV, int GM>
-__device__ __forceinline__ void process_lines(RecPtr recs, int i0, int i1,
-                                              double x0, int wlo, int whi, double Hf, double (&acc)[R]) {
-    if (DIV == 0) {
-        for (int i = i0; i < i1; ++i) {
-            const LineRec r = load_rec(recs, i);
-            const double d0 = x0 - r.cf;
+// Per-wave accumulator state.  acc: finished sums.  N/D: running fraction of the Lorentz
+// terms of the last `cnt` (< 16) lines:  sum_i K_i/den_i = N/D with
+//     N <- N*den + K*D,   D <- D*den        (3 fp64 ops + 2 for den instead of a divide)
+// flushed into acc with one IEEE divide per point every `every` lines (32; 16 when the
+// window is wider than 4e4 points).  K1 routes lines with a2 outside [1e-9, 1e8] to the
+// plain-divide path, so the product of denominators stays within 1e-288 .. 1e296.
+template <int R>
+struct WaveAcc {
+    double acc[R], N[R], D[R];
+    int cnt, every;
+    __device__ __forceinline__ void init(int flush_every) {
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const double d = d0 + (double)k;
-                const double den = fma(d, d, r.a2);
-                double t = r.KL / den;
-                if (MASKED) t = (fabs(d) <= Hf) ? t : 0.0;
-                acc[k] += t;
-            }
-            const int dist = max(0, max(r.ci - whi, wlo - r.ci));
-            if (dist < r.dgi) gauss_term<R, MASKED, GM>(r, d0, Hf, acc);
+        for (int k = 0; k < R; ++k) { acc[k] = 0.0; N[k] = 0.0; D[k] = 1.0; }
+        cnt = 0;
+        every = flush_every;
+    }
+    __device__ __forceinline__ void flush() {
+#pragma unroll
+        for (int k = 0; k < R; ++k) { acc[k] += N[k] / D[k]; N[k] = 0.0; D[k] = 1.0; }
+        cnt = 0;
+    }
+};
+
+// One line against a lane's R points.  DIV == 0: IEEE divide per pair; DIV == 2: running fraction.
+template <int R, bool MASKED, int DIV>
+__device__ __forceinline__ void lorentz_term(double a2, double KL, int flags, double d0, double Hf, WaveAcc<R>& S) {
+    if (DIV == 0 || (flags & REC_DIRECT_DIV)) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double d = d0 + (double)k;
+            double t = KL / fma(d, d, a2);
+            if (MASKED) t = (fabs(d) <= Hf) ? t : 0.0;
+            S.acc[k] += t;
         }
     } else {
-        constexpr int F = 16;
-        for (int ib = i0; ib < i1; ib += F) {
-            const int ie = min(ib + F, i1);
-            double N[R], D[R];
 #pragma unroll
-            for (int k = 0; k < R; ++k) { N[k] = 0.0; D[k] = 1.0; }
-            for (int i = ib; i < ie; ++i) {
-                const LineRec r = load_rec(recs, i);
-                const double d0 = x0 - r.cf;
-                if (r.flags & REC_DIRECT_DIV) {
-#pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        const double d = d0 + (double)k;
-                        double t = r.KL / fma(d, d, r.a2);
-                        if (MASKED) t = (fabs(d) <= Hf) ? t : 0.0;
-                        acc[k] += t;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        const double d = d0 + (double)k;
-                        const double den = fma(d, d, r.a2);
-                        double K = r.KL;
-                        if (MASKED) K = (fabs(d) <= Hf) ? K : 0.0;
-                        const double t = K * D[k];
-                        N[k] = fma(N[k], den, t);
-                        D[k] *= den;
-                    }
-                }
-                const int dist = max(0, max(r.ci - whi, wlo - r.ci));
-                if (dist < r.dgi) gauss_term<R, MASKED, GM>(r, d0, Hf, acc);
-            }
-#pragma unroll
-            for (int k = 0; k < R; ++k) acc[k] += N[k] / D[k];
+        for (int k = 0; k < R; ++k) {
+            const double d = d0 + (double)k;
+            const double den = fma(d, d, a2);
+            double K = KL;
+            if (MASKED) K = (fabs(d) <= Hf) ? K : 0.0;
+            const double t = K * S.D[k];
+            S.N[k] = fma(S.N[k], den, t);
+            S.D[k] *= den;
+        }
+        if (++S.cnt == S.every) S.flush();
+    }
+}
+
+// ---- variants 0-2: line records through the scalar cache (one s_load per wave and line) ----
+template <int R, bool MASKED, int DIV, int GM>
+__device__ __forceinline__ void process_lines_scalar(const HotRec* hot, const ColdRec* cold, int i0, int i1, double x0,
+                                                     int wlo, int whi, double Hf, WaveAcc<R>& S) {
+    for (int i = i0; i < i1; ++i) {
+        Rec r = load_rec_scalar(hot, cold, i, false);
+        const double d0 = x0 - r.cf;
+        lorentz_term<R, MASKED, DIV>(r.a2, r.KL, r.flags, d0, Hf, S);
+        const int dist = max(0, max(r.ci - whi, wlo - r.ci));
+        if (dist < r.dgi) {
+            r = load_rec_scalar(hot, cold, i, true);
+            gauss_term<R, MASKED, GM>(r.KG, r.b, r.q2, d0, Hf, S.acc);
         }
     }
 }
 
-template <int R, int DIV, int GM>
-__global__ __launch_bounds__(256) void xsec_accumulate_kernel(const AccumJob* __restrict__ jobs) {
-    const AccumJob& J = jobs[blockIdx.y];
-    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a
-    // contiguous run of tiles: neighbouring tiles read almost the same line records.
-    const int n_tiles = J.n_tiles;
+// Line ranges of a wave whose points span [wlo, whi] (cidx is sorted):
+//   [iA, iB)  left-edge lines,   c in [wlo-H, whi-H)      -> masked
+//   [iB, iC)  interior lines,    c in [whi-H, wlo+H]      -> every point inside the support
+//   [iC, iD)  right-edge lines,  c in (wlo+H, whi+H]      -> masked
+__device__ __forceinline__ void wave_line_ranges(const int32_t* __restrict__ cidx, int n_lines, int wlo, int whi, int H,
+                                                 int lane, int& iA, int& iB, int& iC, int& iD) {
+    const long long tA = (long long)wlo - H, tB = (long long)whi - H;
+    const long long tC = (long long)wlo + H + 1, tD = (long long)whi + H + 1;
+    const long long tgt = lane == 0 ? tA : lane == 1 ? tB : lane == 2 ? tC : tD;
+    const int pos = lower_bound_i32(cidx, n_lines, tgt);
+    iA = __builtin_amdgcn_readlane(pos, 0);
+    iB = __builtin_amdgcn_readlane(pos, 1);
+    iC = __builtin_amdgcn_readlane(pos, 2);
+    iD = __builtin_amdgcn_readlane(pos, 3);
+    if (tB >= tC) { iB = iD; iC = iD; }      // span wider than the support: no interior line
+}
+
+// XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so each XCD gets a
+// contiguous run of tiles: neighbouring tiles read almost the same line records.
+__device__ __forceinline__ int xcd_tile(int b, int n_tiles) {
     const int chunk = (n_tiles + 7) >> 3;
-    const int b = blockIdx.x;
     const int slot = b >> 3;
-    if (slot >= chunk) return;
+    if (slot >= chunk) return -1;
     const int tile = (b & 7) * chunk + slot;
-    if (tile >= n_tiles) return;
+    return tile < n_tiles ? tile : -1;
+}
 
-    const int lane = threadIdx.x & 63;
-    const int wave = uniform_i32(threadIdx.x >> 6);
-    const int n_work = J.p_end;          // this job computes work-grid points [p_begin, p_end)
-    const long long wave_lo_ll = (long long)J.p_begin + (long long)tile * (256LL * R) + (long long)wave * (64LL * R);
-    if (wave_lo_ll >= n_work) return;
-    const int wlo = (int)wave_lo_ll;
-    const int whi = min(wlo + 64 * R - 1, n_work - 1);
-    const int H = J.H;
-
-    // line ranges of this wave (cidx is sorted):
-    //   [iA, iB)  left-edge lines,   c in [wlo-H, whi-H)      -> masked
-    //   [iB, iC)  interior lines,    c in [whi-H, wlo+H]      -> every point inside the support
-    //   [iC, iD)  right-edge lines,  c in (wlo+H, whi+H]      -> masked
-    int iA, iB, iC, iD;
-    {
-        const long long tA = (long long)wlo - H, tB = (long long)whi - H;
-        const long long tC = (long long)wlo + H + 1, tD = (long long)whi + H + 1;
-        const long long tgt = lane == 0 ? tA : lane == 1 ? tB : lane == 2 ? tC : tD;
-        const int pos = lower_bound_i32(J.cidx, J.n_lines, tgt);
-        iA = __builtin_amdgcn_readlane(pos, 0);
-        iB = __builtin_amdgcn_readlane(pos, 1);
-        iC = __builtin_amdgcn_readlane(pos, 2);
-        iD = __builtin_amdgcn_readlane(pos, 3);
-        if (tB >= tC) { iB = iD; iC = iD; }      // span wider than the support: no interior line
-    }
-
-    const int p0 = wlo + lane * R;
-    const double x0 = (double)p0;
-    const double Hf = (double)H;
-    double acc[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) acc[k] = 0.0;
-
-    const RecPtr recs = as_const_recs(J.recs);
-    process_lines<R, true, DIV, GM>(recs, iA, iB, x0, wlo, whi, Hf, acc);
-    process_lines<R, false, DIV, GM>(recs, iB, iC, x0, wlo, whi, Hf, acc);
-    process_lines<R, true, DIV, GM>(recs, iC, iD, x0, wlo, whi, Hf, acc);
-
-    double* __restrict__ out = J.out;
-    if (p0 + R <= n_work) {
+template <int R>
+__device__ __forceinline__ void store_points(double* __restrict__ out, int p0, int n_end, const double (&acc)[R]) {
+    if (p0 + R <= n_end) {
         if (R >= 2) {
 #pragma unroll
             for (int k = 0; k < R; k += 2) {
@@ -350,7 +342,223 @@ __global__ __launch_bounds__(256) void xsec_accumulate_kernel(const AccumJob* __
     } else {
 #pragma unroll
         for (int k = 0; k < R; ++k)
-            if (p0 + k < n_work) out[p0 + k] = acc[k];
+            if (p0 + k < n_end) out[p0 + k] = acc[k];
+    }
+}
+
+template <int R, int DIV, int GM>
+__global__ __launch_bounds__(256) void xsec_accumulate_kernel(const AccumJob* __restrict__ jobs) {
+    const AccumJob& J = jobs[blockIdx.y];
+    const int tile = xcd_tile(blockIdx.x, J.n_tiles);
+    if (tile < 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform_i32(threadIdx.x >> 6);
+    const int n_end = J.p_end;          // this job computes work-grid points [p_begin, p_end)
+    const long long wave_lo_ll = (long long)J.p_begin + (long long)tile * (256LL * R) + (long long)wave * (64LL * R);
+    if (wave_lo_ll >= n_end) return;
+    const int wlo = (int)wave_lo_ll;
+    const int whi = min(wlo + 64 * R - 1, n_end - 1);
+    const int H = J.H;
+    int iA, iB, iC, iD;
+    wave_line_ranges(J.cidx, J.n_lines, wlo, whi, H, lane, iA, iB, iC, iD);
+
+    const int p0 = wlo + lane * R;
+    const double x0 = (double)p0;
+    const double Hf = (double)H;
+    WaveAcc<R> S;
+    S.init(J.flush_every);
+    process_lines_scalar<R, true, DIV, GM>(J.hot, J.cold, iA, iB, x0, wlo, whi, Hf, S);
+    process_lines_scalar<R, false, DIV, GM>(J.hot, J.cold, iB, iC, x0, wlo, whi, Hf, S);
+    process_lines_scalar<R, true, DIV, GM>(J.hot, J.cold, iC, iD, x0, wlo, whi, Hf, S);
+    S.flush();
+    store_points<R>(J.out, p0, n_end, S.acc);
+}
+
+// ---- variant 3: wave-private LDS staging of the line records --------------------------------
+// The scalar cache is not a streaming path: with one dependent s_load per (wave, line) the
+// kernel ran at a tenth of the fp64 rate.  Here each wave streams its line range in chunks of
+// 64 records with coalesced 16-byte vector loads (lane l fetches record c0+l), parks the chunk
+// in its own 4 KB of LDS and reads every record back as a broadcast (all lanes, one address:
+// conflict-free).  The next chunk's global loads are in flight while the current chunk is
+// consumed, so neither HBM/L2 latency nor LDS latency is exposed, and no workgroup barrier is
+// needed: waves stay independent.
+//
+// LS waves of a workgroup can share the same 64*R grid points and split that span's line range
+// between them (small grids: more wavefronts without shrinking R); their partial sums meet in
+// LDS in a fixed order, so results stay deterministic.
+struct HotVals {
+    double cf, a2, KL;
+};
+
+__device__ __forceinline__ HotVals lds_hot(const double* __restrict__ lh, int j) {
+    const double* h = lh + j * 4;
+    HotVals v;
+    v.cf = h[0]; v.a2 = h[1]; v.KL = h[2];
+    return v;
+}
+
+// Lorentz terms of records j0..j1-1 of the chunk parked in this wave's LDS, as a branch-free
+// running-fraction loop: per point  d = d0+k, den = d*d+a2, t = K*D, N = N*den+t, D = D*den.
+// The NEXT record's broadcast read is issued before the current record's arithmetic, so the LDS
+// latency hides under the 5*R fp64 instructions (slot 63 is re-read harmlessly at the chunk end).
+// The flush test sits outside the inner loop (blocks of at most `every` lines), and Gaussian /
+// plain-divide lines are handled after the chunk from bit masks, so the hot loop has no branch.
+template <int R, bool MASKED>
+__device__ __forceinline__ void rf_segment(const double* __restrict__ lh, int j0, int j1, double x0, double Hf,
+                                           WaveAcc<R>& S) {
+    int j = j0;
+    while (j < j1) {
+        const int nb = min(S.every - S.cnt, j1 - j);
+        HotVals nxt = lds_hot(lh, j);
+#pragma unroll 2
+        for (int t = 0; t < nb; ++t) {
+            const HotVals cur = nxt;
+            nxt = lds_hot(lh, min(j + t + 1, 63));
+            const double d0 = x0 - cur.cf;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double d = d0 + (double)k;
+                const double den = fma(d, d, cur.a2);
+                double K = cur.KL;
+                if (MASKED) K = (fabs(d) <= Hf) ? K : 0.0;
+                const double tt = K * S.D[k];
+                S.N[k] = fma(S.N[k], den, tt);
+                S.D[k] *= den;
+            }
+        }
+        j += nb;
+        S.cnt += nb;
+        if (S.cnt >= S.every) S.flush();
+    }
+}
+
+// Rare per-record work of a chunk, driven by the masks computed when the chunk was staged:
+// gmask bit j: record j's Gaussian term can matter for some point of this wave;
+// dmask bit j: record j's denominator is outside the running-fraction range -> plain divide
+// (its LDS copy carries K = 0, a2 = 1 so the hot loop adds nothing for it).
+template <int R>
+__device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, const double* __restrict__ lc,
+                                             unsigned long long gmask, unsigned long long dmask, double x0, double Hf,
+                                             WaveAcc<R>& S) {
+    while (gmask) {
+        const int j = __builtin_ctzll(gmask);
+        gmask &= gmask - 1;
+        const double d0 = x0 - lh[j * 4];
+        const double* c = lc + j * 4;
+        gauss_term<R, true, 1>(c[0], c[1], c[2], d0, Hf, S.acc);
+    }
+    while (dmask) {
+        const int j = __builtin_ctzll(dmask);
+        dmask &= dmask - 1;
+        const double d0 = x0 - lh[j * 4];
+        const double* c = lc + j * 4;
+        const double a2 = 1.0 / c[1], KL = c[3];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double d = d0 + (double)k;
+            const double t = KL / fma(d, d, a2);
+            S.acc[k] += (fabs(d) <= Hf) ? t : 0.0;
+        }
+    }
+}
+
+template <int R, int LS>
+__global__ __launch_bounds__(256) void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs) {
+    constexpr int PG = 4 / LS;                       // point groups (64*R points each) per workgroup
+    __shared__ double s_hot[4][64 * 4];
+    __shared__ double s_cold[4][64 * 4];
+    __shared__ double s_red[LS > 1 ? 4 * 64 * R : 1];
+
+    const AccumJob& J = jobs[blockIdx.y];
+    const int tile = xcd_tile(blockIdx.x, J.n_tiles);
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform_i32(threadIdx.x >> 6);
+    const int grp = wave / LS, part = wave % LS;
+    const int n_end = J.p_end;
+    const long long wave_lo_ll = (long long)J.p_begin + (long long)(tile < 0 ? 0 : tile) * (64LL * R * PG) + (long long)grp * (64LL * R);
+    const bool active = tile >= 0 && wave_lo_ll < n_end;
+    if (LS == 1 && !active) return;                  // no barrier below when waves do not share points
+    const int wlo = active ? (int)wave_lo_ll : 0;
+    const int whi = active ? min(wlo + 64 * R - 1, n_end - 1) : 0;
+    const int H = J.H;
+    const int p0 = wlo + lane * R;
+    const double x0 = (double)p0;
+    const double Hf = (double)H;
+    WaveAcc<R> S;
+    S.init(J.flush_every);
+
+    if (active) {
+        int iA, iB, iC, iD;
+        wave_line_ranges(J.cidx, J.n_lines, wlo, whi, H, lane, iA, iB, iC, iD);
+        // this wave's share of the span's lines
+        const long long nl = (long long)iD - iA;
+        const int mA = iA + (int)(nl * part / LS), mD = iA + (int)(nl * (part + 1) / LS);
+        // global address space made explicit: a flat load would also count on lgkmcnt and every
+        // LDS wait would then drain the prefetch of the next chunk
+        typedef double v2f64 __attribute__((ext_vector_type(2)));
+        typedef const v2f64 __attribute__((address_space(1)))* GlobalF64x2;
+        const GlobalF64x2 gh = (GlobalF64x2)(unsigned long long)J.hot;
+        const GlobalF64x2 gc = (GlobalF64x2)(unsigned long long)J.cold;
+        double* lh = s_hot[wave];
+        double* lc = s_cold[wave];
+        // software pipeline: registers hold the NEXT chunk while LDS holds the current one
+        v2f64 h0 = {0, 0}, h1 = {0, 0}, c0v = {0, 0}, c1v = {0, 0};
+        if (mA + lane < mD) {
+            const long long r = (long long)(mA + lane) * 2;
+            h0 = gh[r]; h1 = gh[r + 1]; c0v = gc[r]; c1v = gc[r + 1];
+        }
+        for (int c0 = mA; c0 < mD; c0 += 64) {
+            const int c1 = min(c0 + 64, mD);
+            __builtin_amdgcn_wave_barrier();
+            // per-record branch decisions for the whole chunk, one lane per record
+            const int ci = (int)h0.x;
+            const int dgi = __double2loint(h1.y), fl = __double2hiint(h1.y);
+            const bool valid = c0 + lane < c1;
+            const unsigned long long gmask = __ballot(valid && max(0, max(ci - whi, wlo - ci)) < dgi);
+            const bool direct = (fl & REC_DIRECT_DIV) != 0;
+            const unsigned long long dmask = __ballot(valid && direct);
+            v2f64 w0 = h0, w1 = h1;
+            if (direct) { w0.y = 1.0; w1.x = 0.0; }          // a2 = 1, KL = 0 in the hot loop's copy
+            reinterpret_cast<v2f64*>(lh)[lane * 2] = w0;
+            reinterpret_cast<v2f64*>(lh)[lane * 2 + 1] = w1;
+            reinterpret_cast<v2f64*>(lc)[lane * 2] = c0v;
+            reinterpret_cast<v2f64*>(lc)[lane * 2 + 1] = c1v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (c1 + lane < mD) {
+                const long long r = (long long)(c1 + lane) * 2;
+                h0 = gh[r]; h1 = gh[r + 1]; c0v = gc[r]; c1v = gc[r + 1];
+            }
+            // the three classes of lines inside this chunk, as offsets into the chunk
+            const int a0 = 0, a1 = max(min(iB, c1), c0) - c0;
+            const int b1 = max(min(iC, c1), c0) - c0;
+            const int e1 = c1 - c0;
+            rf_segment<R, true>(lh, a0, a1, x0, Hf, S);
+            rf_segment<R, false>(lh, a1, b1, x0, Hf, S);
+            rf_segment<R, true>(lh, b1, e1, x0, Hf, S);
+            chunk_extras<R>(lh, lc, gmask, dmask, x0, Hf, S);
+        }
+        S.flush();
+    }
+
+    if (LS == 1) {
+        store_points<R>(J.out, p0, n_end, S.acc);
+    } else {
+        // fixed-order reduction over the LS waves that share these points
+        double* red = s_red + grp * (LS * 64 * R);
+#pragma unroll
+        for (int k = 0; k < R; ++k) red[(part * R + k) * 64 + lane] = S.acc[k];
+        __syncthreads();
+        if (part == 0 && active) {
+            double tot[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                double t = red[k * 64 + lane];
+                for (int q = 1; q < LS; ++q) t += red[(q * R + k) * 64 + lane];
+                tot[k] = t;
+            }
+            store_points<R>(J.out, p0, n_end, tot);
+        }
     }
 }
 
@@ -525,7 +733,7 @@ void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStrea
 }
 
 template <int R>
-static void launch_accum_r(const AccumJob* d_jobs, int n_jobs, int max_tiles, int variant, hipStream_t s) {
+static void launch_accum_scalar(const AccumJob* d_jobs, int n_jobs, int max_tiles, int variant, hipStream_t s) {
     dim3 grid(((max_tiles + 7) / 8) * 8, n_jobs);
     switch (variant) {
         case 0: hipLaunchKernelGGL((xsec_accumulate_kernel<R, 0, 0>), grid, dim3(256), 0, s, d_jobs); break;
@@ -534,13 +742,37 @@ static void launch_accum_r(const AccumJob* d_jobs, int n_jobs, int max_tiles, in
     }
 }
 
-void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int variant, hipStream_t s) {
+template <int R>
+static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, int LS, hipStream_t s) {
+    dim3 grid(((max_tiles + 7) / 8) * 8, n_jobs);
+    switch (LS) {
+        case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4>), grid, dim3(256), 0, s, d_jobs); break;
+        case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2>), grid, dim3(256), 0, s, d_jobs); break;
+        default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1>), grid, dim3(256), 0, s, d_jobs); break;
+    }
+}
+
+// grid points one workgroup covers
+int accumulate_tile_points(int R, int LS, int variant) {
+    return variant >= 3 ? 64 * R * (4 / LS) : 256 * R;
+}
+
+void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant, hipStream_t s) {
     if (n_jobs <= 0 || max_tiles <= 0) return;
+    if (variant >= 3) {
+        switch (R) {
+            case 1: launch_accum_lds<1>(d_jobs, n_jobs, max_tiles, LS, s); break;
+            case 2: launch_accum_lds<2>(d_jobs, n_jobs, max_tiles, LS, s); break;
+            case 4: launch_accum_lds<4>(d_jobs, n_jobs, max_tiles, LS, s); break;
+            default: launch_accum_lds<8>(d_jobs, n_jobs, max_tiles, LS, s); break;
+        }
+        return;
+    }
     switch (R) {
-        case 1: launch_accum_r<1>(d_jobs, n_jobs, max_tiles, variant, s); break;
-        case 2: launch_accum_r<2>(d_jobs, n_jobs, max_tiles, variant, s); break;
-        case 4: launch_accum_r<4>(d_jobs, n_jobs, max_tiles, variant, s); break;
-        default: launch_accum_r<8>(d_jobs, n_jobs, max_tiles, variant, s); break;
+        case 1: launch_accum_scalar<1>(d_jobs, n_jobs, max_tiles, variant, s); break;
+        case 2: launch_accum_scalar<2>(d_jobs, n_jobs, max_tiles, variant, s); break;
+        case 4: launch_accum_scalar<4>(d_jobs, n_jobs, max_tiles, variant, s); break;
+        default: launch_accum_scalar<8>(d_jobs, n_jobs, max_tiles, variant, s); break;
     }
 }
 
