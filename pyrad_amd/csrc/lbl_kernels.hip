@@ -163,9 +163,9 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
             dg = (u2 > 0.0) ? sqrt(u2) * a + 2.0 : 0.0;
         }
         r.dgi = (dg < 2.0e9) ? (int32_t)dg : 2000000000;
-        // Gaussian recurrence along a lane's consecutive points needs exp(b*R^2) finite and
-        // well inside the normal range; very narrow profiles take the direct exp instead
-        rc.q2 = (rc.b <= 8.0) ? exp(-2.0 * rc.b) : -1.0;
+        // Gaussian recurrence along a lane's consecutive points: only for b <= 4 (see gauss_term);
+        // narrower profiles take one exp per point
+        rc.q2 = (rc.b <= 4.0) ? exp(-2.0 * rc.b) : -1.0;
         rc.KLd = r.KL;
         J.hot[i] = r;
         J.cold[i] = rc;
@@ -197,40 +197,35 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t* __restrict__ a, in
 }
 
 // Gaussian part of one line for a lane's R consecutive points (d0 = offset of the lane's
-// first point from the line centre).
+// first point from the line centre), masked to the line's support |d| <= H.
 //   GM == 0: one exp per point.
-//   GM == 1: two exps per lane, then g(d+1) = g(d) r(d), r(d+1) = r(d) q2 walking AWAY from
-//            the centre (lanes left of the centre are mirrored so the terms only decay).
-template <int R, bool MASKED, int GM>
-__device__ __forceinline__ void gauss_term(double KG, double b, double q2, double d0, double Hf, double (&acc)[R]) {
-    if (GM == 0 || q2 < 0.0 || R < 4) {
+//   GM == 1: two exps per lane, then g(d+1) = g(d) r(d), r(d+1) = r(d) q2 with
+//            r(d) = exp(-b (2d+1)), q2 = exp(-2b): 2 multiplies per further point.
+// The recurrence keeps full relative precision while g(d0) is a normal number.  Walking
+// TOWARDS the centre the terms grow by at most exp(b (R-1) (2|d0| - R + 1)); K1 enables the
+// recurrence only for b <= 4 (q2 >= 0), for which a lane whose first point has underflowed
+// (b d0^2 > 708) cannot reach a point where the term still matters (b d^2 < ~45) within R <= 8
+// steps: there  b (d0^2 - d^2) <= 14 sqrt(45 b) + 49 b < 400.  The exponent of r is clamped so
+// that a far lane computes 0 * finite = 0, never 0 * inf.
+template <int R, int GM>
+__device__ __forceinline__ void gauss_term(double KG, double b, bool recur, double d0, double Hf, double q2,
+                                           double (&acc)[R]) {
+    if (GM == 0 || !recur || R < 4) {
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const double d = d0 + (double)k;
-            double t = KG * exp(-b * (d * d));
-            if (MASKED) t = (fabs(d) <= Hf) ? t : 0.0;
-            acc[k] += t;
+            const double t = KG * exp(-b * (d * d));
+            acc[k] += (fabs(d) <= Hf) ? t : 0.0;
         }
     } else {
-        const bool mirror = (2.0 * d0 + (double)(R - 1)) < 0.0;
-        const double e0 = mirror ? -(d0 + (double)(R - 1)) : d0;
-        double g = KG * exp(-b * (e0 * e0));
-        double rr = exp(-b * (2.0 * e0 + 1.0));
-        double t[R];
+        double g = KG * exp(-b * (d0 * d0));
+        double rr = exp(fmin(-b * (2.0 * d0 + 1.0), 700.0));
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            t[k] = g;
+            const double d = d0 + (double)k;
+            acc[k] += (fabs(d) <= Hf) ? g : 0.0;
             g *= rr;
             rr *= q2;
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            double v = mirror ? t[R - 1 - k] : t[k];
-            if (MASKED) {
-                const double d = d0 + (double)k;
-                v = (fabs(d) <= Hf) ? v : 0.0;
-            }
-            acc[k] += v;
         }
     }
 }
@@ -295,7 +290,7 @@ __device__ __forceinline__ void process_lines_scalar(const HotRec* hot, const Co
         const int dist = max(0, max(r.ci - whi, wlo - r.ci));
         if (dist < r.dgi) {
             r = load_rec_scalar(hot, cold, i, true);
-            gauss_term<R, MASKED, GM>(r.KG, r.b, r.q2, d0, Hf, S.acc);
+            gauss_term<R, GM>(r.KG, r.b, r.q2 >= 0.0, d0, Hf, r.q2, S.acc);
         }
     }
 }
@@ -438,14 +433,24 @@ __device__ __forceinline__ void rf_segment(const double* __restrict__ lh, int j0
 // (its LDS copy carries K = 0, a2 = 1 so the hot loop adds nothing for it).
 template <int R>
 __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, const double* __restrict__ lc,
-                                             unsigned long long gmask, unsigned long long dmask, double x0, double Hf,
-                                             WaveAcc<R>& S) {
-    while (gmask) {
-        const int j = __builtin_ctzll(gmask);
-        gmask &= gmask - 1;
+                                             unsigned long long gmask, unsigned long long emask,
+                                             unsigned long long dmask, double x0, double Hf, WaveAcc<R>& S) {
+    // emask bit j: record j must use one exp per point (profile too narrow for the recurrence)
+    unsigned long long m = gmask & ~emask;
+    while (m) {
+        const int j = __builtin_ctzll(m);
+        m &= m - 1;
         const double d0 = x0 - lh[j * 4];
         const double* c = lc + j * 4;
-        gauss_term<R, true, 1>(c[0], c[1], c[2], d0, Hf, S.acc);
+        gauss_term<R, 1>(c[0], c[1], true, d0, Hf, c[2], S.acc);
+    }
+    m = gmask & emask;
+    while (m) {
+        const int j = __builtin_ctzll(m);
+        m &= m - 1;
+        const double d0 = x0 - lh[j * 4];
+        const double* c = lc + j * 4;
+        gauss_term<R, 0>(c[0], c[1], false, d0, Hf, 0.0, S.acc);
     }
     while (dmask) {
         const int j = __builtin_ctzll(dmask);
@@ -463,7 +468,7 @@ __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, cons
 }
 
 template <int R, int LS>
-__global__ __launch_bounds__(256) void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs) {
+__global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs) {
     constexpr int PG = 4 / LS;                       // point groups (64*R points each) per workgroup
     __shared__ double s_hot[4][64 * 4];
     __shared__ double s_cold[4][64 * 4];
@@ -517,6 +522,7 @@ __global__ __launch_bounds__(256) void xsec_accumulate_lds_kernel(const AccumJob
             const unsigned long long gmask = __ballot(valid && max(0, max(ci - whi, wlo - ci)) < dgi);
             const bool direct = (fl & REC_DIRECT_DIV) != 0;
             const unsigned long long dmask = __ballot(valid && direct);
+            const unsigned long long emask = __ballot(c1v.x < 0.0);          // q2 < 0: no recurrence
             v2f64 w0 = h0, w1 = h1;
             if (direct) { w0.y = 1.0; w1.x = 0.0; }          // a2 = 1, KL = 0 in the hot loop's copy
             reinterpret_cast<v2f64*>(lh)[lane * 2] = w0;
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(256) void xsec_accumulate_lds_kernel(const AccumJob
             rf_segment<R, true>(lh, a0, a1, x0, Hf, S);
             rf_segment<R, false>(lh, a1, b1, x0, Hf, S);
             rf_segment<R, true>(lh, b1, e1, x0, Hf, S);
-            chunk_extras<R>(lh, lc, gmask, dmask, x0, Hf, S);
+            chunk_extras<R>(lh, lc, gmask, emask, dmask, x0, Hf, S);
         }
         S.flush();
     }
