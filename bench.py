@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="accumulate kernel variant 0|1|2|3 (default: library default 3)")
     ap.add_argument("--points-per-lane", type=int, default=None)
     ap.add_argument("--line-split", type=int, default=None)
+    ap.add_argument("--tile-order", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather", default="abs_coef", choices=["abs_coef", "all"])
@@ -152,6 +153,8 @@ def main():
         ctx.set_option("accum_points_per_lane", args.points_per_lane)
     if args.line_split is not None:
         ctx.set_option("accum_line_split", args.line_split)
+    if args.tile_order is not None:
+        ctx.set_option("accum_tile_order", args.tile_order)
 
     comm = None
     rdzv = None

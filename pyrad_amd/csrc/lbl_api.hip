@@ -37,18 +37,21 @@ struct lbl_ctx {
     DeviceArena cold;       // ColdRec per line
     DeviceArena cidx;       // int32 per line
     DeviceArena work;       // work grids that need a regrid
-    DeviceArena jobs;       // PrepJob[] + AccumJob[] + ColumnArgs
-    DeviceArena counts;     // regime counters, 3 x u64 per job
+    DeviceArena jobs;       // PrepJob[] + AccumJob[] + regime counters (3 x u64 per job)
+    DeviceArena colargs;    // ColumnArgs of the column sweep
     DeviceArena red;        // band-integral partials + result
     void* host_stage = nullptr;   // pinned staging ring for job descriptors
     size_t host_stage_cap = 0;
     size_t host_stage_head = 0;
     int last_jobs = 0;
+    unsigned long long* last_counts = nullptr;
     // tuning knobs (lbl_set_option)
     int accum_variant = 3;   // 0: IEEE divide + exp per pair; 1: running fraction; 2: + Gaussian recurrence
                              // (0-2 fetch records through the scalar cache); 3: 2 with wave-private LDS staging
     int accum_R = 0;         // points per lane, 0 = choose per launch
     int accum_LS = 0;        // waves sharing one span of points (line split), 0 = choose per launch
+    int tile_order = 1;      // 1: natural order (default; measured 8 % faster on the clustered C2 grid:
+                             // all CUs work through one region together); 0: each XCD gets a contiguous run
     int live_objects = 0;
     // event timing (lbl_profile_*)
     bool profiling = false;
@@ -207,7 +210,7 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& v : ctx->ev_rec) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->red};
+    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->colargs, &ctx->red};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     (void)hipStreamDestroy(ctx->stream);
@@ -287,6 +290,8 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) {
         if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_points_per_lane must be 0, 1, 2, 4 or 8");
         ctx->accum_R = value;
+    } else if (!strcmp(key, "accum_tile_order")) {
+        ctx->tile_order = value ? 1 : 0;
     } else if (!strcmp(key, "accum_line_split")) {
         if (!(value == 0 || value == 1 || value == 2 || value == 4))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_line_split must be 0, 1, 2 or 4");
@@ -475,11 +480,15 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     if ((rc = arena_reserve(ctx, ctx->cold, std::max<size_t>(tot_lines, 1) * sizeof(ColdRec)))) return rc;
     if ((rc = arena_reserve(ctx, ctx->cidx, std::max<size_t>(tot_lines, 1) * sizeof(int32_t)))) return rc;
     if ((rc = arena_reserve(ctx, ctx->work, std::max<size_t>(tot_work, 1) * sizeof(double)))) return rc;
-    if ((rc = arena_reserve(ctx, ctx->counts, (size_t)n_jobs * 3 * sizeof(unsigned long long)))) return rc;
+    // descriptors and the regime counters share one device block so that a single H2D copy both
+    // refreshes the descriptors and zeroes the counters (one stream operation instead of two)
     const size_t prep_bytes = (size_t)n_jobs * sizeof(PrepJob), acc_bytes = (size_t)n_jobs * sizeof(AccumJob);
-    if ((rc = arena_reserve(ctx, ctx->jobs, prep_bytes + acc_bytes))) return rc;
+    const size_t cnt_bytes = (size_t)n_jobs * 3 * sizeof(unsigned long long);
+    if ((rc = arena_reserve(ctx, ctx->jobs, prep_bytes + acc_bytes + cnt_bytes))) return rc;
     void* stage = nullptr;
-    if ((rc = stage_alloc(ctx, prep_bytes + acc_bytes, &stage))) return rc;
+    if ((rc = stage_alloc(ctx, prep_bytes + acc_bytes + cnt_bytes, &stage))) return rc;
+    memset((char*)stage + prep_bytes + acc_bytes, 0, cnt_bytes);
+    unsigned long long* d_counts = (unsigned long long*)((char*)ctx->jobs.ptr + prep_bytes + acc_bytes);
 
     int R, LS;
     choose_shape(ctx, total_points, min_H, &R, &LS);
@@ -496,11 +505,12 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         p.hot = (HotRec*)ctx->recs.ptr + line_off[j];
         p.cold = (ColdRec*)ctx->cold.ptr + line_off[j];
         p.cidx = (int32_t*)ctx->cidx.ptr + line_off[j];
-        p.regime_counts = (unsigned long long*)ctx->counts.ptr + 3 * (size_t)j;
+        p.regime_counts = d_counts + 3 * (size_t)j;
         if (dbg) { p.dbg_index = dbg->index; p.dbg_lhw = dbg->lhw; p.dbg_ghw = dbg->ghw; p.dbg_intensity = dbg->inten; p.dbg_regime = dbg->regime; }
         p.T = iso[j].T; p.P = iso[j].P; p.q_frac = iso[j].q_frac; p.molmass = iso[j].molmass;
         p.Q_T = iso[j].Q_T; p.Q_296 = iso[j].Q_296;
         p.range_min = grid[j].range_min; p.resolution = grid[j].resolution;
+        p.log_t0_over_T = std::log(296.0 / iso[j].T);
         p.n_lines = (int32_t)L->n;
         AccumJob& a = ha[j];
         memset(&a, 0, sizeof a);
@@ -515,12 +525,13 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         a.p_end = (int32_t)(sf + sc);
         a.n_tiles = (int32_t)((sc + tile_pts - 1) / tile_pts);
         a.flush_every = (a.H + 64 * R + 1 <= 40000) ? 32 : 16;
+        a.pad = ctx->tile_order;
         max_tiles = std::max(max_tiles, a.n_tiles);
     }
     PrepJob* dp = (PrepJob*)ctx->jobs.ptr;
     AccumJob* da = (AccumJob*)((char*)ctx->jobs.ptr + prep_bytes);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->jobs.ptr, stage, prep_bytes + acc_bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->counts.ptr, 0, (size_t)n_jobs * 3 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->jobs.ptr, stage, prep_bytes + acc_bytes + cnt_bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->last_counts = d_counts;
     hipEvent_t ev = prof_begin(ctx);
     launch_line_prep(dp, n_jobs, max_lines, ctx->stream);
     prof_end(ctx, PROF_PREP, ev);
@@ -561,7 +572,7 @@ extern "C" int lbl_last_regime_counts(lbl_ctx* ctx, int n_jobs, int64_t* counts)
     if (!ctx || !counts) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     if (n_jobs < 0 || n_jobs > ctx->last_jobs) return fail(ctx, LBL_ERR_BAD_ARG, "n_jobs exceeds the last batch (%d)", ctx->last_jobs);
     if (n_jobs == 0) return LBL_OK;
-    HIP_TRY(ctx, hipMemcpyAsync(counts, ctx->counts.ptr, (size_t)n_jobs * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(counts, ctx->last_counts, (size_t)n_jobs * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return LBL_OK;
 }
@@ -701,7 +712,7 @@ extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* cons
     if (!I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "need I_in or surface_T > 0");
     void* stage = nullptr;
     if ((rc = stage_alloc(ctx, sizeof(ColumnArgs), &stage))) return rc;
-    if ((rc = arena_reserve(ctx, ctx->jobs, sizeof(ColumnArgs)))) return rc;
+    if ((rc = arena_reserve(ctx, ctx->colargs, sizeof(ColumnArgs)))) return rc;
     ColumnArgs* a = (ColumnArgs*)stage;
     memset(a, 0, sizeof *a);
     for (int l = 0; l < n_layers; ++l) {
@@ -718,9 +729,9 @@ extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* cons
     a->I_out = I_out->d;
     a->n = n; a->first = first; a->count = count;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->jobs.ptr, a, sizeof(ColumnArgs), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->colargs.ptr, a, sizeof(ColumnArgs), hipMemcpyHostToDevice, ctx->stream));
     hipEvent_t ev = prof_begin(ctx);
-    launch_column_sweep((const ColumnArgs*)ctx->jobs.ptr, count, ctx->stream);
+    launch_column_sweep((const ColumnArgs*)ctx->colargs.ptr, count, ctx->stream);
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;

@@ -65,6 +65,7 @@ struct PrepJob {
     long long* dbg_index; double* dbg_lhw; double* dbg_ghw; double* dbg_intensity; int32_t* dbg_regime;
     double T, P, q_frac, molmass, Q_T, Q_296;
     double range_min, resolution;
+    double log_t0_over_T;   // ln(296/T), computed once per job on the host
     int32_t n_lines;
     int32_t pad;
 };

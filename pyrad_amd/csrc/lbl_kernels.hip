@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
         // Line.broadenedLine (pyradClasses.py:252-254)
         const double broadened = nu + J.delta_air[i] * P / p0;
         // Line.lorentzHW (pyradClasses.py:256-259)
-        const double lhw = ((1.0 - q) * J.gamma_air[i] + q * J.gamma_self[i]) * (P / p0) * pow(t0 / T, J.n_air[i]);
+        // (t0/T)**n evaluated as exp(n ln(t0/T)) with the logarithm hoisted to the host (one per job)
+        const double lhw = ((1.0 - q) * J.gamma_air[i] + q * J.gamma_self[i]) * (P / p0) * exp(J.n_air[i] * J.log_t0_over_T);
         // Isotope.molMass (pyradClasses.py:294-296), Line.gaussianHW (pyradClasses.py:261-263)
         const double m = J.molmass / 1000.0 / avo;
         const double ghw = broadened * sqrt(2.0 * kB * T / m / (cLight * cLight));
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
                     u2 = 0.0;
                 } else {
                     double v = log(C);
-                    for (int it = 0; it < 6; ++it) v = log(C * (1.0 + v));
+                    for (int it = 0; it < 3; ++it) v = log(C * (1.0 + v));   // contracts by 1/(1+v) per step
                     u2 = fmin(v + 1.0, u2_under);
                 }
             }
@@ -314,7 +315,8 @@ __device__ __forceinline__ void wave_line_ranges(const int32_t* __restrict__ cid
 
 // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so each XCD gets a
 // contiguous run of tiles: neighbouring tiles read almost the same line records.
-__device__ __forceinline__ int xcd_tile(int b, int n_tiles) {
+__device__ __forceinline__ int xcd_tile(int b, int n_tiles, int natural = 0) {
+    if (natural) return b < n_tiles ? b : -1;
     const int chunk = (n_tiles + 7) >> 3;
     const int slot = b >> 3;
     if (slot >= chunk) return -1;
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_ker
     __shared__ double s_red[LS > 1 ? 4 * 64 * R : 1];
 
     const AccumJob& J = jobs[blockIdx.y];
-    const int tile = xcd_tile(blockIdx.x, J.n_tiles);
+    const int tile = xcd_tile(blockIdx.x, J.n_tiles, J.pad);
     const int lane = threadIdx.x & 63;
     const int wave = uniform_i32(threadIdx.x >> 6);
     const int grp = wave / LS, part = wave % LS;
