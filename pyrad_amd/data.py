@@ -151,7 +151,7 @@ class PyradDataDir:
         os.makedirs(d, exist_ok=True)
         nu = np.asarray(lines["nu"])
         if nu.size:
-            for seg in range(int(nu.min() / 100) * 100, int(nu.max()) + 100, 100):
+            for seg in range(int(nu.min() / 100) * 100, int(nu.max() / 100) * 100 + 100, 100):
                 m = (nu >= seg) & (nu < seg + 100)
                 with open('%s/%s.pyr' % (d, seg), 'w') as f:
                     for i in np.nonzero(m)[0]:

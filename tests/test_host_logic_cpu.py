@@ -1,0 +1,115 @@
+"""CPU: host-side logic of the build — layer grid scalars, data readers in PyRad's on-disk
+formats, the dirty-flag protocol wiring, tables and unit converters."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, unpack_lines
+from pyrad_amd import data, engine, model, settings, synthetic
+from oracle import pyrad_oracle as orc
+
+
+def test_layer_grid_matches_oracle_and_goldens():
+    z = load_golden("G3_pressure_ladder")
+    for j, P in enumerate(z["P_list"]):
+        g = engine.layer_grid(float(P), 640, 660, .01, True)
+        o = orc.layer_grid(float(P), 640, 660, .01, True)
+        for key in ("dfc", "eff_min", "eff_max", "resolution", "n_base", "n_work", "W"):
+            assert g[key] == o[key], key
+        assert (g["W"], g["n_work"]) == (int(z["P%d.W" % j]), int(z["P%d.n_work" % j]))
+    g = engine.layer_grid(1013.25, 500, 900, .001, False)
+    assert (g["n_base"], g["W"], g["resolution"]) == (400000, 5000, .001)
+    assert np.array_equal(engine.x_axis(600, 700, .01), load_golden("G1_c1_cell")["x_axis"])
+
+
+def test_eval_count_matches_oracle():
+    cfg = synthetic.config_c1(n_lines=500)
+    lines = cfg["molecules"][0]["lines"]
+    g = orc.layer_grid(1013.25, 600, 700, .01, True)
+    sel = orc.select_window(lines, g["eff_min"], g["eff_max"])
+    lq = orc.line_quantities(sel, 296, 1013.25, 4e-4, 43.98983, 600, .01)
+    total = orc.eval_count(lq["index"], g["W"], g["n_work"])
+    assert engine.eval_count(sel["nu"], 600, .01, g["W"], g["n_work"]) == total
+    parts = 0
+    for rank in range(3):
+        S, first, count = engine.shard_bounds(g["n_work"], 3, rank)
+        parts += engine.eval_count(sel["nu"], 600, .01, g["W"], g["n_work"], (first, count))
+    assert parts == total
+
+
+def test_concentration_setters_and_converters_match_golden():
+    z = load_golden("G0_functions")
+    got = [model.concentration_from_kwargs(ppm=400.0), model.concentration_from_kwargs(ppb=1.0),
+           model.concentration_from_kwargs(ppb=1800.0), model.concentration_from_kwargs(**{"%": 1.0}),
+           model.concentration_from_kwargs(concentration=0.0004)]
+    assert np.array_equal(np.array(got), z["conc_values"])
+    conv = [model.convertLength(2.0, "m"), model.convertLength(2.0, "ft"), model.convertLength(2.0, "in"),
+            model.convertPressure(2.0, "atm"), model.convertPressure(2.0, "bar"), model.convertPressure(2.0, "pa"),
+            model.convertRange(15.0, "um"), model.convertTemperature(15.0, "C"), model.convertTemperature(59.0, "F")]
+    assert np.array_equal(np.array(conv), z["convert"])
+    assert model.convertTemperature(15.0, "C") == 288          # +273, not 273.15 (cls:154)
+
+
+def test_tables():
+    assert model.MOLECULE_ID['co2'] == 2 and model.MOLECULE_ID['cocl2'] == 49 and len(model.MOLECULE_ID) == 49
+    assert model.getGlobalIsotope(2, 3) == [7, 8, 9]
+    assert model.HITRAN_GLOBAL_ISO[2][12] == 122          # the cls:952 copy of the table
+    assert model.HITRAN_GLOBAL_ISO[16] == {1: 19, 2: 11, 3: 111, 4: 112}
+    assert model.getGlobalIsotope(6, 1) == [32] and model.getGlobalIsotope(3, 1) == [16]
+
+
+def test_pyrad_data_dir_round_trip(tmp_path):
+    """Reader of PyRad's on-disk cache: column order, strict bounds, last-wins duplicates,
+    '#' headers, the NULL_TAG sentinel, 100 cm^-1 segment names."""
+    lines = synthetic.make_lines(7, 400, 580, 730)
+    root = str(tmp_path / "data")
+    data.PyradDataDir.write_tree(root, 7, lines, synthetic.q_table("co2", 400), synthetic.mol_params("co2"), 2, 1)
+    assert sorted(f for f in os.listdir(root + "/7") if f.endswith(".pyr")) == ["500.pyr", "600.pyr", "700.pyr", "params.pyr"]
+    src = data.PyradDataDir(root)
+    assert src.readMolParams(7) == [7, "CO2", 2, 1, 1.0, 286.09, 1, 43.98983]
+    assert src.getQData(7)[296] == synthetic.q_table("co2", 400)[296]
+    got = src.gatherData(7, 595.0, 705.0)
+    m = (lines["nu"] > 595.0) & (lines["nu"] < 705.0)
+    for k in ("nu", "sw", "a", "elower", "gamma_air", "gamma_self", "delta_air", "n_air"):
+        assert np.array_equal(got[k], lines[k][m]), k
+    assert data.PyradDataDir.segments(595.0, 705.0) == [500, 600, 700]
+    # strict bounds (ut:437-438)
+    nu0 = float(lines["nu"][m][0])
+    assert src.gatherData(7, nu0, 705.0)["nu"][0] > nu0
+    # duplicate wavenumber: the later row wins (ut:447)
+    with open(root + "/7/600.pyr", "a") as f:
+        f.write("2,1,%r,9.9e-20,1.0,10.0,0.07,0.09,-0.001,0.7\n" % float(lines["nu"][m][5]))
+    got2 = src.gatherData(7, 595.0, 705.0)
+    assert len(got2["nu"]) == m.sum() and got2["sw"][5] == 9.9e-20
+    # NULL_TAG segment = empty; missing segment = loud error (the reference would download)
+    with open(root + "/7/700.pyr", "w") as f:
+        f.write(data.NULL_TAG + "\n")
+    assert src.gatherData(7, 595.0, 705.0)["nu"].max() < 700
+    os.remove(root + "/7/500.pyr")
+    with pytest.raises(FileNotFoundError):
+        src.gatherData(7, 595.0, 705.0)
+
+
+def test_memory_source_dedupe_and_window():
+    src = data.MemorySource()
+    lines = synthetic.make_lines(9, 50, 600, 610)
+    dup = {k: np.concatenate([v, v[3:4]]) for k, v in lines.items()}
+    dup["sw"][-1] = 1.23e-19
+    src.register(7, dup, {296: 286.09}, synthetic.mol_params("co2"))
+    got = src.gatherData(7, 600, 610)
+    assert len(got["nu"]) == 50 and got["sw"][3] == 1.23e-19
+    assert np.all(np.diff(got["nu"]) > 0)
+
+
+def test_shard_bounds_cover_grid():
+    for n in (1, 7, 400000, 2400001):
+        for world in (1, 2, 3, 8):
+            S = None
+            covered = 0
+            for r in range(world):
+                s, first, count = engine.shard_bounds(n, world, r)
+                S = s
+                assert first == min(r * s, n) and 0 <= count <= s
+                covered += count
+            assert covered == n and S * world >= n
