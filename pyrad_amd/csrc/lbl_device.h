@@ -38,7 +38,10 @@ struct __attribute__((aligned(32))) ColdRec {
 };
 static_assert(sizeof(HotRec) == 32 && sizeof(ColdRec) == 32, "record halves must be 32 bytes");
 
-enum : int32_t { REC_DIRECT_DIV = 1 };
+enum : int32_t {
+    REC_DIRECT_DIV = 1,   // Lorentz denominator outside the running-fraction range: plain divide
+    REC_NO_RECUR = 2      // Gaussian too narrow for the two-exp recurrence (b > 4): one exp per point
+};
 
 // One accumulate job = one isotopologue of one layer (Isotope.createCrossSection).
 struct AccumJob {

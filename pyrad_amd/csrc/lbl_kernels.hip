@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
         // Gaussian recurrence along a lane's consecutive points: only for b <= 4 (see gauss_term);
         // narrower profiles take one exp per point
         rc.q2 = (rc.b <= 4.0) ? exp(-2.0 * rc.b) : -1.0;
+        if (!(rc.b <= 4.0)) r.flags |= REC_NO_RECUR;
         rc.KLd = r.KL;
         J.hot[i] = r;
         J.cold[i] = rc;
@@ -469,12 +470,17 @@ __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, cons
     }
 }
 
+// LDS slot of grid-point offset o within a wave's span (padded so that a lane writing its R
+// consecutive points and a lane reading every 64th point are both nearly conflict-free)
+__device__ __forceinline__ int span_slot(int o) { return o + (o >> 4); }
+
 template <int R, int LS>
 __global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs) {
     constexpr int PG = 4 / LS;                       // point groups (64*R points each) per workgroup
-    __shared__ double s_hot[4][64 * 4];
-    __shared__ double s_cold[4][64 * 4];
-    __shared__ double s_red[LS > 1 ? 4 * 64 * R : 1];
+    // per wave: hot records [0,256), cold records [256,512); after the line loop the same words
+    // hold the wave's 64*R sums in point order (+ padding) for the coalesced store
+    constexpr int STAGE = (68 * R > 512) ? 68 * R : 512;
+    __shared__ double s_stage[4][STAGE];
 
     const AccumJob& J = jobs[blockIdx.y];
     const int tile = xcd_tile(blockIdx.x, J.n_tiles, J.pad);
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_ker
     const int n_end = J.p_end;
     const long long wave_lo_ll = (long long)J.p_begin + (long long)(tile < 0 ? 0 : tile) * (64LL * R * PG) + (long long)grp * (64LL * R);
     const bool active = tile >= 0 && wave_lo_ll < n_end;
-    if (LS == 1 && !active) return;                  // no barrier below when waves do not share points
+    if (LS == 1 && !active) return;                  // no workgroup barrier below when waves do not share points
     const int wlo = active ? (int)wave_lo_ll : 0;
     const int whi = active ? min(wlo + 64 * R - 1, n_end - 1) : 0;
     const int H = J.H;
@@ -493,6 +499,8 @@ __global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_ker
     const double Hf = (double)H;
     WaveAcc<R> S;
     S.init(J.flush_every);
+    double* lh = s_stage[wave];
+    double* lc = s_stage[wave] + 256;
 
     if (active) {
         int iA, iB, iC, iD;
@@ -506,13 +514,11 @@ __global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_ker
         typedef const v2f64 __attribute__((address_space(1)))* GlobalF64x2;
         const GlobalF64x2 gh = (GlobalF64x2)(unsigned long long)J.hot;
         const GlobalF64x2 gc = (GlobalF64x2)(unsigned long long)J.cold;
-        double* lh = s_hot[wave];
-        double* lc = s_cold[wave];
-        // software pipeline: registers hold the NEXT chunk while LDS holds the current one
-        v2f64 h0 = {0, 0}, h1 = {0, 0}, c0v = {0, 0}, c1v = {0, 0};
+        // software pipeline: registers hold the NEXT chunk's hot halves while LDS holds the current one
+        v2f64 h0 = {0, 0}, h1 = {0, 0};
         if (mA + lane < mD) {
             const long long r = (long long)(mA + lane) * 2;
-            h0 = gh[r]; h1 = gh[r + 1]; c0v = gc[r]; c1v = gc[r + 1];
+            h0 = gh[r]; h1 = gh[r + 1];
         }
         for (int c0 = mA; c0 < mD; c0 += 64) {
             const int c1 = min(c0 + 64, mD);
@@ -521,21 +527,27 @@ __global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_ker
             const int ci = (int)h0.x;
             const int dgi = __double2loint(h1.y), fl = __double2hiint(h1.y);
             const bool valid = c0 + lane < c1;
-            const unsigned long long gmask = __ballot(valid && max(0, max(ci - whi, wlo - ci)) < dgi);
-            const bool direct = (fl & REC_DIRECT_DIV) != 0;
-            const unsigned long long dmask = __ballot(valid && direct);
-            const unsigned long long emask = __ballot(c1v.x < 0.0);          // q2 < 0: no recurrence
+            const bool gauss = valid && max(0, max(ci - whi, wlo - ci)) < dgi;
+            const bool direct = valid && (fl & REC_DIRECT_DIV) != 0;
+            const unsigned long long gmask = __ballot(gauss);
+            const unsigned long long dmask = __ballot(direct);
+            const unsigned long long emask = __ballot((fl & REC_NO_RECUR) != 0);
             v2f64 w0 = h0, w1 = h1;
             if (direct) { w0.y = 1.0; w1.x = 0.0; }          // a2 = 1, KL = 0 in the hot loop's copy
             reinterpret_cast<v2f64*>(lh)[lane * 2] = w0;
             reinterpret_cast<v2f64*>(lh)[lane * 2 + 1] = w1;
-            reinterpret_cast<v2f64*>(lc)[lane * 2] = c0v;
-            reinterpret_cast<v2f64*>(lc)[lane * 2 + 1] = c1v;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // cold halves only for the records that will use them (about one in eight); they
+            // land while the Lorentz loop below runs
+            v2f64 c0v = {0, 0}, c1v = {0, 0};
+            if (gauss || direct) {
+                const long long r = (long long)(c0 + lane) * 2;
+                c0v = gc[r]; c1v = gc[r + 1];
+            }
             if (c1 + lane < mD) {
                 const long long r = (long long)(c1 + lane) * 2;
-                h0 = gh[r]; h1 = gh[r + 1]; c0v = gc[r]; c1v = gc[r + 1];
+                h0 = gh[r]; h1 = gh[r + 1];
             }
             // the three classes of lines inside this chunk, as offsets into the chunk
             const int a0 = 0, a1 = max(min(iB, c1), c0) - c0;
@@ -544,28 +556,36 @@ __global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_ker
             rf_segment<R, true>(lh, a0, a1, x0, Hf, S);
             rf_segment<R, false>(lh, a1, b1, x0, Hf, S);
             rf_segment<R, true>(lh, b1, e1, x0, Hf, S);
-            chunk_extras<R>(lh, lc, gmask, emask, dmask, x0, Hf, S);
+            if (gmask | dmask) {
+                if (gauss || direct) {
+                    reinterpret_cast<v2f64*>(lc)[lane * 2] = c0v;
+                    reinterpret_cast<v2f64*>(lc)[lane * 2 + 1] = c1v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                chunk_extras<R>(lh, lc, gmask, emask, dmask, x0, Hf, S);
+            }
         }
         S.flush();
     }
 
-    if (LS == 1) {
-        store_points<R>(J.out, p0, n_end, S.acc);
-    } else {
-        // fixed-order reduction over the LS waves that share these points
-        double* red = s_red + grp * (LS * 64 * R);
+    // Results leave through LDS so that every store instruction writes 512 contiguous bytes
+    // (a lane owns R CONSECUTIVE points; storing them directly would touch 64 cache lines per
+    // instruction).  With LS > 1 the LS partial sums of a span meet here in a fixed order.
+    double* mine = s_stage[wave];
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < R; ++k) red[(part * R + k) * 64 + lane] = S.acc[k];
-        __syncthreads();
-        if (part == 0 && active) {
-            double tot[R];
+    for (int k = 0; k < R; ++k) mine[span_slot(lane * R + k)] = S.acc[k];
+    if (LS > 1) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    if (part == 0 && active) {
+        double* __restrict__ out = J.out;
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                double t = red[k * 64 + lane];
-                for (int q = 1; q < LS; ++q) t += red[(q * R + k) * 64 + lane];
-                tot[k] = t;
-            }
-            store_points<R>(J.out, p0, n_end, tot);
+        for (int i = 0; i < R; ++i) {
+            const int o = i * 64 + lane;
+            double t = mine[span_slot(o)];
+            for (int q = 1; q < LS; ++q) t += s_stage[wave + q][span_slot(o)];
+            if (wlo + o < n_end) out[wlo + o] = t;
         }
     }
 }
