@@ -58,6 +58,10 @@ def main():
         f.write("kernel,calls,total_us,avg_us,min_us,max_us\n")
         for k, (c, tot, mn, mx) in sorted(kt.items(), key=lambda kv: -kv[1][1]):
             f.write("%s,%d,%.3f,%.3f,%.3f,%.3f\n" % (k, c, tot, tot / c, mn, mx))
+    raw = find(os.path.join(out, "trace_" + wl), "kernel_stats.csv")          # rocprofv3 --stats output, verbatim
+    if raw:
+        with open(raw) as f, open(os.path.join(here, "%s_%s_rocprofv3_stats.csv" % (tag, wl)), "w") as g:
+            g.write(f.read())
     fetch, nf = counters(os.path.join(out, "pmc_fetch_" + wl))
     write, nw = counters(os.path.join(out, "pmc_write_" + wl))
     valu, nv = counters(os.path.join(out, "pmc_valu_" + wl))

@@ -39,12 +39,14 @@ struct lbl_ctx {
     DeviceArena work;       // work grids that need a regrid
     DeviceArena jobs;       // PrepJob[] + AccumJob[] + regime counters (3 x u64 per job)
     DeviceArena colargs;    // ColumnArgs of the column sweep
+    DeviceArena counts;     // per-block regime counts of the last batch
     DeviceArena red;        // band-integral partials + result
     void* host_stage = nullptr;   // pinned staging ring for job descriptors
     size_t host_stage_cap = 0;
     size_t host_stage_head = 0;
     int last_jobs = 0;
-    unsigned long long* last_counts = nullptr;
+    int last_blocks_per_job = 0;
+    std::vector<int> last_job_lines;
     // tuning knobs (lbl_set_option)
     int accum_variant = 3;   // 0: IEEE divide + exp per pair; 1: running fraction; 2: + Gaussian recurrence
                              // (0-2 fetch records through the scalar cache); 3: 2 with wave-private LDS staging
@@ -210,7 +212,7 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& v : ctx->ev_rec) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->colargs, &ctx->red};
+    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->colargs, &ctx->counts, &ctx->red};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     (void)hipStreamDestroy(ctx->stream);
@@ -480,15 +482,15 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     if ((rc = arena_reserve(ctx, ctx->cold, std::max<size_t>(tot_lines, 1) * sizeof(ColdRec)))) return rc;
     if ((rc = arena_reserve(ctx, ctx->cidx, std::max<size_t>(tot_lines, 1) * sizeof(int32_t)))) return rc;
     if ((rc = arena_reserve(ctx, ctx->work, std::max<size_t>(tot_work, 1) * sizeof(double)))) return rc;
-    // descriptors and the regime counters share one device block so that a single H2D copy both
-    // refreshes the descriptors and zeroes the counters (one stream operation instead of two)
+    // per-block regime counts (3 x u32 per block of 256 lines), summed on the host on demand
+    const int blocks_per_job = (max_lines + 255) / 256;
     const size_t prep_bytes = (size_t)n_jobs * sizeof(PrepJob), acc_bytes = (size_t)n_jobs * sizeof(AccumJob);
-    const size_t cnt_bytes = (size_t)n_jobs * 3 * sizeof(unsigned long long);
-    if ((rc = arena_reserve(ctx, ctx->jobs, prep_bytes + acc_bytes + cnt_bytes))) return rc;
+    const size_t cnt_bytes = (size_t)n_jobs * std::max(blocks_per_job, 1) * 3 * sizeof(unsigned int);
+    if ((rc = arena_reserve(ctx, ctx->jobs, prep_bytes + acc_bytes))) return rc;
+    if ((rc = arena_reserve(ctx, ctx->counts, cnt_bytes))) return rc;
     void* stage = nullptr;
-    if ((rc = stage_alloc(ctx, prep_bytes + acc_bytes + cnt_bytes, &stage))) return rc;
-    memset((char*)stage + prep_bytes + acc_bytes, 0, cnt_bytes);
-    unsigned long long* d_counts = (unsigned long long*)((char*)ctx->jobs.ptr + prep_bytes + acc_bytes);
+    if ((rc = stage_alloc(ctx, prep_bytes + acc_bytes, &stage))) return rc;
+    unsigned int* d_counts = (unsigned int*)ctx->counts.ptr;
 
     int R, LS;
     choose_shape(ctx, total_points, min_H, &R, &LS);
@@ -505,7 +507,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         p.hot = (HotRec*)ctx->recs.ptr + line_off[j];
         p.cold = (ColdRec*)ctx->cold.ptr + line_off[j];
         p.cidx = (int32_t*)ctx->cidx.ptr + line_off[j];
-        p.regime_counts = d_counts + 3 * (size_t)j;
+        p.block_counts = d_counts + (size_t)j * blocks_per_job * 3;
         if (dbg) { p.dbg_index = dbg->index; p.dbg_lhw = dbg->lhw; p.dbg_ghw = dbg->ghw; p.dbg_intensity = dbg->inten; p.dbg_regime = dbg->regime; }
         p.T = iso[j].T; p.P = iso[j].P; p.q_frac = iso[j].q_frac; p.molmass = iso[j].molmass;
         p.Q_T = iso[j].Q_T; p.Q_296 = iso[j].Q_296;
@@ -530,8 +532,10 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     }
     PrepJob* dp = (PrepJob*)ctx->jobs.ptr;
     AccumJob* da = (AccumJob*)((char*)ctx->jobs.ptr + prep_bytes);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->jobs.ptr, stage, prep_bytes + acc_bytes + cnt_bytes, hipMemcpyHostToDevice, ctx->stream));
-    ctx->last_counts = d_counts;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->jobs.ptr, stage, prep_bytes + acc_bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->last_blocks_per_job = blocks_per_job;
+    ctx->last_job_lines.assign(n_jobs, 0);
+    for (int j = 0; j < n_jobs; ++j) ctx->last_job_lines[j] = (int)lines[j]->n;
     hipEvent_t ev = prof_begin(ctx);
     launch_line_prep(dp, n_jobs, max_lines, ctx->stream);
     prof_end(ctx, PROF_PREP, ev);
@@ -572,8 +576,19 @@ extern "C" int lbl_last_regime_counts(lbl_ctx* ctx, int n_jobs, int64_t* counts)
     if (!ctx || !counts) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     if (n_jobs < 0 || n_jobs > ctx->last_jobs) return fail(ctx, LBL_ERR_BAD_ARG, "n_jobs exceeds the last batch (%d)", ctx->last_jobs);
     if (n_jobs == 0) return LBL_OK;
-    HIP_TRY(ctx, hipMemcpyAsync(counts, ctx->last_counts, (size_t)n_jobs * 3 * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    const int bpj = ctx->last_blocks_per_job;
+    std::vector<unsigned int> host((size_t)n_jobs * std::max(bpj, 1) * 3, 0u);
+    if (bpj > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->counts.ptr, host.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < n_jobs; ++j) {
+        int64_t c[3] = {0, 0, 0};
+        const int nb = (ctx->last_job_lines[j] + 255) / 256;        // blocks past the job's lines never ran
+        for (int b = 0; b < nb; ++b)
+            for (int k = 0; k < 3; ++k) c[k] += host[((size_t)j * bpj + b) * 3 + k];
+        counts[3 * j] = c[0]; counts[3 * j + 1] = c[1]; counts[3 * j + 2] = c[2];
+    }
     return LBL_OK;
 }
 

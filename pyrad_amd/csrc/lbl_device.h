@@ -63,7 +63,7 @@ struct PrepJob {
     const double* nu; const double* sw; const double* elower; const double* gamma_air;
     const double* gamma_self; const double* n_air; const double* delta_air;
     HotRec* hot; ColdRec* cold; int32_t* cidx;
-    unsigned long long* regime_counts;    // [3]
+    unsigned int* block_counts;           // [blocks of 256 lines][3]: per-block regime counts, no atomics
     // optional debug outputs
     long long* dbg_index; double* dbg_lhw; double* dbg_ghw; double* dbg_intensity; int32_t* dbg_regime;
     double T, P, q_frac, molmass, Q_T, Q_296;

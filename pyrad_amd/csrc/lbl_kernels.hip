@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
         const double c2 = cLight * hPlanck * 100.0 / kB;                  // pyradIntensity.py:13
         const double E = J.elower[i];
         const double stim = (1.0 - exp(-c2 * broadened / T)) / (1.0 - exp(-c2 * broadened / t0));
-        const double boltz = exp(-c2 * E / T) / exp(-c2 * E / t0);
+        // exp(-c2 E/T) / exp(-c2 E/t0) as one exponential of the difference (exactly 1 at T = t0,
+        // like the quotient; elsewhere within |c2 E (1/T - 1/t0)| ulps of it, < 1e-14 relative)
+        const double boltz = exp(c2 * E / t0 - c2 * E / T);
         const double A = J.sw[i] * (J.Q_296 / J.Q_T) * stim * boltz;
         // centre index from the UNSHIFTED wavenumber, truncation toward zero (pyradClasses.py:390)
         const double fidx = (nu - J.range_min) / J.resolution;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
             const double g2 = g * g, l2 = l * l;
             const double f5 = g2 * g2 * g + 2.69269 * g2 * g2 * l + 2.42843 * g2 * g * l2 +
                               4.47163 * g2 * l2 * l + .07842 * g * l2 * l2 + l2 * l2 * l;
-            const double f = pow(f5, .2);
+            const double f = exp(.2 * log(f5));                                 // f5 ** .2
             const double x = l / f;
             const double eta = 1.36603 * x - .47719 * x * x + .11116 * x * x * x;
             hw = f / 2.0;
@@ -178,12 +180,18 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
         if (J.dbg_intensity) J.dbg_intensity[i] = A;
         if (J.dbg_regime) J.dbg_regime[i] = regime;
     }
-    // regime counters (pyradClasses.py:368-370, 406): one atomic per wave and regime
-    const int lane = threadIdx.x & 63;
+    // regime counters (pyradClasses.py:368-370, 406).  One plain store per block: thousands of
+    // atomics on one cache line cost ~12 ns each and made this kernel 3x longer than its arithmetic.
+    __shared__ unsigned int s_cnt[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k = 0; k < 3; ++k) {
         const unsigned long long m = __ballot(regime == k);
-        if (lane == 0 && m) atomicAdd(&J.regime_counts[k], (unsigned long long)__popcll(m));
+        if (lane == 0) s_cnt[wave][k] = (unsigned int)__popcll(m);
     }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        J.block_counts[blockIdx.x * 3 + threadIdx.x] =
+            s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
 }
 
 // ----------------------------------------------------------------------------------------
