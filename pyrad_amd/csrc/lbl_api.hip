@@ -432,22 +432,33 @@ extern "C" int lbl_lines_count(const lbl_lines* lines, int64_t* n) {
 // ----------------------------------------------------------------------------------------
 // the hot path
 // ----------------------------------------------------------------------------------------
-// Launch shape: R grid points per lane and, for the LDS variant, LS waves sharing one span of
-// 64*R points.  Wanted: about 4 wavefronts per SIMD (256 CUs x 4 SIMDs) and no more points
-// per wave than a line's support is wide.  Small grids keep R and split the lines instead.
-static void choose_shape(const lbl_ctx* ctx, long long total_points, long long min_H, int* R_out, int* LS_out) {
-    const long long simds = 4LL * (ctx->n_cu > 0 ? ctx->n_cu : 256);
+// Launch shape of the LDS variant, from measurements on MI355X (scripts/sweep*.sh):
+//   R  points per lane: 4 is the sweet spot (R = 8 needs 136 VGPRs: spills or a slower loop);
+//      drop to 2 when the grid has fewer than 8 spans per CU (finer tail), and never more
+//      points per wave than a line's support is wide.
+//   LS waves sharing one span and splitting its lines: 4 when a span sees >= 1024 lines,
+//      2 from 256 (the four waves of a workgroup then finish together and workgroups are
+//      short, which balances the clustered line density), else 1.
+// The scalar-cache variants (0-2) keep their original rule: about 3 waves per SIMD.
+static void choose_shape(const lbl_ctx* ctx, long long total_points, long long total_lines, long long min_H,
+                         int* R_out, int* LS_out) {
+    const long long cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
     const bool lds = ctx->accum_variant >= 3;
     int R = ctx->accum_R, LS = lds ? ctx->accum_LS : 1;
     if (!R) {
-        R = 8;
+        if (lds) {
+            R = 4;
+            while (R > 2 && total_points / (64LL * R) < 8 * cus) R >>= 1;
+        } else {
+            R = 8;
+            while (R > 1 && total_points / (64LL * R) < 12 * cus) R >>= 1;
+        }
         while (R > 1 && 64LL * R > 2 * min_H + 1) R >>= 1;
-        const int r_floor = lds ? (R < 4 ? R : 4) : 1;
-        while (R > r_floor && total_points / (64LL * R) * (lds ? 4 : 1) < 3 * simds) R >>= 1;
     }
     if (!LS) {
-        LS = 1;
-        while (LS < 4 && total_points / (64LL * R) * LS < 3 * simds) LS <<= 1;
+        const double lines_per_span = total_points > 0
+            ? (double)total_lines / (double)total_points * (double)(2 * min_H + 64LL * R) : 0.0;
+        LS = lines_per_span >= 1024.0 ? 4 : lines_per_span >= 256.0 ? 2 : 1;
     }
     *R_out = R; *LS_out = LS;
 }
@@ -493,7 +504,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     unsigned int* d_counts = (unsigned int*)ctx->counts.ptr;
 
     int R, LS;
-    choose_shape(ctx, total_points, min_H, &R, &LS);
+    choose_shape(ctx, total_points, (long long)tot_lines, min_H, &R, &LS);
     const long long tile_pts = accumulate_tile_points(R, LS, ctx->accum_variant);
     PrepJob* hp = (PrepJob*)stage;
     AccumJob* ha = (AccumJob*)((char*)stage + prep_bytes);
