@@ -118,6 +118,21 @@ def cpu_baseline(cfg, seconds_target=15.0):
     }
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on stdout when a communicator is created; rank 0 must print
+    exactly one JSON line there, so file descriptor 1 points at stderr while RCCL initialises."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +146,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather", default="abs_coef", choices=["abs_coef", "all"])
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-gather in stream instead of pipelined")
     ap.add_argument("--check", action="store_true", help="also compare one shard against the oracle (slow)")
     args = ap.parse_args()
 
@@ -158,32 +174,49 @@ def main():
 
     comm = None
     rdzv = None
-    if world > 1:
+    force_comm = os.environ.get("PYRAD_FORCE_COMM") == "1"      # exercise the RCCL path with one rank
+    if world > 1 or force_comm:
         rdzv = dist.FileRendezvous(rank, world)
-        uid = rdzv.broadcast("rccl_unique_id", nat.Comm.unique_id() if rank == 0 else None)
-        comm = nat.Comm(ctx, uid, world, rank)
+        with _StdoutToStderr():
+            uid = rdzv.broadcast("rccl_unique_id", nat.Comm.unique_id() if rank == 0 else None)
+            comm = nat.Comm(ctx, uid, world, rank)
 
     cfg, desc = build_workload(args.workload, world)
     t_setup = time.perf_counter()
-    layer = engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"],
-                                 molecules_of(cfg), cfg["base_resolution"], cfg.get("dynamic_resolution", True),
-                                 shard=(world, rank) if world > 1 else None)
+    # With a communicator the steps are software-pipelined over two buffer sets: the all-gather of
+    # step k (communicator stream) overlaps the kernels of step k+1 (context stream, other set).
+    n_sets = 2 if (comm is not None and not args.no_overlap) else 1
+    mols = molecules_of(cfg)
+    layers = [engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"],
+                                   mols, cfg["base_resolution"], cfg.get("dynamic_resolution", True),
+                                   shard=(world, rank) if world > 1 else None) for _ in range(n_sets)]
+    layer = layers[0]
     ctx.sync()
     t_setup = time.perf_counter() - t_setup
 
     # small device buffers for the RCCL barrier / max-over-ranks reduction
     red = ctx.buffer(max(world, 1))
-    gather_bufs = (layer.abs_coef,) if args.gather == "abs_coef" else (layer.abs_coef, layer.trans, layer.I_out)
+
+    def gather_bufs(L):
+        return (L.abs_coef,) if args.gather == "abs_coef" else (L.abs_coef, L.trans, L.I_out)
 
     def barrier():
         if comm is not None:
+            comm.fence_dev(-1)
             comm.allgather_dev(red, rank, 1, red)
         ctx.sync()
 
+    step_no = [0]
+
     def step():
-        layer.enqueue(surface_T=288.0)
+        k = step_no[0]
+        step_no[0] += 1
+        L = layers[k % n_sets]
+        if comm is not None and n_sets > 1:
+            comm.fence_dev(k % n_sets)          # the gather that last used this set (step k-2) is done
+        L.enqueue(surface_T=288.0)
         if comm is not None:
-            layer.enqueue_allgather(comm, gather_bufs)
+            L.enqueue_allgather(comm, gather_bufs(L), overlap_slot=(k % n_sets) if n_sets > 1 else None)
 
     for _ in range(args.warmup):
         step()
@@ -238,7 +271,9 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "grid_points_per_gpu": int(pts), "lines_per_gpu": int(layer.n_lines),
                        "window_W": int(g["W"]), "evals_per_step": evals_total, "parallelism": "grid-range x%d" % world,
-                       "gathered": args.gather, "device": info["name"]},
+                       "gathered": args.gather, "device": info["name"],
+                       "allgather": ("none" if comm is None else "in-stream" if n_sets == 1 else
+                                     "overlapped with the next step (2 buffer sets)")},
             "roofline": {"bound": "hbm", "kernel": "xsec_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc.get("xsec_accumulate_kernel"),
@@ -268,7 +303,8 @@ def main():
         rdzv.cleanup()
     if comm is not None:
         comm.free()
-    layer.free()
+    for L in layers:
+        L.free()
     red.free()
     ctx.close()
     if rank == 0:

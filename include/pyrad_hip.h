@@ -219,6 +219,14 @@ int lbl_comm_destroy(lbl_comm* comm);
  * Enqueued on the context stream (send may alias recv at its own slot: in-place). */
 int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count,
                       lbl_buffer* recv);
+/* Same collective, but the context stream does not wait for it: kernels enqueued afterwards
+ * (the next step, on OTHER buffers) overlap the transfer.  `slot` (0..3) names the completion
+ * event; lbl_comm_fence_dev(comm, slot) makes the context stream wait (no host sync) for the
+ * collective issued with that slot, slot -1 for all of them: call it before send/recv of that
+ * collective are touched again.  Collectives run, in issue order, on a stream the communicator owns. */
+int lbl_allgather_overlap_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count,
+                              lbl_buffer* recv, int slot);
+int lbl_comm_fence_dev(lbl_comm* comm, int slot);
 
 #ifdef __cplusplus
 }

@@ -92,6 +92,8 @@ SIGNATURES = {
     "lbl_comm_create": (C.c_int, [_P, C.c_char_p, C.c_int, C.c_int, C.POINTER(_P)]),
     "lbl_comm_destroy": (C.c_int, [_P]),
     "lbl_allgather_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
+    "lbl_allgather_overlap_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int]),
+    "lbl_comm_fence_dev": (C.c_int, [_P, C.c_int]),
 }
 
 _lib = None
@@ -404,8 +406,17 @@ class Comm:
             raise LblError(rc, (lib.lbl_last_error(None) or b"").decode())
         return buf.raw
 
-    def allgather_dev(self, send: Buffer, send_offset: int, count: int, recv: Buffer):
-        self.ctx.check(self.ctx.lib.lbl_allgather_dev(self.h, send.h, int(send_offset), int(count), recv.h))
+    def allgather_dev(self, send: Buffer, send_offset: int, count: int, recv: Buffer, overlap_slot=None):
+        """In-stream all-gather, or (overlap_slot 0..3) one the context stream does not wait for."""
+        if overlap_slot is None:
+            self.ctx.check(self.ctx.lib.lbl_allgather_dev(self.h, send.h, int(send_offset), int(count), recv.h))
+        else:
+            self.ctx.check(self.ctx.lib.lbl_allgather_overlap_dev(self.h, send.h, int(send_offset), int(count), recv.h,
+                                                                  int(overlap_slot)))
+
+    def fence_dev(self, slot: int = -1):
+        """Context stream waits (no host sync) for the collective issued with ``slot`` (-1: all)."""
+        self.ctx.check(self.ctx.lib.lbl_comm_fence_dev(self.h, int(slot)))
 
     def free(self):
         if self.h:

@@ -15,6 +15,7 @@
 extern "C" int lbl_ctx_stream(lbl_ctx* ctx, void** stream);
 extern "C" int lbl_buffer_devptr(lbl_buffer* buf, void** devptr);
 extern "C" int lbl_buffer_size(const lbl_buffer* buf, int64_t* n);
+extern "C" int lbl_comm_fence_dev(lbl_comm* comm, int slot);
 namespace lbl {
 int comm_fail(lbl_ctx* ctx, int code, const char* msg);
 int ctx_device(lbl_ctx* ctx);
@@ -22,10 +23,18 @@ void* comm_prof_begin(lbl_ctx* ctx);
 void comm_prof_end(lbl_ctx* ctx, void* start);
 }
 
+// Every collective of a communicator is issued on ONE stream of its own (cstream), in the same
+// order on every rank.  The context stream and cstream are ordered with events only, so the
+// all-gather of step k can run while the kernels of step k+1 compute (lbl_allgather_overlap_dev
+// + lbl_comm_fence_dev); lbl_allgather_dev is the same path with the fence applied at once.
 struct lbl_comm {
     lbl_ctx* ctx;
     ncclComm_t comm;
     int world, rank;
+    hipStream_t cstream;
+    hipEvent_t ready;      // context stream -> cstream: inputs of the collective are complete
+    hipEvent_t done[4];    // cstream -> context stream: the collective issued with this slot has finished
+    bool pending[4];       // a collective was issued with this slot since its last fence
 };
 
 static_assert(sizeof(ncclUniqueId) <= LBL_UNIQUE_ID_BYTES, "unique id does not fit");
@@ -51,8 +60,21 @@ extern "C" int lbl_comm_create(lbl_ctx* ctx, const char id[LBL_UNIQUE_ID_BYTES],
     ncclComm_t c;
     ncclResult_t r = ncclCommInitRank(&c, world_size, u, rank);
     if (r != ncclSuccess) return lbl::comm_fail(ctx, LBL_ERR_RCCL, ncclGetErrorString(r));
-    lbl_comm* cm = new (std::nothrow) lbl_comm{ctx, c, world_size, rank};
+    lbl_comm* cm = new (std::nothrow) lbl_comm();
     if (!cm) { ncclCommDestroy(c); return lbl::comm_fail(ctx, LBL_ERR_OOM, "host allocation failed"); }
+    cm->ctx = ctx; cm->comm = c; cm->world = world_size; cm->rank = rank;
+    cm->cstream = nullptr; cm->ready = nullptr;
+    bool ok = hipStreamCreateWithFlags(&cm->cstream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&cm->ready, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 4; ++i) {
+        cm->done[i] = nullptr; cm->pending[i] = false;
+        ok = ok && hipEventCreateWithFlags(&cm->done[i], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+        ncclCommDestroy(c);
+        delete cm;
+        return lbl::comm_fail(ctx, LBL_ERR_HIP, "communicator stream/event creation failed");
+    }
     *out = cm;
     return LBL_OK;
 }
@@ -62,14 +84,20 @@ extern "C" int lbl_comm_destroy(lbl_comm* comm) {
     void* s = nullptr;
     lbl_ctx_stream(comm->ctx, &s);
     (void)hipStreamSynchronize((hipStream_t)s);
+    (void)hipStreamSynchronize(comm->cstream);
     ncclCommDestroy(comm->comm);
+    (void)hipEventDestroy(comm->ready);
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(comm->done[i]);
+    (void)hipStreamDestroy(comm->cstream);
     delete comm;
     return LBL_OK;
 }
 
-extern "C" int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count, lbl_buffer* recv) {
+static int allgather_impl(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count, lbl_buffer* recv,
+                          int slot, bool fence_now) {
     if (!comm || !send || !recv) return lbl::comm_fail(comm ? comm->ctx : nullptr, LBL_ERR_BAD_ARG, "NULL argument");
     lbl_ctx* ctx = comm->ctx;
+    if (slot < 0 || slot > 3) return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "slot must be 0..3");
     int64_t ns = 0, nr = 0;
     lbl_buffer_size(send, &ns);
     lbl_buffer_size(recv, &nr);
@@ -80,9 +108,42 @@ extern "C" int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_
     lbl_buffer_devptr(send, &ps);
     lbl_buffer_devptr(recv, &pr);
     lbl_ctx_stream(ctx, &s);
-    void* ev = lbl::comm_prof_begin(ctx);
-    ncclResult_t r = ncclAllGather((const double*)ps + send_offset, pr, (size_t)count, ncclDouble, comm->comm, (hipStream_t)s);
-    lbl::comm_prof_end(ctx, ev);
+    hipStream_t main_stream = (hipStream_t)s;
+    if (hipSetDevice(lbl::ctx_device(ctx)) != hipSuccess) return lbl::comm_fail(ctx, LBL_ERR_HIP, "hipSetDevice failed");
+    // the collective starts when everything enqueued so far on the context stream is complete
+    if (hipEventRecord(comm->ready, main_stream) != hipSuccess ||
+        hipStreamWaitEvent(comm->cstream, comm->ready, 0) != hipSuccess)
+        return lbl::comm_fail(ctx, LBL_ERR_HIP, "stream ordering (ready) failed");
+    ncclResult_t r = ncclAllGather((const double*)ps + send_offset, pr, (size_t)count, ncclDouble, comm->comm, comm->cstream);
     if (r != ncclSuccess) return lbl::comm_fail(ctx, LBL_ERR_RCCL, ncclGetErrorString(r));
+    if (hipEventRecord(comm->done[slot], comm->cstream) != hipSuccess) return lbl::comm_fail(ctx, LBL_ERR_HIP, "hipEventRecord(done) failed");
+    comm->pending[slot] = true;
+    if (fence_now) return lbl_comm_fence_dev(comm, slot);
     return LBL_OK;
+}
+
+extern "C" int lbl_comm_fence_dev(lbl_comm* comm, int slot) {
+    if (!comm) return lbl::comm_fail(nullptr, LBL_ERR_BAD_ARG, "comm is NULL");
+    if (slot < -1 || slot > 3) return lbl::comm_fail(comm->ctx, LBL_ERR_BAD_ARG, "slot must be -1 (all) or 0..3");
+    void* s = nullptr;
+    lbl_ctx_stream(comm->ctx, &s);
+    for (int i = 0; i < 4; ++i) {
+        if ((slot >= 0 && i != slot) || !comm->pending[i]) continue;
+        if (hipStreamWaitEvent((hipStream_t)s, comm->done[i], 0) != hipSuccess)
+            return lbl::comm_fail(comm->ctx, LBL_ERR_HIP, "stream ordering (done) failed");
+        comm->pending[i] = false;
+    }
+    return LBL_OK;
+}
+
+extern "C" int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count, lbl_buffer* recv) {
+    void* ev = comm ? lbl::comm_prof_begin(comm->ctx) : nullptr;
+    int rc = allgather_impl(comm, send, send_offset, count, recv, 3, true);
+    if (comm) lbl::comm_prof_end(comm->ctx, ev);
+    return rc;
+}
+
+extern "C" int lbl_allgather_overlap_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count,
+                                         lbl_buffer* recv, int slot) {
+    return allgather_impl(comm, send, send_offset, count, recv, slot, false);
 }

@@ -309,16 +309,34 @@ __device__ __forceinline__ void process_lines_scalar(const HotRec* hot, const Co
 //   [iA, iB)  left-edge lines,   c in [wlo-H, whi-H)      -> masked
 //   [iB, iC)  interior lines,    c in [whi-H, wlo+H]      -> every point inside the support
 //   [iC, iD)  right-edge lines,  c in (wlo+H, whi+H]      -> masked
+// Four lower bounds at once: lane group q = lane/16 searches target q with a 16-ary search
+// (16 probes per step, range / 17 per step): 4-5 dependent loads for 10^5..10^6 lines instead
+// of the 17-19 of a binary search, which cost a third of a short wave's lifetime.
 __device__ __forceinline__ void wave_line_ranges(const int32_t* __restrict__ cidx, int n_lines, int wlo, int whi, int H,
                                                  int lane, int& iA, int& iB, int& iC, int& iD) {
     const long long tA = (long long)wlo - H, tB = (long long)whi - H;
     const long long tC = (long long)wlo + H + 1, tD = (long long)whi + H + 1;
-    const long long tgt = lane == 0 ? tA : lane == 1 ? tB : lane == 2 ? tC : tD;
-    const int pos = lower_bound_i32(cidx, n_lines, tgt);
-    iA = __builtin_amdgcn_readlane(pos, 0);
-    iB = __builtin_amdgcn_readlane(pos, 1);
-    iC = __builtin_amdgcn_readlane(pos, 2);
-    iD = __builtin_amdgcn_readlane(pos, 3);
+    const int q = lane >> 4, jj = lane & 15;
+    const long long tgt = q == 0 ? tA : q == 1 ? tB : q == 2 ? tC : tD;
+    const unsigned long long gmask = 0xFFFFull << (q * 16);
+    int lo = 0, hi = n_lines;                       // answer a = first i with cidx[i] >= tgt, a in [lo, hi]
+    while (__any(hi > lo)) {
+        const long long len = (long long)hi - lo;
+        const int pos = lo + (int)(((long long)(jj + 1) * len) / 17);       // < hi whenever len > 0
+        const bool below = (len > 0) && ((long long)cidx[len > 0 ? pos : 0] < tgt);
+        const int k = __popcll(__ballot(below) & gmask);                     // probes are sorted: the first k are below
+        if (len > 0) {
+            const int p_k = lo + (int)(((long long)(k + 1) * len) / 17);
+            const int p_km1 = lo + (int)(((long long)k * len) / 17);
+            const int new_lo = k > 0 ? p_km1 + 1 : lo;
+            const int new_hi = k < 16 ? p_k : hi;
+            lo = new_lo; hi = new_hi;
+        }
+    }
+    iA = __builtin_amdgcn_readlane(lo, 0);
+    iB = __builtin_amdgcn_readlane(lo, 16);
+    iC = __builtin_amdgcn_readlane(lo, 32);
+    iD = __builtin_amdgcn_readlane(lo, 48);
     if (tB >= tC) { iB = iD; iC = iD; }      // span wider than the support: no interior line
 }
 

@@ -182,10 +182,12 @@ class ResidentLayer:
         self.enqueue_xsec()
         self.enqueue_sweep(I_in=I_in, surface_T=surface_T)
 
-    def enqueue_allgather(self, comm: nat.Comm, buffers=None):
-        """The single RCCL all-gather of the path, in place on the padded buffers."""
+    def enqueue_allgather(self, comm: nat.Comm, buffers=None, overlap_slot=None):
+        """The single RCCL all-gather of the path, in place on the padded buffers.  With
+        ``overlap_slot`` the context stream does not wait for it: call
+        ``comm.fence_dev(overlap_slot)`` before this layer's buffers are touched again."""
         for b in (buffers if buffers is not None else (self.abs_coef,)):
-            comm.allgather_dev(b, self.rank * self.S, self.S, b)
+            comm.allgather_dev(b, self.rank * self.S, self.S, b, overlap_slot=overlap_slot)
 
     # -- results ------------------------------------------------------------------------
     def xsec_host(self, i=0):

@@ -310,3 +310,24 @@ def test_error_paths(ctx):
         ctx.xsec_accumulate(lines, iso, gz)          # W = 0: the reference raises IndexError (cls:393)
     xs, counts = ctx.xsec_accumulate({k: v[:0] for k, v in lines.items()}, iso, engine.native_grid(g))
     assert xs.shape == (g["n_base"],) and not xs.any() and counts == (0, 0, 0)   # empty line list
+
+
+def test_rccl_comm_single_rank_inplace_allgather_and_overlap(ctx):
+    """The RCCL path with a one-rank communicator (all a 1-GPU box can run): in-place all-gather in
+    stream, then the overlapped form on the communicator's own stream with slot fences."""
+    from pyrad_amd import _native as nat
+    comm = nat.Comm(ctx, nat.Comm.unique_id(), 1, 0)
+    a = ctx.buffer(1000, np.arange(1000.0))
+    comm.allgather_dev(a, 0, 1000, a)
+    assert np.array_equal(a.download(), np.arange(1000.0))
+    b = ctx.buffer(2000).fill(0.0)
+    comm.allgather_dev(a, 100, 500, b, overlap_slot=1)       # not in place: b[:500] = a[100:600]
+    comm.fence_dev(1)
+    assert np.array_equal(b.download(500), np.arange(100.0, 600.0))
+    comm.allgather_dev(a, 0, 10, b, overlap_slot=0)
+    comm.allgather_dev(a, 10, 10, b, overlap_slot=1)
+    comm.fence_dev(-1)
+    assert np.array_equal(b.download(10), np.arange(10.0, 20.0))
+    with pytest.raises(nat.LblError):
+        comm.allgather_dev(a, 990, 20, b)                    # send range out of bounds
+    comm.free(); a.free(); b.free()
