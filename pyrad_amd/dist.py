@@ -65,13 +65,22 @@ class FileRendezvous:
             time.sleep(0.005)
 
     def cleanup(self):
-        if self.rank == 0:
-            try:
-                for f in os.listdir(self.dir):
-                    os.remove(os.path.join(self.dir, f))
-                os.rmdir(self.dir)
-            except OSError:
-                pass
+        """Every rank acknowledges that it is past its last wait; rank 0 removes the directory
+        only after all acknowledgements (otherwise it could delete files a slower rank still polls)."""
+        open(os.path.join(self.dir, "ack.%d" % self.rank), "wb").close()
+        if self.rank != 0:
+            return
+        t0 = time.time()
+        while not all(os.path.isfile(os.path.join(self.dir, "ack.%d" % r)) for r in range(self.world)):
+            if time.time() - t0 > self.timeout:
+                return                      # leave the files rather than hang
+            time.sleep(0.005)
+        try:
+            for f in os.listdir(self.dir):
+                os.remove(os.path.join(self.dir, f))
+            os.rmdir(self.dir)
+        except OSError:
+            pass
 
 
 # ----------------------------------------------------------------------------------------

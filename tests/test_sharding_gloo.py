@@ -90,6 +90,7 @@ def test_file_rendezvous_two_ranks(tmp_path):
         r = pdist.FileRendezvous(1, 2, key="t", root=str(tmp_path), timeout=30)
         q.put(r.broadcast("uid", None))
         r.arrive("done")
+        r.cleanup()
 
     q = mp.get_context("fork").Queue()
     p = mp.get_context("fork").Process(target=rank1, args=(q,))
