@@ -49,6 +49,10 @@ def build_workload(workload: str, world: int):
         rmin, rmax = 100, 100 + 2400 * world
         cfg = synthetic.config_c3(n_lines=131072 * world, range_min=rmin, range_max=rmax)
         desc = "CO2+H2O+CH4 %d-%d cm^-1 @0.001, 3x%d lines, 1013.25 mbar, 296 K (C3 shape)" % (rmin, rmax, 131072 * world)
+    elif workload == "C5":
+        cfg = synthetic.config_c5(n_layers=30, n_lines=131072, range_min=100, range_max=100 + 2400 * world)
+        desc = ("30-layer column H2O+CO2+O3 100-%d cm^-1 @0.001, 3x131072 lines per layer window, "
+                "P 1013->10 mbar (C5 shape)" % (100 + 2400 * world))
     elif workload == "C1":
         cfg = synthetic.config_c1()
         desc = "CO2 600-700 cm^-1 @0.01, 4096 lines (C1, the reference's own CPU-runnable case)"
@@ -58,7 +62,7 @@ def build_workload(workload: str, world: int):
 
 
 def molecules_of(cfg):
-    """config dict -> ResidentLayer molecule descriptions (host logic only)."""
+    """layer config dict -> ResidentLayer molecule descriptions (host logic only)."""
     from pyrad_amd import synthetic
     from pyrad_amd.model import concentration_from_kwargs
     mols = []
@@ -138,7 +142,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3"])
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--variant", type=int, default=None, help="accumulate kernel variant 0|1|2|3 (default: library default 3)")
     ap.add_argument("--points-per-lane", type=int, default=None)
     ap.add_argument("--line-split", type=int, default=None)
@@ -186,10 +190,15 @@ def main():
     # With a communicator the steps are software-pipelined over two buffer sets: the all-gather of
     # step k (communicator stream) overlaps the kernels of step k+1 (context stream, other set).
     n_sets = 2 if (comm is not None and not args.no_overlap) else 1
-    mols = molecules_of(cfg)
-    layers = [engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"],
-                                   mols, cfg["base_resolution"], cfg.get("dynamic_resolution", True),
-                                   shard=(world, rank) if world > 1 else None) for _ in range(n_sets)]
+    shard = (world, rank) if world > 1 else None
+    if args.workload == "C5":
+        layer_cfgs = [dict(c, molecules=molecules_of(c)) for c in cfg["layers"]]
+        layers = [engine.ResidentColumn(ctx, layer_cfgs, cfg["surface_T"], shard=shard) for _ in range(n_sets)]
+    else:
+        mols = molecules_of(cfg)
+        layers = [engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"],
+                                       mols, cfg["base_resolution"], cfg.get("dynamic_resolution", True),
+                                       shard=shard) for _ in range(n_sets)]
     layer = layers[0]
     ctx.sync()
     t_setup = time.perf_counter() - t_setup
@@ -199,6 +208,8 @@ def main():
 
     def gather_bufs(L):
         return (L.abs_coef,) if args.gather == "abs_coef" else (L.abs_coef, L.trans, L.I_out)
+
+    is_column = args.workload == "C5"
 
     def barrier():
         if comm is not None:
@@ -214,9 +225,15 @@ def main():
         L = layers[k % n_sets]
         if comm is not None and n_sets > 1:
             comm.fence_dev(k % n_sets)          # the gather that last used this set (step k-2) is done
-        L.enqueue(surface_T=288.0)
-        if comm is not None:
-            L.enqueue_allgather(comm, gather_bufs(L), overlap_slot=(k % n_sets) if n_sets > 1 else None)
+        slot = (k % n_sets) if n_sets > 1 else None
+        if is_column:
+            L.enqueue()
+            if comm is not None:
+                L.enqueue_allgather(comm, overlap_slot=slot)
+        else:
+            L.enqueue(surface_T=288.0)
+            if comm is not None:
+                L.enqueue_allgather(comm, gather_bufs(L), overlap_slot=slot)
 
     for _ in range(args.warmup):
         step()
@@ -253,15 +270,19 @@ def main():
         n_sw, ms_sw = prof["layer_sweep"]
         n_prep, ms_prep = prof["line_prep"]
         n_ag, ms_ag = prof["allgather"]
-        g = layer.g
+        g = layer.layers[0].g if is_column else layer.g
         pts = layer.count if world > 1 else g["n_work"]
         # algorithmic bytes per launch of the dominant kernel: every line's 7 fp64
         # HITRAN fields once + every grid point written once
         balg_acc = 56.0 * layer.n_lines + 8.0 * pts
         t_acc = (ms_acc / max(n_acc, 1)) * 1e-3
+        t_acc_step = (ms_acc / max(args.steps, 1)) * 1e-3       # all K2 launches of one step
         achieved = balg_acc / t_acc / 1e9 if t_acc > 0 else 0.0
-        n_mol_arrays = len(layer.jobs)
-        balg_sw = 8.0 * pts * (n_mol_arrays + 3)           # M xsec reads + k, T, I_out writes (I_in computed in-kernel)
+        n_mol_arrays = len(layer.layers[0].jobs) if is_column else len(layer.jobs)
+        # per sweep launch: M xsec reads + k, T (, I_out) writes; I_in is computed in-kernel
+        balg_sw = 8.0 * pts * (n_mol_arrays + (2 if is_column else 3))
+        if is_column:
+            balg_acc = balg_acc / max(n_acc // max(args.steps, 1), 1)     # K2 is launched once per window group
         t_sw = (ms_sw / max(n_sw, 1)) * 1e-3
         pmc = load_pmc_traffic()
         result = {
@@ -281,10 +302,12 @@ def main():
                          "note": "compulsory traffic only (56 B/line + 8 B/grid point): this kernel is fp64-VALU "
                                  "bound by construction (SURVEY.md §8d), see valu_f64"},
             "valu_f64": {"instr_per_eval": FP64_INSTR_PER_EVAL,
-                         "achieved_lane_instr_per_s": FP64_INSTR_PER_EVAL * evals_local / t_acc if t_acc > 0 else 0.0,
+                         "achieved_lane_instr_per_s": FP64_INSTR_PER_EVAL * evals_local / t_acc_step if t_acc_step > 0 else 0.0,
                          "peak_lane_instr_per_s": FP64_VALU_PEAK_INSTR,
-                         "frac": (FP64_INSTR_PER_EVAL * evals_local / t_acc / FP64_VALU_PEAK_INSTR) if t_acc > 0 else 0.0,
-                         "kernel_evals_per_s": evals_local / t_acc if t_acc > 0 else 0.0},
+                         "frac": (FP64_INSTR_PER_EVAL * evals_local / t_acc_step / FP64_VALU_PEAK_INSTR) if t_acc_step > 0 else 0.0,
+                         "kernel_evals_per_s": evals_local / t_acc_step if t_acc_step > 0 else 0.0,
+                         "note": "5 fp64 instr per eval is the running-fraction Lorentz loop's minimum; measured "
+                                 "ceiling of that loop alone on this chip: 4.9e12 evals/s (scripts/ubench_fp64.hip)"},
             "roofline_sweep": {"bound": "hbm", "kernel": "layer_sweep_kernel",
                                "achieved": balg_sw / t_sw / 1e9 if t_sw > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": (balg_sw / t_sw / 1e9 / HBM_PEAK_GBS) if t_sw > 0 else 0.0,
@@ -295,7 +318,7 @@ def main():
             "setup_s": t_setup,
         }
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(cfg["layers"][0] if is_column else cfg, args.cpu_seconds)
         if args.check:
             result["check"] = oracle_check(layer, cfg)
     if rdzv is not None:

@@ -503,12 +503,37 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     if ((rc = stage_alloc(ctx, prep_bytes + acc_bytes, &stage))) return rc;
     unsigned int* d_counts = (unsigned int*)ctx->counts.ptr;
 
-    int R, LS;
-    choose_shape(ctx, total_points, (long long)tot_lines, min_H, &R, &LS);
-    const long long tile_pts = accumulate_tile_points(R, LS, ctx->accum_variant);
+    // Jobs of one batch can have very different windows (a column: W = 5000 at the surface,
+    // 50 at 10 mbar).  A wave must not own more points than a line's support is wide, so jobs are
+    // grouped by the largest R their window allows and every group gets its own launch shape.
+    auto r_cap = [&](int j) {
+        const long long H = std::max<long long>(grid[j].window - 2, 0);
+        int r = 8;
+        while (r > 1 && 64LL * r > 2 * H + 1) r >>= 1;
+        return ctx->accum_R ? 8 : r;              // a forced R keeps one group
+    };
+    std::vector<int> order(n_jobs);
+    for (int j = 0; j < n_jobs; ++j) order[j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return r_cap(a) > r_cap(b); });
+    struct Group { int first, count, R, LS, max_tiles; };
+    std::vector<Group> groups;
+    for (int k = 0; k < n_jobs;) {
+        int e = k;
+        long long pts = 0, lns = 0, mh = 1LL << 40;
+        while (e < n_jobs && r_cap(order[e]) == r_cap(order[k])) {
+            long long f, c;
+            shard_range(grid[order[e]], &f, &c);
+            pts += c; lns += lines[order[e]]->n;
+            mh = std::min<long long>(mh, std::max<long long>(grid[order[e]].window - 2, 0));
+            ++e;
+        }
+        Group g{k, e - k, 0, 0, 0};
+        choose_shape(ctx, pts, lns, mh, &g.R, &g.LS);
+        groups.push_back(g);
+        k = e;
+    }
     PrepJob* hp = (PrepJob*)stage;
     AccumJob* ha = (AccumJob*)((char*)stage + prep_bytes);
-    int max_tiles = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const lbl_lines* L = lines[j];
         PrepJob& p = hp[j];
@@ -525,21 +550,28 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         p.range_min = grid[j].range_min; p.resolution = grid[j].resolution;
         p.log_t0_over_T = std::log(296.0 / iso[j].T);
         p.n_lines = (int32_t)L->n;
-        AccumJob& a = ha[j];
-        memset(&a, 0, sizeof a);
-        a.hot = p.hot; a.cold = p.cold; a.cidx = p.cidx;
-        a.out = needs_regrid(grid[j]) ? (double*)ctx->work.ptr + work_off[j] : out_dev[j];
-        a.n_lines = (int32_t)L->n;
-        a.n_work = (int32_t)grid[j].n_work;
-        a.H = (int32_t)std::max<long long>(grid[j].window - 2, 0);
-        long long sf, sc;
-        shard_range(grid[j], &sf, &sc);
-        a.p_begin = (int32_t)sf;
-        a.p_end = (int32_t)(sf + sc);
-        a.n_tiles = (int32_t)((sc + tile_pts - 1) / tile_pts);
-        a.flush_every = (a.H + 64 * R + 1 <= 40000) ? 32 : 16;
-        a.pad = ctx->tile_order;
-        max_tiles = std::max(max_tiles, a.n_tiles);
+    }
+    for (Group& g : groups) {
+        const long long tile_pts = accumulate_tile_points(g.R, g.LS, ctx->accum_variant);
+        for (int k = g.first; k < g.first + g.count; ++k) {
+            const int j = order[k];
+            const PrepJob& p = hp[j];
+            AccumJob& a = ha[k];
+            memset(&a, 0, sizeof a);
+            a.hot = p.hot; a.cold = p.cold; a.cidx = p.cidx;
+            a.out = needs_regrid(grid[j]) ? (double*)ctx->work.ptr + work_off[j] : out_dev[j];
+            a.n_lines = p.n_lines;
+            a.n_work = (int32_t)grid[j].n_work;
+            a.H = (int32_t)std::max<long long>(grid[j].window - 2, 0);
+            long long sf, sc;
+            shard_range(grid[j], &sf, &sc);
+            a.p_begin = (int32_t)sf;
+            a.p_end = (int32_t)(sf + sc);
+            a.n_tiles = (int32_t)((sc + tile_pts - 1) / tile_pts);
+            a.flush_every = (a.H + 64 * g.R + 1 <= 40000) ? 32 : 16;
+            a.pad = ctx->tile_order;
+            g.max_tiles = std::max(g.max_tiles, a.n_tiles);
+        }
     }
     PrepJob* dp = (PrepJob*)ctx->jobs.ptr;
     AccumJob* da = (AccumJob*)((char*)ctx->jobs.ptr + prep_bytes);
@@ -553,10 +585,12 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     HIP_TRY(ctx, hipGetLastError());
     ctx->last_jobs = n_jobs;
     if (prep_only) return LBL_OK;
-    ev = prof_begin(ctx);
-    launch_accumulate(da, n_jobs, max_tiles, R, LS, ctx->accum_variant, ctx->stream);
-    prof_end(ctx, PROF_ACCUM, ev);
-    HIP_TRY(ctx, hipGetLastError());
+    for (const Group& g : groups) {
+        ev = prof_begin(ctx);
+        launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, ctx->accum_variant, ctx->stream);
+        prof_end(ctx, PROF_ACCUM, ev);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     for (int j = 0; j < n_jobs; ++j) {
         if (!needs_regrid(grid[j])) continue;
         ev = prof_begin(ctx);

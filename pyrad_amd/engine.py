@@ -203,3 +203,54 @@ class ResidentLayer:
         for b in (self.abs_coef, self.trans, self.I_out):
             b.free()
         self.jobs = []
+
+
+class ResidentColumn:
+    """A column of layers (bottom to top) resident in HBM: all layers' isotopologue jobs go
+    through ONE batched K1/K2 launch sequence, every layer gets its fused sweep, and the
+    column-sweep kernel folds Layer.transmission (cls:784-787) over the layers:
+    I <- T_i I + (1 - T_i) B(nu, T_i), I_0 = B(nu, surface_T).  All layers share one wavenumber
+    range and base grid.  With ``shard=(world, rank)`` every rank keeps ALL layers for its own
+    contiguous grid range (the fold is independent per grid point), so one all-gather of the
+    outgoing spectrum suffices."""
+
+    def __init__(self, ctx: nat.Context, layer_cfgs, surface_T, shard=None):
+        self.ctx = ctx
+        self.surface_T = float(surface_T)
+        self.layers = [ResidentLayer(ctx, c["depth"], c["T"], c["P"], c["range_min"], c["range_max"], c["molecules"],
+                                     c.get("base_resolution"), c.get("dynamic_resolution", True), shard=shard)
+                       for c in layer_cfgs]
+        first = self.layers[0]
+        for L in self.layers[1:]:
+            if (L.range_min, L.range_max, L.n) != (first.range_min, first.range_max, first.n):
+                raise ValueError("all layers of a column must share one wavenumber range and base grid")
+        self.n = first.n
+        self.world, self.rank, self.S = first.world, first.rank, first.S
+        self.first, self.count = first.first, first.count
+        self.I_toa = ctx.buffer(max(first.padded_n, 1)).fill(0.0)
+        self.jobs = [j for L in self.layers for j in L.jobs]
+        self.evals = sum(L.evals for L in self.layers)
+        self.n_lines = sum(L.n_lines for L in self.layers)
+
+    def enqueue(self):
+        self.ctx.xsec_accumulate_dev(self.jobs)
+        for L in self.layers:
+            L.enqueue_sweep(want_I=False)
+        first, count = (0, 0) if self.world == 1 else (self.first, self.count)
+        if self.world > 1 and self.count == 0:
+            return
+        self.ctx.column_sweep_dev([L.trans for L in self.layers], [L.T for L in self.layers],
+                                  self.layers[0].range_min, self.layers[0].range_max, self.n, self.I_toa,
+                                  surface_T=self.surface_T, first=first, count=count)
+
+    def enqueue_allgather(self, comm: nat.Comm, overlap_slot=None):
+        comm.allgather_dev(self.I_toa, self.rank * self.S, self.S, self.I_toa, overlap_slot=overlap_slot)
+
+    def results(self):
+        return dict(toa=self.I_toa.download(self.n),
+                    transmittance=[L.trans.download(self.n) for L in self.layers])
+
+    def free(self):
+        for L in self.layers:
+            L.free()
+        self.I_toa.free()

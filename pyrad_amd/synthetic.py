@@ -161,6 +161,7 @@ def config_c5(n_layers: int = 30, n_lines: int = 131072, range_min=100, range_ma
     lo, hi = layer_window(1013.25, range_min, range_max)
     line_sets = {s: make_lines(seed, n_lines, lo, hi) for s, seed in zip(("h2o", "co2", "o3"), seeds)}
     P = np.exp(np.linspace(np.log(1013.25), np.log(10.0), n_layers))
+    P[0], P[-1] = 1013.25, 10.0                       # exact end points (exp(log(x)) is off by an ulp)
     frac = (np.log(1013.25) - np.log(P)) / (np.log(1013.25) - np.log(10.0))
     T = np.rint(288.0 - frac * (288.0 - 217.0)).astype(int)
     # hydrostatic thickness of a layer centred on P_i with scale height R T / (M g)
