@@ -143,10 +143,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
-    ap.add_argument("--variant", type=int, default=None, help="accumulate kernel variant 0|1|2|3 (default: library default 3)")
+    ap.add_argument("--variant", type=int, default=None, help="accumulate kernel variant 0..4 (default: library default 3)")
     ap.add_argument("--points-per-lane", type=int, default=None)
     ap.add_argument("--line-split", type=int, default=None)
     ap.add_argument("--tile-order", type=int, default=None)
+    ap.add_argument("--blocks-per-cu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather", default="abs_coef", choices=["abs_coef", "all"])
@@ -175,6 +176,8 @@ def main():
         ctx.set_option("accum_line_split", args.line_split)
     if args.tile_order is not None:
         ctx.set_option("accum_tile_order", args.tile_order)
+    if args.blocks_per_cu is not None:
+        ctx.set_option("accum_blocks_per_cu", args.blocks_per_cu)
 
     comm = None
     rdzv = None

@@ -98,7 +98,8 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
 /* Tuning knobs for A/B parity and benchmarking (no reference counterpart):
  *   "accum_variant"          0 IEEE divide + exp per pair | 1 running fraction | 2 + Gaussian recurrence
  *                            (0-2 fetch line records through the scalar cache) |
- *                            3 (default) = 2 with wave-private LDS staging of the records
+ *                            3 (default) = 2 with wave-private LDS staging of the records |
+ *                            4 = 3 with a balanced single-round partition of (span, line) pairs
  *   "accum_points_per_lane"  0 (auto) | 1 | 2 | 4 | 8
  *   "accum_line_split"       0 (auto) | 1 | 2 | 4 waves of a workgroup share one span of points
  *                            and split its lines (variant 3 only) */

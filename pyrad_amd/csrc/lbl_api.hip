@@ -40,6 +40,7 @@ struct lbl_ctx {
     DeviceArena jobs;       // PrepJob[] + AccumJob[] + regime counters (3 x u64 per job)
     DeviceArena colargs;    // ColumnArgs of the column sweep
     DeviceArena counts;     // per-block regime counts of the last batch
+    DeviceArena bal;        // balanced variant: span table, counts, prefix, slab
     DeviceArena red;        // band-integral partials + result
     void* host_stage = nullptr;   // pinned staging ring for job descriptors
     size_t host_stage_cap = 0;
@@ -49,9 +50,13 @@ struct lbl_ctx {
     std::vector<int> last_job_lines;
     // tuning knobs (lbl_set_option)
     int accum_variant = 3;   // 0: IEEE divide + exp per pair; 1: running fraction; 2: + Gaussian recurrence
-                             // (0-2 fetch records through the scalar cache); 3: 2 with wave-private LDS staging
+                             // (0-2 fetch records through the scalar cache); 3 (default): 2 with wave-private
+                             // LDS staging; 4: 3 with the balanced single-round partition of (span, line)
+                             // pairs (measured: same main-kernel time as 3 plus ~20 us of helper kernels:
+                             // the kernel is throughput-bound per CU, not imbalance-bound)
     int accum_R = 0;         // points per lane, 0 = choose per launch
     int accum_LS = 0;        // waves sharing one span of points (line split), 0 = choose per launch
+    int bal_workers[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident wavefronts of the balanced kernel per R (cached)
     int tile_order = 1;      // 1: natural order (default; measured 8 % faster on the clustered C2 grid:
                              // all CUs work through one region together); 0: each XCD gets a contiguous run
     int live_objects = 0;
@@ -212,7 +217,7 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& v : ctx->ev_rec) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->colargs, &ctx->counts, &ctx->red};
+    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->colargs, &ctx->counts, &ctx->bal, &ctx->red};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     (void)hipStreamDestroy(ctx->stream);
@@ -286,12 +291,15 @@ void comm_prof_end(lbl_ctx* ctx, void* start) { prof_end(ctx, PROF_GATHER, (hipE
 extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     if (!strcmp(key, "accum_variant")) {
-        if (value < 0 || value > 3) return fail(ctx, LBL_ERR_BAD_ARG, "accum_variant must be 0..3");
+        if (value < 0 || value > 4) return fail(ctx, LBL_ERR_BAD_ARG, "accum_variant must be 0..4");
         ctx->accum_variant = value;
     } else if (!strcmp(key, "accum_points_per_lane")) {
         if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_points_per_lane must be 0, 1, 2, 4 or 8");
         ctx->accum_R = value;
+    } else if (!strcmp(key, "accum_blocks_per_cu")) {
+        if (value < 0 || value > 8) return fail(ctx, LBL_ERR_BAD_ARG, "accum_blocks_per_cu must be 0 (auto) .. 8");
+        for (int r = 0; r < 9; ++r) ctx->bal_workers[r] = value ? (ctx->n_cu > 0 ? ctx->n_cu : 256) * value * 4 : 0;
     } else if (!strcmp(key, "accum_tile_order")) {
         ctx->tile_order = value ? 1 : 0;
     } else if (!strcmp(key, "accum_line_split")) {
@@ -446,7 +454,9 @@ static void choose_shape(const lbl_ctx* ctx, long long total_points, long long t
     const bool lds = ctx->accum_variant >= 3;
     int R = ctx->accum_R, LS = lds ? ctx->accum_LS : 1;
     if (!R) {
-        if (lds) {
+        if (ctx->accum_variant >= 4) {
+            R = 4;                       // work is split by lines, not spans: no reason to shrink R on small grids
+        } else if (lds) {
             R = 4;
             while (R > 2 && total_points / (64LL * R) < 8 * cus) R >>= 1;
         } else {
@@ -551,6 +561,10 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         p.log_t0_over_T = std::log(296.0 / iso[j].T);
         p.n_lines = (int32_t)L->n;
     }
+    const bool balanced = ctx->accum_variant >= 4;
+    // balanced variant scratch, per group: SpanRec[S] | counts u32[S] | prefix u64[S+1] | slab
+    std::vector<size_t> bal_off(groups.size() + 1, 0);
+    std::vector<int> group_spans(groups.size(), 0), group_workers(groups.size(), 0);
     for (Group& g : groups) {
         const long long tile_pts = accumulate_tile_points(g.R, g.LS, ctx->accum_variant);
         for (int k = g.first; k < g.first + g.count; ++k) {
@@ -571,7 +585,26 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             a.flush_every = (a.H + 64 * g.R + 1 <= 40000) ? 32 : 16;
             a.pad = ctx->tile_order;
             g.max_tiles = std::max(g.max_tiles, a.n_tiles);
+            if (balanced) {
+                const size_t gi = (size_t)(&g - &groups[0]);
+                a.span_first = group_spans[gi];
+                a.n_spans = (int32_t)((sc + 64LL * g.R - 1) / (64LL * g.R));
+                group_spans[gi] += a.n_spans;
+            }
         }
+    }
+    if (balanced) {
+        size_t tot = 0;
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const size_t S = (size_t)group_spans[gi];
+            group_workers[gi] = ctx->bal_workers[groups[gi].R] ? ctx->bal_workers[groups[gi].R]
+                                                                 : (ctx->bal_workers[groups[gi].R] = balanced_workers(groups[gi].R, ctx->n_cu));
+            bal_off[gi] = tot;
+            tot += ((S * sizeof(SpanRec) + S * sizeof(unsigned int) + (S + 1) * sizeof(unsigned long long) + 255) & ~(size_t)255)
+                   + (size_t)group_workers[gi] * 2 * 64 * groups[gi].R * sizeof(double) + 256;
+        }
+        bal_off[groups.size()] = tot;
+        if ((rc = arena_reserve(ctx, ctx->bal, std::max<size_t>(tot, 256)))) return rc;
     }
     PrepJob* dp = (PrepJob*)ctx->jobs.ptr;
     AccumJob* da = (AccumJob*)((char*)ctx->jobs.ptr + prep_bytes);
@@ -585,9 +618,21 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     HIP_TRY(ctx, hipGetLastError());
     ctx->last_jobs = n_jobs;
     if (prep_only) return LBL_OK;
-    for (const Group& g : groups) {
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const Group& g = groups[gi];
         ev = prof_begin(ctx);
-        launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, ctx->accum_variant, ctx->stream);
+        if (balanced) {
+            const size_t S = (size_t)group_spans[gi];
+            char* base = (char*)ctx->bal.ptr + bal_off[gi];
+            SpanRec* spans = (SpanRec*)base;
+            unsigned long long* prefix = (unsigned long long*)(base + S * sizeof(SpanRec));       // 8-byte aligned: 16 B * S
+            unsigned int* cnts = (unsigned int*)(base + S * sizeof(SpanRec) + (S + 1) * sizeof(unsigned long long));
+            double* slab = (double*)(base + ((S * sizeof(SpanRec) + S * sizeof(unsigned int) + (S + 1) * sizeof(unsigned long long) + 255) & ~(size_t)255));
+            launch_accumulate_balanced(da + g.first, g.count, (int)S, g.R, group_workers[gi], spans, cnts, prefix, slab,
+                                       ctx->stream);
+        } else {
+            launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, ctx->accum_variant, ctx->stream);
+        }
         prof_end(ctx, PROF_ACCUM, ev);
         HIP_TRY(ctx, hipGetLastError());
     }

@@ -56,8 +56,14 @@ struct AccumJob {
     int32_t p_begin;       // shard of the work grid computed by this job: [p_begin, p_end)
     int32_t p_end;
     int32_t flush_every;   // lines per running-fraction block: 32, or 16 for very wide windows
-    int32_t pad;
+    int32_t pad;           // LS variant: tile order (0 XCD-chunked, 1 natural)
+    int32_t span_first;    // balanced variant: first global span id of this job
+    int32_t n_spans;
 };
+
+// Balanced variant: spans (64*R consecutive grid points) of all jobs of a launch group are
+// numbered job-major; job j owns spans [span_first, span_first + n_spans).
+struct SpanRec { int32_t iA, iB, iC, iD; };
 
 struct PrepJob {
     const double* nu; const double* sw; const double* elower; const double* gamma_air;
@@ -104,6 +110,11 @@ struct ColumnArgs {
 void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStream_t s);
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant, hipStream_t s);
 int accumulate_tile_points(int R, int LS, int variant);
+// balanced variant (4): span ranges -> prefix sum -> equal shares of (span, line) pairs per wave -> slab reduce
+int balanced_workers(int R, int n_cu);
+void launch_accumulate_balanced(const AccumJob* d_jobs, int n_jobs, int total_spans, int R, int n_workers,
+                                SpanRec* spans, unsigned int* counts, unsigned long long* prefix, double* slab,
+                                hipStream_t s);
 void launch_regrid(const double* work, long long n_work, double* out, long long n_base, double start, double stop,
                    hipStream_t s);
 void launch_layer_sweep(const SweepArgs& a, hipStream_t s);

@@ -496,6 +496,74 @@ __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, cons
     }
 }
 
+// Lines [mA, mD) of one job against the 64*R points of a wave (wlo..whi; x0 = this lane's first
+// point).  Lines below iB or from iC on end inside the wave's span and are masked per point.
+// The wave streams the records in chunks of 64 through its own LDS (lh: hot halves, lc: cold
+// halves), with the next chunk's loads in flight while the current one is consumed.
+template <int R>
+__device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRec* cold, int mA, int mD, int iB, int iC,
+                                                 int wlo, int whi, double x0, double Hf, double* lh, double* lc, int lane,
+                                                 WaveAcc<R>& S) {
+    // global address space made explicit: a flat load would also count on lgkmcnt and every
+    // LDS wait would then drain the prefetch of the next chunk
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    typedef const v2f64 __attribute__((address_space(1)))* GlobalF64x2;
+    const GlobalF64x2 gh = (GlobalF64x2)(unsigned long long)hot;
+    const GlobalF64x2 gc = (GlobalF64x2)(unsigned long long)cold;
+    // software pipeline: registers hold the NEXT chunk's hot halves while LDS holds the current one
+    v2f64 h0 = {0, 0}, h1 = {0, 0};
+    if (mA + lane < mD) {
+        const long long r = (long long)(mA + lane) * 2;
+        h0 = gh[r]; h1 = gh[r + 1];
+    }
+    for (int c0 = mA; c0 < mD; c0 += 64) {
+        const int c1 = min(c0 + 64, mD);
+        __builtin_amdgcn_wave_barrier();
+        // per-record branch decisions for the whole chunk, one lane per record
+        const int ci = (int)h0.x;
+        const int dgi = __double2loint(h1.y), fl = __double2hiint(h1.y);
+        const bool valid = c0 + lane < c1;
+        const bool gauss = valid && max(0, max(ci - whi, wlo - ci)) < dgi;
+        const bool direct = valid && (fl & REC_DIRECT_DIV) != 0;
+        const unsigned long long gmask = __ballot(gauss);
+        const unsigned long long dmask = __ballot(direct);
+        const unsigned long long emask = __ballot((fl & REC_NO_RECUR) != 0);
+        v2f64 w0 = h0, w1 = h1;
+        if (direct) { w0.y = 1.0; w1.x = 0.0; }          // a2 = 1, KL = 0 in the hot loop's copy
+        reinterpret_cast<v2f64*>(lh)[lane * 2] = w0;
+        reinterpret_cast<v2f64*>(lh)[lane * 2 + 1] = w1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // cold halves only for the records that will use them (about one in eight); they
+        // land while the Lorentz loop below runs
+        v2f64 c0v = {0, 0}, c1v = {0, 0};
+        if (gauss || direct) {
+            const long long r = (long long)(c0 + lane) * 2;
+            c0v = gc[r]; c1v = gc[r + 1];
+        }
+        if (c1 + lane < mD) {
+            const long long r = (long long)(c1 + lane) * 2;
+            h0 = gh[r]; h1 = gh[r + 1];
+        }
+        // the three classes of lines inside this chunk, as offsets into the chunk
+        const int a0 = 0, a1 = max(min(iB, c1), c0) - c0;
+        const int b1 = max(min(iC, c1), c0) - c0;
+        const int e1 = c1 - c0;
+        rf_segment<R, true>(lh, a0, a1, x0, Hf, S);
+        rf_segment<R, false>(lh, a1, b1, x0, Hf, S);
+        rf_segment<R, true>(lh, b1, e1, x0, Hf, S);
+        if (gmask | dmask) {
+            if (gauss || direct) {
+                reinterpret_cast<v2f64*>(lc)[lane * 2] = c0v;
+                reinterpret_cast<v2f64*>(lc)[lane * 2 + 1] = c1v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            chunk_extras<R>(lh, lc, gmask, emask, dmask, x0, Hf, S);
+        }
+    }
+}
+
 // LDS slot of grid-point offset o within a wave's span (padded so that a lane writing its R
 // consecutive points and a lane reading every 64th point are both nearly conflict-free)
 __device__ __forceinline__ int span_slot(int o) { return o + (o >> 4); }
@@ -534,64 +602,7 @@ __global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_ker
         // this wave's share of the span's lines
         const long long nl = (long long)iD - iA;
         const int mA = iA + (int)(nl * part / LS), mD = iA + (int)(nl * (part + 1) / LS);
-        // global address space made explicit: a flat load would also count on lgkmcnt and every
-        // LDS wait would then drain the prefetch of the next chunk
-        typedef double v2f64 __attribute__((ext_vector_type(2)));
-        typedef const v2f64 __attribute__((address_space(1)))* GlobalF64x2;
-        const GlobalF64x2 gh = (GlobalF64x2)(unsigned long long)J.hot;
-        const GlobalF64x2 gc = (GlobalF64x2)(unsigned long long)J.cold;
-        // software pipeline: registers hold the NEXT chunk's hot halves while LDS holds the current one
-        v2f64 h0 = {0, 0}, h1 = {0, 0};
-        if (mA + lane < mD) {
-            const long long r = (long long)(mA + lane) * 2;
-            h0 = gh[r]; h1 = gh[r + 1];
-        }
-        for (int c0 = mA; c0 < mD; c0 += 64) {
-            const int c1 = min(c0 + 64, mD);
-            __builtin_amdgcn_wave_barrier();
-            // per-record branch decisions for the whole chunk, one lane per record
-            const int ci = (int)h0.x;
-            const int dgi = __double2loint(h1.y), fl = __double2hiint(h1.y);
-            const bool valid = c0 + lane < c1;
-            const bool gauss = valid && max(0, max(ci - whi, wlo - ci)) < dgi;
-            const bool direct = valid && (fl & REC_DIRECT_DIV) != 0;
-            const unsigned long long gmask = __ballot(gauss);
-            const unsigned long long dmask = __ballot(direct);
-            const unsigned long long emask = __ballot((fl & REC_NO_RECUR) != 0);
-            v2f64 w0 = h0, w1 = h1;
-            if (direct) { w0.y = 1.0; w1.x = 0.0; }          // a2 = 1, KL = 0 in the hot loop's copy
-            reinterpret_cast<v2f64*>(lh)[lane * 2] = w0;
-            reinterpret_cast<v2f64*>(lh)[lane * 2 + 1] = w1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // cold halves only for the records that will use them (about one in eight); they
-            // land while the Lorentz loop below runs
-            v2f64 c0v = {0, 0}, c1v = {0, 0};
-            if (gauss || direct) {
-                const long long r = (long long)(c0 + lane) * 2;
-                c0v = gc[r]; c1v = gc[r + 1];
-            }
-            if (c1 + lane < mD) {
-                const long long r = (long long)(c1 + lane) * 2;
-                h0 = gh[r]; h1 = gh[r + 1];
-            }
-            // the three classes of lines inside this chunk, as offsets into the chunk
-            const int a0 = 0, a1 = max(min(iB, c1), c0) - c0;
-            const int b1 = max(min(iC, c1), c0) - c0;
-            const int e1 = c1 - c0;
-            rf_segment<R, true>(lh, a0, a1, x0, Hf, S);
-            rf_segment<R, false>(lh, a1, b1, x0, Hf, S);
-            rf_segment<R, true>(lh, b1, e1, x0, Hf, S);
-            if (gmask | dmask) {
-                if (gauss || direct) {
-                    reinterpret_cast<v2f64*>(lc)[lane * 2] = c0v;
-                    reinterpret_cast<v2f64*>(lc)[lane * 2 + 1] = c1v;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                chunk_extras<R>(lh, lc, gmask, emask, dmask, x0, Hf, S);
-            }
-        }
+        accumulate_lines<R>(J.hot, J.cold, mA, mD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S);
         S.flush();
     }
 
@@ -613,6 +624,229 @@ __global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_ker
             for (int q = 1; q < LS; ++q) t += s_stage[wave + q][span_slot(o)];
             if (wlo + o < n_end) out[wlo + o] = t;
         }
+    }
+}
+
+// ---- variant 4: balanced single-round partition -----------------------------------------------
+// Small grids do not fill the chip evenly with one workgroup per span: C2 has 1.5-3 rounds of
+// workgroups of very different length (line density varies 7x) and ran with the VALU only 55-69 %
+// busy.  Here the unit of work is a (span, line) pair.  P1 finds every span's line range, P2
+// prefix-sums the counts, and K2b gives each of the W resident wavefronts exactly ceil(P/W)
+// consecutive pairs: every wave does the same number of line iterations and they all finish
+// together.  A wave's share may start and end inside a span; such partial sums go to a slab
+// (at most two per wave) and P3 adds the slabs of a split span in wave order, so the result is
+// still deterministic.  Spans covered by one wave are stored directly.
+__device__ __forceinline__ int find_job(const AccumJob* __restrict__ jobs, int n_jobs, int g, int j0 = 0) {
+    int j = j0;
+    while (j + 1 < n_jobs && g >= jobs[j].span_first + jobs[j].n_spans) ++j;
+    return j;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void span_ranges_kernel(const AccumJob* __restrict__ jobs, int n_jobs, int total_spans,
+                                                          SpanRec* __restrict__ spans, unsigned int* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int g = uniform_i32(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (g >= total_spans) return;
+    const AccumJob& J = jobs[find_job(jobs, n_jobs, g)];
+    const int wlo = J.p_begin + (g - J.span_first) * (64 * R);
+    const int whi = min(wlo + 64 * R - 1, J.p_end - 1);
+    int iA, iB, iC, iD;
+    wave_line_ranges(J.cidx, J.n_lines, wlo, whi, J.H, lane, iA, iB, iC, iD);
+    if (lane == 0) {
+        SpanRec r; r.iA = iA; r.iB = iB; r.iC = iC; r.iD = iD;
+        spans[g] = r;
+        counts[g] = (unsigned int)(iD - iA);
+    }
+}
+
+// exclusive prefix sum of n counts into prefix[0..n] (single workgroup of 1024 threads)
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const unsigned int* __restrict__ counts, int n,
+                                                           unsigned long long* __restrict__ prefix) {
+    __shared__ unsigned long long part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(t * per, n), hi = min(lo + per, n);
+    unsigned long long s = 0;
+    for (int i = lo; i < hi; ++i) s += counts[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
+        unsigned long long v = (t >= off) ? part[t - off] : 0ull;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned long long run = part[t] - s;                 // exclusive base of this thread's segment
+    for (int i = lo; i < hi; ++i) { prefix[i] = run; run += counts[i]; }
+    if (t == 1023) prefix[n] = part[1023];
+}
+
+// first index i in [0, n] with prefix[i] > key (prefix non-decreasing): 16-ary search by the
+// first 16 lanes' worth of probes replicated over the wave
+__device__ __forceinline__ int upper_bound_u64(const unsigned long long* __restrict__ a, int n, unsigned long long key,
+                                               int lane) {
+    const int jj = lane & 15;
+    int lo = 0, hi = n;                                   // answer in [lo, hi]; a[n] treated as > key if none
+    while (hi > lo) {
+        const long long len = (long long)hi - lo;
+        const int pos = lo + (int)(((long long)(jj + 1) * len) / 17);
+        const bool le = a[pos] <= key;                    // pos < hi <= n: always a valid slot of prefix[0..n]
+        const int k = __popcll(__ballot(le) & 0xFFFFull);
+        const int p_k = lo + (int)(((long long)(k + 1) * len) / 17);
+        const int p_km1 = lo + (int)(((long long)k * len) / 17);
+        const int new_lo = k > 0 ? p_km1 + 1 : lo;
+        const int new_hi = k < 16 ? p_k : hi;
+        lo = new_lo; hi = new_hi;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ unsigned long long pairs_per_worker(unsigned long long P, int W) {
+    unsigned long long q = (P + (unsigned long long)W - 1) / (unsigned long long)W;
+    return q < 64ull ? 64ull : q;                         // at least one chunk of lines per wave
+}
+
+template <int R>
+__global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_balanced_kernel(
+        const AccumJob* __restrict__ jobs, int n_jobs, int total_spans, const SpanRec* __restrict__ spans,
+        const unsigned long long* __restrict__ prefix, int W, double* __restrict__ slab) {
+    constexpr int STAGE = (68 * R > 512) ? 68 * R : 512;
+    __shared__ double s_stage[4][STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform_i32(threadIdx.x >> 6);
+    const int w = uniform_i32(blockIdx.x * 4 + wave);
+    if (w >= W) return;
+    const unsigned long long P = prefix[total_spans];
+    const unsigned long long Q = pairs_per_worker(P, W);
+    const unsigned long long start = (unsigned long long)w * Q;
+    if (start >= P) return;
+    const unsigned long long end = (start + Q < P) ? start + Q : P;
+    double* lh = s_stage[wave];
+    double* lc = s_stage[wave] + 256;
+
+    int s = uniform_i32(upper_bound_u64(prefix, total_spans, start, lane)) - 1;      // prefix[s] <= start < prefix[s+1]
+    int j = 0;
+    unsigned long long pos = start;
+    while (pos < end) {
+        const unsigned long long p_lo = prefix[s], p_hi = prefix[s + 1];
+        if (p_hi <= pos) { ++s; continue; }               // empty span, or the previous one was just finished
+        const int n_s = (int)(p_hi - p_lo);
+        const int off = (int)(pos - p_lo);
+        const int piece = (int)((end - pos < (unsigned long long)(n_s - off)) ? (end - pos) : (unsigned long long)(n_s - off));
+        j = find_job(jobs, n_jobs, s, j);
+        const AccumJob& J = jobs[j];
+        const SpanRec r = spans[s];
+        const int wlo = J.p_begin + (s - J.span_first) * (64 * R);
+        const int n_end = J.p_end;
+        const int whi = min(wlo + 64 * R - 1, n_end - 1);
+        const double x0 = (double)(wlo + lane * R);
+        const double Hf = (double)J.H;
+        WaveAcc<R> S;
+        S.init(J.flush_every);
+        accumulate_lines<R>(J.hot, J.cold, r.iA + off, r.iA + off + piece, r.iB, r.iC, wlo, whi, x0, Hf, lh, lc, lane, S);
+        S.flush();
+        // coalesced store through LDS: whole spans straight to the output, partial ones to the slab
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < R; ++k) lh[span_slot(lane * R + k)] = S.acc[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool whole = (off == 0) && (piece == n_s);
+        double* __restrict__ dst = whole ? (J.out + wlo)
+                                         : (slab + ((size_t)w * 2 + (pos == start ? 0 : 1)) * (size_t)(64 * R));
+        const int limit = whole ? (n_end - wlo) : 64 * R;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int o = i * 64 + lane;
+            if (o < limit) dst[o] = lh[span_slot(o)];
+        }
+        __builtin_amdgcn_wave_barrier();
+        pos += (unsigned long long)piece;
+    }
+}
+
+// P3: one wave per span: zeros for spans no line reaches, slab sums (in wave order) for split spans
+template <int R>
+__global__ __launch_bounds__(256) void span_finalize_kernel(const AccumJob* __restrict__ jobs, int n_jobs, int total_spans,
+                                                            const unsigned long long* __restrict__ prefix, int W,
+                                                            const double* __restrict__ slab) {
+    const int lane = threadIdx.x & 63;
+    const int g = uniform_i32(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (g >= total_spans) return;
+    const AccumJob& J = jobs[find_job(jobs, n_jobs, g)];
+    const int wlo = J.p_begin + (g - J.span_first) * (64 * R);
+    const int n_end = J.p_end;
+    double* __restrict__ out = J.out;
+    const unsigned long long p_lo = prefix[g], p_hi = prefix[g + 1];
+    if (p_hi == p_lo) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int o = i * 64 + lane;
+            if (wlo + o < n_end) out[wlo + o] = 0.0;
+        }
+        return;
+    }
+    const unsigned long long Q = pairs_per_worker(prefix[total_spans], W);
+    const int w0 = (int)(p_lo / Q), w1 = (int)((p_hi - 1) / Q);
+    if (w0 == w1) return;                                  // stored directly by its only wave
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int o = i * 64 + lane;
+        double t = 0.0;
+        for (int w = w0; w <= w1; ++w) {
+            // a wave that started before this span contributes its LAST piece (slot 1); a wave that
+            // starts inside (or at) the span contributes its FIRST piece (slot 0)
+            const int slot = (w == w0 && (unsigned long long)w0 * Q < p_lo) ? 1 : 0;
+            t += slab[((size_t)w * 2 + slot) * (size_t)(64 * R) + o];
+        }
+        if (wlo + o < n_end) out[wlo + o] = t;
+    }
+}
+
+// Number of wavefronts that are resident at once: the partition must fit in ONE round, so ask the
+// runtime how many 256-thread workgroups of the kernel a CU holds (registers, LDS) and stay one
+// workgroup per CU below the answer when it is at the 8-block edge (the API over-reports there for
+// SGPR-heavy kernels, MI355X_MICROARCH.md "Residency and cooperative launch").
+template <int R>
+static int balanced_workers_r(int n_cu) {
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, xsec_accumulate_balanced_kernel<R>, 256, 0) != hipSuccess || blocks < 1)
+        blocks = 2;
+    if (blocks >= 8) blocks = 7;
+    return (n_cu > 0 ? n_cu : 256) * blocks * 4;
+}
+
+int balanced_workers(int R, int n_cu) {
+    switch (R) {
+        case 1: return balanced_workers_r<1>(n_cu);
+        case 2: return balanced_workers_r<2>(n_cu);
+        case 4: return balanced_workers_r<4>(n_cu);
+        default: return balanced_workers_r<8>(n_cu);
+    }
+}
+
+template <int R>
+static void launch_balanced_r(const AccumJob* d_jobs, int n_jobs, int total_spans, int n_workers, SpanRec* spans,
+                              unsigned int* counts, unsigned long long* prefix, double* slab, hipStream_t s) {
+    const int span_blocks = (total_spans + 3) / 4;
+    hipLaunchKernelGGL((span_ranges_kernel<R>), dim3(span_blocks), dim3(256), 0, s, d_jobs, n_jobs, total_spans, spans, counts);
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, counts, total_spans, prefix);
+    hipLaunchKernelGGL((xsec_accumulate_balanced_kernel<R>), dim3((n_workers + 3) / 4), dim3(256), 0, s, d_jobs, n_jobs,
+                       total_spans, spans, prefix, n_workers, slab);
+    hipLaunchKernelGGL((span_finalize_kernel<R>), dim3(span_blocks), dim3(256), 0, s, d_jobs, n_jobs, total_spans, prefix,
+                       n_workers, slab);
+}
+
+void launch_accumulate_balanced(const AccumJob* d_jobs, int n_jobs, int total_spans, int R, int n_workers,
+                                SpanRec* spans, unsigned int* counts, unsigned long long* prefix, double* slab,
+                                hipStream_t s) {
+    if (n_jobs <= 0 || total_spans <= 0) return;
+    switch (R) {
+        case 1: launch_balanced_r<1>(d_jobs, n_jobs, total_spans, n_workers, spans, counts, prefix, slab, s); break;
+        case 2: launch_balanced_r<2>(d_jobs, n_jobs, total_spans, n_workers, spans, counts, prefix, slab, s); break;
+        case 4: launch_balanced_r<4>(d_jobs, n_jobs, total_spans, n_workers, spans, counts, prefix, slab, s); break;
+        default: launch_balanced_r<8>(d_jobs, n_jobs, total_spans, n_workers, spans, counts, prefix, slab, s); break;
     }
 }
 

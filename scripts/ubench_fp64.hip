@@ -21,6 +21,109 @@ __global__ __launch_bounds__(256) void k_fma(double* out, int iters, double a, d
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+template <int R>
+__global__ __launch_bounds__(256) void k_mul(double* out, int iters, double a) {
+    double v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) v[k] = 1.0 + threadIdx.x * 1e-9 + k * 1e-10;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = v[k] * a;
+    }
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) s += v[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_add(double* out, int iters, double a) {
+    double v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) v[k] = threadIdx.x * 1e-3 + k;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = v[k] + a;
+    }
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) s += v[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// FMA whose three sources are all (non-uniform) VGPR pairs
+template <int R>
+__global__ __launch_bounds__(256) void k_fma3(double* out, int iters) {
+    double v[R], w[R], u[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { v[k] = threadIdx.x * 1e-3 + k; w[k] = 1.0 + 1e-9 * threadIdx.x + 1e-10 * k; u[k] = 1e-9 * (threadIdx.x + k); }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = fma(v[k], w[k], u[k]);
+    }
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) s += v[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// running fraction with the per-line constants in VGPRs (as after an LDS broadcast read)
+template <int R>
+__global__ __launch_bounds__(256) void k_rf_vgpr(double* out, int iters, const double* __restrict__ params) {
+    double N[R], D[R];
+    const double x0 = threadIdx.x * (double)R;
+#pragma unroll
+    for (int k = 0; k < R; ++k) { N[k] = 0; D[k] = 1; }
+    double acc = 0;
+    __shared__ double sh[128];
+    if (threadIdx.x < 128) sh[threadIdx.x] = params[threadIdx.x];
+    __syncthreads();
+    for (int i = 0; i < iters; ++i) {
+        const double cf = sh[(i & 63) * 2 + 0] + i, a2 = sh[(i & 63) * 2 + 1], KL = sh[((i + 7) & 63) * 2 + 1] * 1e-24;
+        const double d0 = x0 - cf;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double d = d0 + (double)k;
+            const double den = fma(d, d, a2);
+            const double t = KL * D[k];
+            N[k] = fma(N[k], den, t);
+            D[k] *= den;
+        }
+        if ((i & 31) == 31) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) { acc += N[k] / D[k]; N[k] = 0; D[k] = 1; }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+// running fraction with every multiply and add written as an FMA
+template <int R>
+__global__ __launch_bounds__(256) void k_rf_fma(double* out, int iters, const double* __restrict__ params, double one, double zero) {
+    double N[R], D[R];
+    const double x0 = threadIdx.x * (double)R;
+#pragma unroll
+    for (int k = 0; k < R; ++k) { N[k] = 0; D[k] = 1; }
+    double acc = 0;
+    for (int i = 0; i < iters; ++i) {
+        const double cf = params[(i & 63) * 2 + 0] + i, a2 = params[(i & 63) * 2 + 1];
+        const double d0 = x0 - cf;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double d = __builtin_fma(one, d0, (double)k);
+            const double den = __builtin_fma(d, d, a2);
+            const double t = __builtin_fma(1e-20, D[k], zero);
+            N[k] = __builtin_fma(N[k], den, t);
+            D[k] = __builtin_fma(D[k], den, zero);
+        }
+        if ((i & 15) == 15) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) { acc += N[k] / D[k]; N[k] = 0; D[k] = 1; }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 // the running-fraction Lorentz body: per point  d = d0+k; den = d*d+a2; t = K*D; N = N*den+t; D *= den
 template <int R>
 __global__ __launch_bounds__(256) void k_rf(double* out, int iters, const double* __restrict__ params) {
@@ -127,7 +230,7 @@ static float time_it(F launch, int reps) {
 }
 
 int main() {
-    const int blocks_per_cu[] = {1, 2, 4, 8};
+    const int blocks_per_cu[] = {2, 8};
     double* out; double* params;
     CHECK(hipMalloc(&out, 256 * 8 * 256 * sizeof(double) * 4));
     CHECK(hipMalloc(&params, 128 * sizeof(double)));
@@ -142,6 +245,16 @@ int main() {
         float ms;
         ms = time_it([&] { hipLaunchKernelGGL(k_fma<8>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0000001, 1e-9); }, 5);
         printf("%-28s %8d %10.3f %14.3e %16s\n", "fma x8 chains", bpc, ms, lanes * iters * 8 / (ms * 1e-3), "-");
+        ms = time_it([&] { hipLaunchKernelGGL(k_mul<8>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0000001); }, 5);
+        printf("%-28s %8d %10.3f %14.3e %16s\n", "mul x8 chains", bpc, ms, lanes * iters * 8 / (ms * 1e-3), "-");
+        ms = time_it([&] { hipLaunchKernelGGL(k_add<8>, dim3(grid), dim3(256), 0, 0, out, iters, 1e-9); }, 5);
+        printf("%-28s %8d %10.3f %14.3e %16s\n", "add x8 chains", bpc, ms, lanes * iters * 8 / (ms * 1e-3), "-");
+        ms = time_it([&] { hipLaunchKernelGGL(k_fma3<8>, dim3(grid), dim3(256), 0, 0, out, iters); }, 5);
+        printf("%-28s %8d %10.3f %14.3e %16s\n", "fma 3 VGPR sources x8", bpc, ms, lanes * iters * 8 / (ms * 1e-3), "-");
+        ms = time_it([&] { hipLaunchKernelGGL(k_rf_vgpr<4>, dim3(grid), dim3(256), 0, 0, out, iters, params); }, 5);
+        printf("%-28s %8d %10.3f %14.3e %16.3e\n", "running fraction LDS consts R=4", bpc, ms, lanes * iters * 4 * 5 / (ms * 1e-3), lanes * iters * 4 / (ms * 1e-3));
+        ms = time_it([&] { hipLaunchKernelGGL(k_rf_fma<4>, dim3(grid), dim3(256), 0, 0, out, iters, params, 1.0, 0.0); }, 5);
+        printf("%-28s %8d %10.3f %14.3e %16.3e\n", "running fraction FMA-only R=4", bpc, ms, lanes * iters * 4 * 5 / (ms * 1e-3), lanes * iters * 4 / (ms * 1e-3));
         ms = time_it([&] { hipLaunchKernelGGL(k_rf<4>, dim3(grid), dim3(256), 0, 0, out, iters, params); }, 5);
         printf("%-28s %8d %10.3f %14.3e %16.3e\n", "running fraction R=4", bpc, ms, lanes * iters * 4 * 5 / (ms * 1e-3), lanes * iters * 4 / (ms * 1e-3));
         ms = time_it([&] { hipLaunchKernelGGL(k_rf<8>, dim3(grid), dim3(256), 0, 0, out, iters, params); }, 5);
