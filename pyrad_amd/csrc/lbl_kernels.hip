@@ -217,7 +217,7 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t* __restrict__ a, in
 // (b d0^2 > 708) cannot reach a point where the term still matters (b d^2 < ~45) within R <= 8
 // steps: there  b (d0^2 - d^2) <= 14 sqrt(45 b) + 49 b < 400.  The exponent of r is clamped so
 // that a far lane computes 0 * finite = 0, never 0 * inf.
-template <int R, int GM>
+template <int R, int GM, bool MASKED = true>
 __device__ __forceinline__ void gauss_term(double KG, double b, bool recur, double d0, double Hf, double q2,
                                            double (&acc)[R]) {
     if (GM == 0 || !recur || R < 4) {
@@ -225,15 +225,19 @@ __device__ __forceinline__ void gauss_term(double KG, double b, bool recur, doub
         for (int k = 0; k < R; ++k) {
             const double d = d0 + (double)k;
             const double t = KG * exp(-b * (d * d));
-            acc[k] += (fabs(d) <= Hf) ? t : 0.0;
+            acc[k] += (!MASKED || fabs(d) <= Hf) ? t : 0.0;
         }
     } else {
         double g = KG * exp(-b * (d0 * d0));
         double rr = exp(fmin(-b * (2.0 * d0 + 1.0), 700.0));
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const double d = d0 + (double)k;
-            acc[k] += (fabs(d) <= Hf) ? g : 0.0;
+            if (MASKED) {
+                const double d = d0 + (double)k;
+                acc[k] += (fabs(d) <= Hf) ? g : 0.0;
+            } else {
+                acc[k] += g;
+            }
             g *= rr;
             rr *= q2;
         }
@@ -256,9 +260,20 @@ struct WaveAcc {
         cnt = 0;
         every = flush_every;
     }
+    // N/D by reciprocal + two Newton steps + one residual correction of the quotient (7 fp64
+    // instructions instead of the 12 of an IEEE divide; D is a product of finite positive
+    // denominators in [1e-288, 1e296], so no special cases; the quotient is within 1 ulp)
     __device__ __forceinline__ void flush() {
 #pragma unroll
-        for (int k = 0; k < R; ++k) { acc[k] += N[k] / D[k]; N[k] = 0.0; D[k] = 1.0; }
+        for (int k = 0; k < R; ++k) {
+            double r = __builtin_amdgcn_rcp(D[k]);
+            r = fma(fma(-D[k], r, 1.0), r, r);
+            r = fma(fma(-D[k], r, 1.0), r, r);
+            double q = N[k] * r;
+            q = fma(fma(-D[k], q, N[k]), r, q);
+            acc[k] += q;
+            N[k] = 0.0; D[k] = 1.0;
+        }
         cnt = 0;
     }
 };
@@ -463,15 +478,25 @@ __device__ __forceinline__ void rf_segment(const double* __restrict__ lh, int j0
 template <int R>
 __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, const double* __restrict__ lc,
                                              unsigned long long gmask, unsigned long long emask,
-                                             unsigned long long dmask, double x0, double Hf, WaveAcc<R>& S) {
+                                             unsigned long long dmask, unsigned long long imask, double x0, double Hf,
+                                             WaveAcc<R>& S) {
     // emask bit j: record j must use one exp per point (profile too narrow for the recurrence)
-    unsigned long long m = gmask & ~emask;
+    // imask bit j: record j is an interior line (every point of the wave inside its support): no masking
+    unsigned long long m = gmask & ~emask & imask;
     while (m) {
         const int j = __builtin_ctzll(m);
         m &= m - 1;
         const double d0 = x0 - lh[j * 4];
         const double* c = lc + j * 4;
-        gauss_term<R, 1>(c[0], c[1], true, d0, Hf, c[2], S.acc);
+        gauss_term<R, 1, false>(c[0], c[1], true, d0, Hf, c[2], S.acc);
+    }
+    m = gmask & ~emask & ~imask;
+    while (m) {
+        const int j = __builtin_ctzll(m);
+        m &= m - 1;
+        const double d0 = x0 - lh[j * 4];
+        const double* c = lc + j * 4;
+        gauss_term<R, 1, true>(c[0], c[1], true, d0, Hf, c[2], S.acc);
     }
     m = gmask & emask;
     while (m) {
@@ -559,7 +584,9 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            chunk_extras<R>(lh, lc, gmask, emask, dmask, x0, Hf, S);
+            // records a1..b1-1 of the chunk are interior lines
+            const unsigned long long imask = (b1 > a1) ? ((b1 - a1 >= 64 ? ~0ull : ((1ull << (b1 - a1)) - 1ull)) << a1) : 0ull;
+            chunk_extras<R>(lh, lc, gmask, emask, dmask, imask, x0, Hf, S);
         }
     }
 }
