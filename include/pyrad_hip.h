@@ -108,6 +108,7 @@ int lbl_set_option(lbl_ctx* ctx, const char* key, int value);
 /* Kernel timing with HIP events recorded on the context stream around every launch of a
  * kernel class (the stream the kernels run on; torch.cuda.Event would not see it).
  * kind: 0 line_prep, 1 xsec_accumulate, 2 regrid, 3 layer_sweep, 4 column_sweep, 5 all-gather.
+ * `on` is a bit mask of kinds (bit k = kind k; 0x3F = all; <= 0 = off).
  * lbl_profile_read drains the stream, returns the number of launches recorded since the last
  * reset and their summed duration in milliseconds. */
 int lbl_profile_enable(lbl_ctx* ctx, int on);

@@ -201,8 +201,17 @@ class Context:
     PROFILE_KINDS = {"line_prep": 0, "xsec_accumulate": 1, "regrid": 2, "layer_sweep": 3, "column_sweep": 4,
                      "allgather": 5}
 
-    def profile_enable(self, on=True):
-        self.check(self.lib.lbl_profile_enable(self.h, 1 if on else 0))
+    def profile_enable(self, kinds=True):
+        """kinds: True (all), False (off) or an iterable of PROFILE_KINDS names."""
+        if kinds is True:
+            mask = 0x3F
+        elif not kinds:
+            mask = 0
+        else:
+            mask = 0
+            for k in kinds:
+                mask |= 1 << self.PROFILE_KINDS[k]
+        self.check(self.lib.lbl_profile_enable(self.h, mask))
 
     def profile_reset(self):
         self.check(self.lib.lbl_profile_reset(self.h))

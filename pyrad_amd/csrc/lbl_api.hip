@@ -61,7 +61,7 @@ struct lbl_ctx {
                              // all CUs work through one region together); 0: each XCD gets a contiguous run
     int live_objects = 0;
     // event timing (lbl_profile_*)
-    bool profiling = false;
+    unsigned profiling = 0;        // bit k set: time kernel class k
     std::vector<hipEvent_t> ev_pool;                       // idle events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_rec[kProfileKinds];
 };
@@ -117,8 +117,8 @@ static hipEvent_t prof_event(lbl_ctx* ctx) {
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
-static hipEvent_t prof_begin(lbl_ctx* ctx) {
-    if (!ctx->profiling) return nullptr;
+static hipEvent_t prof_begin(lbl_ctx* ctx, int kind) {
+    if (!((ctx->profiling >> kind) & 1u)) return nullptr;
     hipEvent_t e = prof_event(ctx);
     if (e) (void)hipEventRecord(e, ctx->stream);
     return e;
@@ -251,7 +251,7 @@ extern "C" int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu
 
 extern "C" int lbl_profile_enable(lbl_ctx* ctx, int on) {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
-    ctx->profiling = on != 0;
+    ctx->profiling = on > 0 ? (unsigned)on : 0u;
     return LBL_OK;
 }
 
@@ -282,7 +282,7 @@ extern "C" int lbl_profile_read(lbl_ctx* ctx, int kind, int64_t* launches, doubl
 
 // hook for lbl_comm.hip: time the all-gather like any other kernel class
 namespace lbl {
-void* comm_prof_begin(lbl_ctx* ctx) { return (void*)prof_begin(ctx); }
+void* comm_prof_begin(lbl_ctx* ctx) { return (void*)prof_begin(ctx, PROF_GATHER); }
 void comm_prof_end(lbl_ctx* ctx, void* start) { prof_end(ctx, PROF_GATHER, (hipEvent_t)start); }
 }  // namespace lbl
 
@@ -612,7 +612,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     ctx->last_blocks_per_job = blocks_per_job;
     ctx->last_job_lines.assign(n_jobs, 0);
     for (int j = 0; j < n_jobs; ++j) ctx->last_job_lines[j] = (int)lines[j]->n;
-    hipEvent_t ev = prof_begin(ctx);
+    hipEvent_t ev = prof_begin(ctx, PROF_PREP);
     launch_line_prep(dp, n_jobs, max_lines, ctx->stream);
     prof_end(ctx, PROF_PREP, ev);
     HIP_TRY(ctx, hipGetLastError());
@@ -620,7 +620,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     if (prep_only) return LBL_OK;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const Group& g = groups[gi];
-        ev = prof_begin(ctx);
+        ev = prof_begin(ctx, PROF_ACCUM);
         if (balanced) {
             const size_t S = (size_t)group_spans[gi];
             char* base = (char*)ctx->bal.ptr + bal_off[gi];
@@ -638,7 +638,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     }
     for (int j = 0; j < n_jobs; ++j) {
         if (!needs_regrid(grid[j])) continue;
-        ev = prof_begin(ctx);
+        ev = prof_begin(ctx, PROF_REGRID);
         launch_regrid((const double*)ctx->work.ptr + work_off[j], grid[j].n_work, out_dev[j], grid[j].n_base,
                       grid[j].range_min, grid[j].range_max, ctx->stream);
         prof_end(ctx, PROF_REGRID, ev);
@@ -795,7 +795,7 @@ extern "C" int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* x
     a.I_out = I_out ? I_out->d : nullptr;
     a.n = n; a.first = first; a.count = count;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipEvent_t ev = prof_begin(ctx);
+    hipEvent_t ev = prof_begin(ctx, PROF_SWEEP);
     launch_layer_sweep(a, ctx->stream);
     prof_end(ctx, PROF_SWEEP, ev);
     HIP_TRY(ctx, hipGetLastError());
@@ -835,7 +835,7 @@ extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* cons
     a->n = n; a->first = first; a->count = count;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->colargs.ptr, a, sizeof(ColumnArgs), hipMemcpyHostToDevice, ctx->stream));
-    hipEvent_t ev = prof_begin(ctx);
+    hipEvent_t ev = prof_begin(ctx, PROF_COLUMN);
     launch_column_sweep((const ColumnArgs*)ctx->colargs.ptr, count, ctx->stream);
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
