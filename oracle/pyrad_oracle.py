@@ -362,3 +362,36 @@ def column_transmission(layer_trans, layer_T, xaxis, surface_T):
     for tr, T in zip(layer_trans, layer_T):
         I = transmission(tr, I, planckWavenumber(xaxis, T))
     return I
+
+
+def cross_section_at_points(lines, T, P, conc, molmass, q_T, q296, grid, points):
+    """Work-grid cross section at a few selected grid indices only (full-size parity checks):
+    for each point j the lines with |j - index| <= W-2 contribute rightCurve[|j - index|] * intensity
+    exactly as cls:392-400 deposits them (same profile sample x = |dx| * res, cls:377), summed in
+    line order."""
+    res = grid["resolution"]
+    W = grid["W"]
+    H = max(W - 2, 0)
+    lq = line_quantities(lines, T, P, conc, molmass, grid["range_min"], res)
+    inten = intensityFactor(lines["sw"], lq["broadened"], T, lines["elower"], q_T, q296)
+    out = np.zeros(len(points))
+    idx = lq["index"]
+    for n, j in enumerate(points):
+        sel = np.nonzero(np.abs(idx - j) <= H)[0]
+        if W < 1 or sel.size == 0:
+            continue
+        dx = np.abs(idx[sel] - j)
+        x = 0 + dx * res                                    # element dx of np.arange(0, dfc, res)
+        reg = lq["regime"][sel]
+        g, l = lq["ghw"][sel], lq["lhw"][sel]
+        f, eta = pseudoVoigtParams(g, l)
+        with np.errstate(under="ignore"):
+            curve = np.where(reg == 0, gaussianLineShape(g, x),
+                             np.where(reg == 1, lorentzLineShape(l, x),
+                                      eta * lorentzLineShape(f / 2, x) + (1 - eta) * gaussianLineShape(f / 2, x)))
+        terms = curve * inten[sel]
+        s = 0.0
+        for t in terms:                                      # line order, like the reference's loop
+            s = s + t
+        out[n] = s
+    return out

@@ -638,10 +638,9 @@ class Molecule(_OpticalMixin, list):
 
     @property
     def lineSurvey(self):
-        tempAxis = np.zeros(int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION))
-        for isotope in self:
-            tempAxis += isotope.lineSurvey
-        return tempAxis
+        """cls:589-594: sum of the isotopologue surveys (device sum, list order)."""
+        return _sum_host_arrays([isotope.lineSurvey for isotope in self],
+                                int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION))
 
     P = property(lambda self: self.layer.P)
     T = property(lambda self: self.layer.T)
@@ -652,6 +651,19 @@ class Molecule(_OpticalMixin, list):
     distanceFromCenter = property(lambda self: self.layer.distanceFromCenter)
     yAxis = property(lambda self: np.copy(self.layer.yAxis))
     xAxis = property(lambda self: np.copy(self.layer.xAxis))
+
+
+def _sum_host_arrays(arrays, n):
+    """zeros(n) + a0 + a1 + ... for host arrays, summed by the device kernel."""
+    ctx = _ctx()
+    tmp = []
+    try:
+        for a in arrays:
+            tmp.append(ctx.buffer(max(n, 1)).upload(np.ascontiguousarray(a, dtype=np.float64)))
+        return _sum_on_device(ctx, tmp, n)
+    finally:
+        for b in tmp:
+            b.free()
 
 
 def _sum_on_device(ctx, bufs, n):
@@ -748,10 +760,9 @@ class Layer(_OpticalMixin, list):
 
     @property
     def lineSurvey(self):
-        tempAxis = np.zeros(int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION))
-        for molecule in self:
-            tempAxis += molecule.lineSurvey
-        return tempAxis
+        """cls:691-696: sum of the molecule surveys (device sum, list order)."""
+        return _sum_host_arrays([molecule.lineSurvey for molecule in self],
+                                int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION))
 
     @property
     def yAxis(self):

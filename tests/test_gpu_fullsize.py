@@ -1,0 +1,118 @@
+"""GPU: parity and size-independent properties at BASELINE.json's full sizes (C2: 4e5 grid points,
+65,536 lines, W = 5000; C3: 2.4e6 points, 3 x 131,072 lines), where the oracle cannot evaluate the
+whole spectrum in seconds: sampled-point parity against the oracle, linearity, superposition,
+non-negativity, variant agreement, bit-identical reruns."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from pyrad_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from pyrad_amd import _native as nat
+    c = nat.Context(0)
+    yield c
+    c.close()
+
+
+def accumulate(ctx, lines, species, conc, cfg, variant=None):
+    from pyrad_amd import _native as nat, engine
+    g = engine.layer_grid(cfg["P"], cfg["range_min"], cfg["range_max"], cfg["base_resolution"], cfg["dynamic_resolution"])
+    sel = engine.select_window(lines, g["eff_min"], g["eff_max"])
+    sp = synthetic.SPECIES[species]
+    iso = nat.IsoParams(float(cfg["T"]), float(cfg["P"]), float(conc), sp["molmass"],
+                        synthetic.q_value(species, cfg["T"]), sp["q296"])
+    if variant is not None:
+        ctx.set_option("accum_variant", variant)
+    try:
+        xs, counts = ctx.xsec_accumulate(sel, iso, engine.native_grid(g))
+    finally:
+        ctx.set_option("accum_variant", 3)
+    return xs, counts, g, sel
+
+
+def sample_points(g, sel, n=48, seed=0):
+    """grid indices at line centres, between lines, at both ends and at random places"""
+    rng = np.random.default_rng(seed)
+    idx = ((sel["nu"] - g["range_min"]) / g["resolution"]).astype(np.int64)
+    inside = idx[(idx >= 0) & (idx < g["n_work"])]
+    pts = np.concatenate([[0, 1, g["n_work"] - 2, g["n_work"] - 1], rng.choice(inside, n // 2),
+                          rng.integers(0, g["n_work"], n // 2)])
+    return np.unique(pts)
+
+
+def test_c2_full_size_sampled_parity_and_properties(ctx):
+    from oracle import pyrad_oracle as orc
+    cfg = synthetic.config_c2()
+    lines = cfg["molecules"][0]["lines"]
+    xs, counts, g, sel = accumulate(ctx, lines, "co2", 4e-4, cfg)
+    assert xs.shape == (400000,) and g["W"] == 5000 and sum(counts) == len(sel["nu"]) == 65536
+    assert counts[1] > 10000 and counts[2] > 10000          # Lorentz and pseudo-Voigt regimes both live
+    sp = synthetic.SPECIES["co2"]
+    pts = sample_points(g, sel)
+    ref = orc.cross_section_at_points(sel, cfg["T"], cfg["P"], 4e-4, sp["molmass"], synthetic.q_value("co2", cfg["T"]),
+                                      sp["q296"], g, pts)
+    assert rel_err(xs[pts], ref) <= RTOL
+    assert np.all(xs > 0) and np.all(np.isfinite(xs))
+    # bit-identical rerun; every kernel variant agrees to rounding
+    xs2, _, _, _ = accumulate(ctx, lines, "co2", 4e-4, cfg)
+    assert np.array_equal(xs, xs2)
+    for v in (2, 4):
+        xv, _, _, _ = accumulate(ctx, lines, "co2", 4e-4, cfg, variant=v)
+        assert rel_err(xv, xs) <= 1e-12
+    # linearity in the line intensity: a power-of-two scale is exact in fp64
+    scaled = dict(lines, sw=lines["sw"] * 4.0)
+    x4, _, _, _ = accumulate(ctx, scaled, "co2", 4e-4, cfg)
+    assert np.array_equal(x4, xs * 4.0)
+    # superposition: odd + even lines = all lines
+    odd = {k: v[1::2] for k, v in lines.items()}
+    even = {k: v[0::2] for k, v in lines.items()}
+    xo, _, _, _ = accumulate(ctx, odd, "co2", 4e-4, cfg)
+    xe, _, _, _ = accumulate(ctx, even, "co2", 4e-4, cfg)
+    assert rel_err(xo + xe, xs) <= 1e-12
+
+
+def test_c3_full_size_layer_sampled_parity(ctx):
+    """Three molecules, 2.4e6 points: cross sections at sampled points and the fused sweep there."""
+    from oracle import pyrad_oracle as orc
+    from pyrad_amd import engine
+    from pyrad_amd.model import concentration_from_kwargs
+    cfg = synthetic.config_c3()
+    mols = []
+    for mol in cfg["molecules"]:
+        sp = synthetic.SPECIES[mol["species"]]
+        mols.append(dict(conc=concentration_from_kwargs(**mol["conc"]),
+                         isotopologues=[dict(lines=mol["lines"], molmass=sp["molmass"],
+                                             q_T=synthetic.q_value(mol["species"], cfg["T"]), q296=sp["q296"])]))
+    L = engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"], mols,
+                             cfg["base_resolution"], cfg["dynamic_resolution"], keep_host_lines=True)
+    L.enqueue(surface_T=288)
+    r = L.results()
+    g = L.g
+    assert L.n == 2400000 and L.evals > 3.8e9
+    rng = np.random.default_rng(1)
+    pts = np.unique(np.concatenate([[0, L.n - 1], rng.integers(0, L.n, 30)]))
+    k_ref = np.zeros(len(pts))
+    for i, mol in enumerate(cfg["molecules"]):
+        sp = synthetic.SPECIES[mol["species"]]
+        sel = L._keep[i]
+        xs_ref = orc.cross_section_at_points(sel, cfg["T"], cfg["P"], mols[i]["conc"], sp["molmass"],
+                                             synthetic.q_value(mol["species"], cfg["T"]), sp["q296"], g, pts)
+        assert rel_err(L.xsec_host(i)[pts], xs_ref) <= RTOL, mol["species"]
+        k_ref = k_ref + orc.abs_coef(xs_ref, mols[i]["conc"], cfg["P"], cfg["T"])
+    assert rel_err(r["abs_coef"][pts], k_ref) <= RTOL
+    tr = orc.transmittance(k_ref, cfg["depth"])
+    assert rel_err(r["transmittance"][pts], tr) <= RTOL
+    xa = orc.x_axis(cfg["range_min"], cfg["range_max"], cfg["base_resolution"])[pts]
+    spec = orc.transmission(tr, orc.planckWavenumber(xa, 288), orc.planckWavenumber(xa, cfg["T"]))
+    assert rel_err(r["transmission"][pts], spec) <= RTOL
+    # idempotence of the step: enqueueing again reproduces every array bit for bit
+    L.enqueue(surface_T=288)
+    r2 = L.results()
+    assert all(np.array_equal(r[k], r2[k]) for k in r)
+    L.free()
