@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--line-split", type=int, default=None)
     ap.add_argument("--tile-order", type=int, default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
+    ap.add_argument("--scale", type=int, default=1, help="experiment: widen the per-GPU range and line count by this factor")
+    ap.add_argument("--lines", type=int, default=None, help="experiment: C2 with this many lines instead of 65,536")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather", default="abs_coef", choices=["abs_coef", "all"])
@@ -188,7 +190,13 @@ def main():
             uid = rdzv.broadcast("rccl_unique_id", nat.Comm.unique_id() if rank == 0 else None)
             comm = nat.Comm(ctx, uid, world, rank)
 
-    cfg, desc = build_workload(args.workload, world)
+    cfg, desc = build_workload(args.workload, world * args.scale)
+    if args.scale != 1:
+        desc += " [--scale %d: not a BASELINE configuration]" % args.scale
+    if args.lines is not None and args.workload == "C2":
+        from pyrad_amd import synthetic as _syn
+        cfg = _syn.config_c2(n_lines=args.lines, range_min=500, range_max=500 + 400 * world * args.scale, seed=2)
+        desc += " [--lines %d: not a BASELINE configuration]" % args.lines
     t_setup = time.perf_counter()
     # With a communicator the steps are software-pipelined over two buffer sets: the all-gather of
     # step k (communicator stream) overlaps the kernels of step k+1 (context stream, other set).
@@ -299,7 +307,7 @@ def main():
         if is_column:
             balg_acc = balg_acc / max(n_acc // max(args.steps, 1), 1)     # K2 is launched once per window group
         t_sw = (ms_sw / max(n_sw, 1)) * 1e-3
-        pmc = load_pmc_traffic()
+        pmc = load_pmc_traffic(args.workload if (args.scale == 1 and args.lines is None and world == 1) else None)
         result = {
             "metric": "line*gridpoint evals/sec (whole job)", "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -349,16 +357,18 @@ def main():
         print(json.dumps(result))
 
 
-def load_pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json,
-    produced by profiles/collect.sh on the GPU box; FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950).  Missing file -> traffic null."""
+def load_pmc_traffic(workload):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this workload
+    (profiles/pmc_traffic.json, produced by profiles/collect.sh + summarize.py on the GPU box in
+    separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950).  PMC counters cannot be read inside a timed run, so this is the value measured
+    for the same command; no entry for the workload -> traffic null."""
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    if not os.path.isfile(path):
+    if workload is None or not os.path.isfile(path):
         return {}
     try:
         with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch", {})
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch", {})
     except (OSError, ValueError):
         return {}
 

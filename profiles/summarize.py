@@ -77,13 +77,23 @@ def main():
             pmc["kernels"][k]["valu"] = {kk: vv / nl for kk, vv in c.items()}
     with open(os.path.join(here, "%s_%s_pmc.json" % (tag, wl)), "w") as f:
         json.dump(pmc, f, indent=1, sort_keys=True)
-    if wl == "C2":
-        traffic = {}
-        for k, v in pmc["kernels"].items():
-            base = "xsec_accumulate_kernel" if k.startswith("xsec_accumulate") else k
-            traffic[base] = v["hbm_bytes_corrected"]
-        with open(os.path.join(here, "pmc_traffic.json"), "w") as f:
-            json.dump({"source": "%s_%s_pmc.json" % (tag, wl), "hbm_bytes_per_launch": traffic}, f, indent=1, sort_keys=True)
+    # what bench.py reports as roofline.traffic, keyed by workload
+    tpath = os.path.join(here, "pmc_traffic.json")
+    allt = {}
+    if os.path.isfile(tpath):
+        try:
+            allt = json.load(open(tpath))
+        except ValueError:
+            allt = {}
+    if "hbm_bytes_per_launch" in allt:          # old single-workload layout
+        allt = {}
+    traffic = {}
+    for k, v in pmc["kernels"].items():
+        base = "xsec_accumulate_kernel" if k.startswith("xsec_accumulate") else k
+        traffic[base] = v["hbm_bytes_corrected"]
+    allt[wl] = {"source": "%s_%s_pmc.json" % (tag, wl), "hbm_bytes_per_launch": traffic}
+    with open(tpath, "w") as f:
+        json.dump(allt, f, indent=1, sort_keys=True)
     b = os.path.join(out, "bench_%s.json" % wl)
     if os.path.isfile(b) and os.path.getsize(b):
         with open(b) as f, open(os.path.join(here, "%s_%s_bench.json" % (tag, wl)), "w") as g:
