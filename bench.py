@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--line-split", type=int, default=None)
     ap.add_argument("--tile-order", type=int, default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
+    ap.add_argument("--longest-first", type=int, default=None, help="0: positional tile order, 1 (default): longest-first worklist")
     ap.add_argument("--scale", type=int, default=1, help="experiment: widen the per-GPU range and line count by this factor")
     ap.add_argument("--lines", type=int, default=None, help="experiment: C2 with this many lines instead of 65,536")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -180,6 +181,8 @@ def main():
         ctx.set_option("accum_tile_order", args.tile_order)
     if args.blocks_per_cu is not None:
         ctx.set_option("accum_blocks_per_cu", args.blocks_per_cu)
+    if args.longest_first is not None:
+        ctx.set_option("accum_longest_first", args.longest_first)
 
     comm = None
     rdzv = None

@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpyrad_hip.so")
+LIB_PATH = os.environ.get("PYRAD_HIP_LIB") or os.path.join(_HERE, "lib", "libpyrad_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 LBL_OK = 0

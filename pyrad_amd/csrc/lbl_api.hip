@@ -57,6 +57,11 @@ struct lbl_ctx {
     int accum_R = 0;         // points per lane, 0 = choose per launch
     int accum_LS = 0;        // waves sharing one span of points (line split), 0 = choose per launch
     int bal_workers[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident wavefronts of the balanced kernel per R (cached)
+    // schedule cache: (job, tile) lists sorted longest first, per launch group
+    struct Schedule { std::vector<uint64_t> key; int2* d_list; int total; };
+    std::vector<Schedule> schedules;
+    uint64_t lines_serial = 0;
+    int lpt = 1;             // 1: longest-first worklist (default); 0: positional tile order
     int tile_order = 1;      // 1: natural order (default; measured 8 % faster on the clustered C2 grid:
                              // all CUs work through one region together); 0: each XCD gets a contiguous run
     int live_objects = 0;
@@ -76,6 +81,8 @@ struct lbl_lines {
     lbl_ctx* ctx;
     double* d;        // 7 arrays of n: nu, sw, elower, gamma_air, gamma_self, n_air, delta_air
     int64_t n;
+    std::vector<double> host_nu;   // for scheduling only: longest-first tile order (never used for results)
+    uint64_t serial;               // identity for the schedule cache
     const double* field(int k) const { return d + (size_t)k * (size_t)n; }
 };
 
@@ -217,6 +224,7 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& v : ctx->ev_rec) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (auto& sc : ctx->schedules) if (sc.d_list) (void)hipFree(sc.d_list);
     DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->colargs, &ctx->counts, &ctx->bal, &ctx->red};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
@@ -297,11 +305,14 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) {
         if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_points_per_lane must be 0, 1, 2, 4 or 8");
         ctx->accum_R = value;
+    } else if (!strcmp(key, "accum_longest_first")) {
+        ctx->lpt = value ? 1 : 0;
     } else if (!strcmp(key, "accum_blocks_per_cu")) {
         if (value < 0 || value > 8) return fail(ctx, LBL_ERR_BAD_ARG, "accum_blocks_per_cu must be 0 (auto) .. 8");
         for (int r = 0; r < 9; ++r) ctx->bal_workers[r] = value ? (ctx->n_cu > 0 ? ctx->n_cu : 256) * value * 4 : 0;
     } else if (!strcmp(key, "accum_tile_order")) {
-        ctx->tile_order = value ? 1 : 0;
+        if (value < 0 || value > 2) return fail(ctx, LBL_ERR_BAD_ARG, "accum_tile_order must be 0, 1 or 2");
+        ctx->tile_order = value;
     } else if (!strcmp(key, "accum_line_split")) {
         if (!(value == 0 || value == 1 || value == 2 || value == 4))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_line_split must be 0, 1, 2 or 4");
@@ -414,8 +425,10 @@ extern "C" int lbl_lines_create(lbl_ctx* ctx, const double* nu, const double* sw
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, LBL_ERR_HIP, "line upload: %s", hipGetErrorString(e)); }
-    lbl_lines* L = new (std::nothrow) lbl_lines{ctx, d, n_lines};
+    lbl_lines* L = new (std::nothrow) lbl_lines{ctx, d, n_lines, {}, 0};
     if (!L) { (void)hipFree(d); return fail(ctx, LBL_ERR_OOM, "host allocation failed"); }
+    L->host_nu.assign(nu, nu + n_lines);
+    L->serial = ++ctx->lines_serial;
     ctx->live_objects++;
     *out = L;
     return LBL_OK;
@@ -471,6 +484,65 @@ static void choose_shape(const lbl_ctx* ctx, long long total_points, long long t
         LS = lines_per_span >= 1024.0 ? 4 : lines_per_span >= 256.0 ? 2 : 1;
     }
     *R_out = R; *LS_out = LS;
+}
+
+// Longest-first schedule of one launch group.  Workgroups differ 7x in length (line density), and
+// in positional order a dense region that happens to start late is the kernel's tail (C2: half of
+// the CUs idle for the last third of the kernel).  The host knows every line's centre index (same
+// IEEE expression as K1) and counts the lines each tile will walk; the sorted (job, tile) list
+// depends only on the line lists and the grid, so it is built once and reused across calls
+// (temperature, pressure-independent).  It steers the dispatch order only, never a result.
+static const int2* group_schedule(lbl_ctx* ctx, const std::vector<int>& jobs_in_group, lbl_lines* const* lines,
+                                  const lbl_grid* grid, int R, int LS, long long tile_pts, int* total_out) {
+    std::vector<uint64_t> key;
+    key.push_back((uint64_t)R << 32 | (uint64_t)LS);
+    for (int j : jobs_in_group) {
+        long long sf, sc;
+        shard_range(grid[j], &sf, &sc);
+        uint64_t bits_a, bits_b;
+        memcpy(&bits_a, &grid[j].range_min, 8); memcpy(&bits_b, &grid[j].resolution, 8);
+        key.push_back(lines[j]->serial); key.push_back((uint64_t)lines[j]->n);
+        key.push_back(bits_a); key.push_back(bits_b);
+        key.push_back((uint64_t)sf); key.push_back((uint64_t)sc); key.push_back((uint64_t)grid[j].window);
+    }
+    for (auto& sc : ctx->schedules)
+        if (sc.key == key) { *total_out = sc.total; return sc.d_list; }
+    struct Item { int count, job, tile; };
+    std::vector<Item> items;
+    std::vector<long long> idx;
+    for (size_t k = 0; k < jobs_in_group.size(); ++k) {
+        const int j = jobs_in_group[k];
+        const lbl_lines* L = lines[j];
+        idx.resize((size_t)L->n);
+        for (int64_t i = 0; i < L->n; ++i) idx[i] = (long long)((L->host_nu[i] - grid[j].range_min) / grid[j].resolution);
+        long long sf, sc;
+        shard_range(grid[j], &sf, &sc);
+        const long long H = std::max<long long>(grid[j].window - 2, 0);
+        const long long n_tiles = (sc + tile_pts - 1) / tile_pts;
+        for (long long t = 0; t < n_tiles; ++t) {
+            const long long lo = sf + t * tile_pts, hi = std::min(lo + tile_pts - 1, sf + sc - 1);
+            const auto a = std::lower_bound(idx.begin(), idx.end(), lo - H);
+            const auto b = std::lower_bound(idx.begin(), idx.end(), hi + H + 1);
+            items.push_back({(int)(b - a), (int)k, (int)t});
+        }
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.count > y.count; });
+    std::vector<int2> host(items.size());
+    for (size_t i = 0; i < items.size(); ++i) { host[i].x = items[i].job; host[i].y = items[i].tile; }
+    int2* d_list = nullptr;
+    if (hipMalloc((void**)&d_list, std::max<size_t>(host.size(), 1) * sizeof(int2)) != hipSuccess) return nullptr;
+    if (!host.empty() && hipMemcpy(d_list, host.data(), host.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d_list);
+        return nullptr;
+    }
+    if (ctx->schedules.size() >= 16) {                    // small cache: drop the oldest entry
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->schedules.front().d_list);
+        ctx->schedules.erase(ctx->schedules.begin());
+    }
+    ctx->schedules.push_back({key, d_list, (int)host.size()});
+    *total_out = (int)host.size();
+    return d_list;
 }
 
 struct DbgOut { long long* index; double* lhw; double* ghw; double* inten; int32_t* regime; };
@@ -631,7 +703,15 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             launch_accumulate_balanced(da + g.first, g.count, (int)S, g.R, group_workers[gi], spans, cnts, prefix, slab,
                                        ctx->stream);
         } else {
-            launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, ctx->accum_variant, ctx->stream);
+            const int2* worklist = nullptr;
+            int total_tiles = 0;
+            if (ctx->accum_variant == 3 && ctx->lpt) {
+                std::vector<int> members(order.begin() + g.first, order.begin() + g.first + g.count);
+                worklist = group_schedule(ctx, members, lines, grid, g.R, g.LS,
+                                          accumulate_tile_points(g.R, g.LS, ctx->accum_variant), &total_tiles);
+            }
+            launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, ctx->accum_variant, worklist, total_tiles,
+                              ctx->stream);
         }
         prof_end(ctx, PROF_ACCUM, ev);
         HIP_TRY(ctx, hipGetLastError());
@@ -695,7 +775,10 @@ extern "C" int lbl_xsec_accumulate(lbl_ctx* ctx, const double* nu, const double*
     rc = lbl_lines_create(ctx, nu, sw, elower, gamma_air, gamma_self, n_air, delta_air, n_lines, &L);
     if (rc) return rc;
     rc = lbl_buffer_create(ctx, grid->n_base, &B);
+    const int keep_lpt = ctx->lpt;
+    ctx->lpt = 0;            // a one-shot line list is never seen again: no point in building (and caching) a schedule
     if (!rc) rc = lbl_xsec_accumulate_dev(ctx, 1, &L, iso, grid, &B);
+    ctx->lpt = keep_lpt;
     if (!rc) rc = lbl_buffer_download(B, xsec_out, grid->n_base, 0);
     if (!rc && regime_counts) rc = lbl_last_regime_counts(ctx, 1, regime_counts);
     std::string keep = ctx->err;

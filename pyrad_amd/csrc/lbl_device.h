@@ -108,7 +108,8 @@ struct ColumnArgs {
 
 // ---- launchers (lbl_kernels.hip) ---------------------------------------------------------
 void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStream_t s);
-void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant, hipStream_t s);
+void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
+                       const int2* worklist, int total_tiles, hipStream_t s);
 int accumulate_tile_points(int R, int LS, int variant);
 // balanced variant (4): span ranges -> prefix sum -> equal shares of (span, line) pairs per wave -> slab reduce
 int balanced_workers(int R, int n_cu);

@@ -358,7 +358,18 @@ __device__ __forceinline__ void wave_line_ranges(const int32_t* __restrict__ cid
 // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so each XCD gets a
 // contiguous run of tiles: neighbouring tiles read almost the same line records.
 __device__ __forceinline__ int xcd_tile(int b, int n_tiles, int natural = 0) {
-    if (natural) return b < n_tiles ? b : -1;
+    if (natural == 1) return b < n_tiles ? b : -1;
+    if (natural >= 2) {
+        // low-discrepancy order: step through the tiles with a stride near n_tiles/phi (made coprime
+        // to n_tiles), so that at any time the resident workgroups sample the whole grid evenly and
+        // the last ones to start are a random draw instead of one dense region
+        if (b >= n_tiles) return -1;
+        int stride = (int)(0.6180339887498949 * (double)n_tiles) | 1;
+        auto gcd = [](int a, int c) { while (c) { const int t = a % c; a = c; c = t; } return a; };
+        while (stride > 1 && gcd(stride, n_tiles) != 1) stride += 2;
+        if (stride >= n_tiles) stride = 1;
+        return (int)(((long long)b * stride) % n_tiles);
+    }
     const int chunk = (n_tiles + 7) >> 3;
     const int slot = b >> 3;
     if (slot >= chunk) return -1;
@@ -521,14 +532,18 @@ __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, cons
     }
 }
 
-// Lines [mA, mD) of one job against the 64*R points of a wave (wlo..whi; x0 = this lane's first
-// point).  Lines below iB or from iC on end inside the wave's span and are masked per point.
+// Lines of one job against the 64*R points of a wave (wlo..whi; x0 = this lane's first point):
+// the 64-line chunks [c0, c0+64) for c0 = mA, mA+stride, ... below mD.  stride = 64 walks a
+// contiguous range; stride = 64*LS deals the chunks of a span round-robin to the LS waves that
+// share it, so each wave gets its share of the expensive lines near the span (Gaussian passes):
+// with contiguous quarters the two middle waves did ~1.8x the work of the outer two.
+// Lines below iB or from iC on end inside the wave's span and are masked per point.
 // The wave streams the records in chunks of 64 through its own LDS (lh: hot halves, lc: cold
 // halves), with the next chunk's loads in flight while the current one is consumed.
 template <int R>
 __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRec* cold, int mA, int mD, int iB, int iC,
                                                  int wlo, int whi, double x0, double Hf, double* lh, double* lc, int lane,
-                                                 WaveAcc<R>& S) {
+                                                 WaveAcc<R>& S, int stride = 64) {
     // global address space made explicit: a flat load would also count on lgkmcnt and every
     // LDS wait would then drain the prefetch of the next chunk
     typedef double v2f64 __attribute__((ext_vector_type(2)));
@@ -541,7 +556,7 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
         const long long r = (long long)(mA + lane) * 2;
         h0 = gh[r]; h1 = gh[r + 1];
     }
-    for (int c0 = mA; c0 < mD; c0 += 64) {
+    for (int c0 = mA; c0 < mD; c0 += stride) {
         const int c1 = min(c0 + 64, mD);
         __builtin_amdgcn_wave_barrier();
         // per-record branch decisions for the whole chunk, one lane per record
@@ -566,8 +581,8 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
             const long long r = (long long)(c0 + lane) * 2;
             c0v = gc[r]; c1v = gc[r + 1];
         }
-        if (c1 + lane < mD) {
-            const long long r = (long long)(c1 + lane) * 2;
+        if (c0 + stride + lane < mD && lane < 64) {
+            const long long r = (long long)(c0 + stride + lane) * 2;
             h0 = gh[r]; h1 = gh[r + 1];
         }
         // the three classes of lines inside this chunk, as offsets into the chunk
@@ -596,15 +611,24 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
 __device__ __forceinline__ int span_slot(int o) { return o + (o >> 4); }
 
 template <int R, int LS>
-__global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs) {
+__global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs,
+                                                                                   const int2* __restrict__ worklist) {
     constexpr int PG = 4 / LS;                       // point groups (64*R points each) per workgroup
     // per wave: hot records [0,256), cold records [256,512); after the line loop the same words
     // hold the wave's 64*R sums in point order (+ padding) for the coalesced store
     constexpr int STAGE = (68 * R > 512) ? 68 * R : 512;
     __shared__ double s_stage[4][STAGE];
 
-    const AccumJob& J = jobs[blockIdx.y];
-    const int tile = xcd_tile(blockIdx.x, J.n_tiles, J.pad);
+    // worklist: (job, tile) pairs of the whole launch sorted by decreasing line count (longest
+    // first), built once per (line lists, grid) on the host; without it blockIdx.y is the job
+    int job = blockIdx.y, tile;
+    if (worklist) {
+        const int2 wk = worklist[blockIdx.x];
+        job = wk.x; tile = wk.y;
+    } else {
+        tile = xcd_tile(blockIdx.x, jobs[job].n_tiles, jobs[job].pad);
+    }
+    const AccumJob& J = jobs[job];
     const int lane = threadIdx.x & 63;
     const int wave = uniform_i32(threadIdx.x >> 6);
     const int grp = wave / LS, part = wave % LS;
@@ -626,10 +650,8 @@ __global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_ker
     if (active) {
         int iA, iB, iC, iD;
         wave_line_ranges(J.cidx, J.n_lines, wlo, whi, H, lane, iA, iB, iC, iD);
-        // this wave's share of the span's lines
-        const long long nl = (long long)iD - iA;
-        const int mA = iA + (int)(nl * part / LS), mD = iA + (int)(nl * (part + 1) / LS);
-        accumulate_lines<R>(J.hot, J.cold, mA, mD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S);
+        // this wave's share of the span's lines: every LS-th chunk of 64, starting at chunk `part`
+        accumulate_lines<R>(J.hot, J.cold, iA + part * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
         S.flush();
     }
 
@@ -1058,12 +1080,17 @@ static void launch_accum_scalar(const AccumJob* d_jobs, int n_jobs, int max_tile
 }
 
 template <int R>
-static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, int LS, hipStream_t s) {
+static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, int LS, const int2* worklist,
+                             int total_tiles, hipStream_t s) {
     dim3 grid(((max_tiles + 7) / 8) * 8, n_jobs);
+    if (worklist) {
+        if (total_tiles <= 0) return;
+        grid = dim3(total_tiles, 1);
+    }
     switch (LS) {
-        case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4>), grid, dim3(256), 0, s, d_jobs); break;
-        case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2>), grid, dim3(256), 0, s, d_jobs); break;
-        default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1>), grid, dim3(256), 0, s, d_jobs); break;
+        case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4>), grid, dim3(256), 0, s, d_jobs, worklist); break;
+        case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2>), grid, dim3(256), 0, s, d_jobs, worklist); break;
+        default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1>), grid, dim3(256), 0, s, d_jobs, worklist); break;
     }
 }
 
@@ -1072,14 +1099,15 @@ int accumulate_tile_points(int R, int LS, int variant) {
     return variant >= 3 ? 64 * R * (4 / LS) : 256 * R;
 }
 
-void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant, hipStream_t s) {
+void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
+                       const int2* worklist, int total_tiles, hipStream_t s) {
     if (n_jobs <= 0 || max_tiles <= 0) return;
     if (variant >= 3) {
         switch (R) {
-            case 1: launch_accum_lds<1>(d_jobs, n_jobs, max_tiles, LS, s); break;
-            case 2: launch_accum_lds<2>(d_jobs, n_jobs, max_tiles, LS, s); break;
-            case 4: launch_accum_lds<4>(d_jobs, n_jobs, max_tiles, LS, s); break;
-            default: launch_accum_lds<8>(d_jobs, n_jobs, max_tiles, LS, s); break;
+            case 1: launch_accum_lds<1>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 2: launch_accum_lds<2>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 4: launch_accum_lds<4>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            default: launch_accum_lds<8>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
         }
         return;
     }
