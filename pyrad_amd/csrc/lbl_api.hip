@@ -455,8 +455,7 @@ extern "C" int lbl_lines_count(const lbl_lines* lines, int64_t* n) {
 // ----------------------------------------------------------------------------------------
 // Launch shape of the LDS variant, from measurements on MI355X (scripts/sweep*.sh):
 //   R  points per lane: 4 is the sweet spot (R = 8 needs 136 VGPRs: spills or a slower loop);
-//      drop to 2 when the grid has fewer than 8 spans per CU (finer tail), and never more
-//      points per wave than a line's support is wide.
+//      never more points per wave than a line's support is wide.
 //   LS waves sharing one span and splitting its lines: 4 when a span sees >= 1024 lines,
 //      2 from 256 (the four waves of a workgroup then finish together and workgroups are
 //      short, which balances the clustered line density), else 1.
@@ -471,7 +470,9 @@ static void choose_shape(const lbl_ctx* ctx, long long total_points, long long t
             R = 4;                       // work is split by lines, not spans: no reason to shrink R on small grids
         } else if (lds) {
             R = 4;
-            while (R > 2 && total_points / (64LL * R) < 8 * cus) R >>= 1;
+            // positional order only: finer spans shorten the tail on small grids; the longest-first
+            // schedule removes that tail and then the lower instruction count of R = 4 wins
+            while (!ctx->lpt && R > 2 && total_points / (64LL * R) < 8 * cus) R >>= 1;
         } else {
             R = 8;
             while (R > 1 && total_points / (64LL * R) < 12 * cus) R >>= 1;
