@@ -314,8 +314,8 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) {
         if (value < 0 || value > 2) return fail(ctx, LBL_ERR_BAD_ARG, "accum_tile_order must be 0, 1 or 2");
         ctx->tile_order = value;
     } else if (!strcmp(key, "accum_line_split")) {
-        if (!(value == 0 || value == 1 || value == 2 || value == 4))
-            return fail(ctx, LBL_ERR_BAD_ARG, "accum_line_split must be 0, 1, 2 or 4");
+        if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
+            return fail(ctx, LBL_ERR_BAD_ARG, "accum_line_split must be 0, 1, 2, 4 or 8");
         ctx->accum_LS = value;
     } else {
         return fail(ctx, LBL_ERR_BAD_ARG, "unknown option '%s'", key);

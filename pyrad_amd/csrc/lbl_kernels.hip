@@ -611,13 +611,14 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
 __device__ __forceinline__ int span_slot(int o) { return o + (o >> 4); }
 
 template <int R, int LS>
-__global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs,
-                                                                                   const int2* __restrict__ worklist) {
-    constexpr int PG = 4 / LS;                       // point groups (64*R points each) per workgroup
+__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), ((R >= 8 && LS <= 4) ? 4 : 1))
+void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* __restrict__ worklist) {
+    constexpr int NW = LS > 4 ? LS : 4;              // wavefronts per workgroup (LS = 8: 512 threads)
+    constexpr int PG = NW / LS;                      // point groups (64*R points each) per workgroup
     // per wave: hot records [0,256), cold records [256,512); after the line loop the same words
     // hold the wave's 64*R sums in point order (+ padding) for the coalesced store
     constexpr int STAGE = (68 * R > 512) ? 68 * R : 512;
-    __shared__ double s_stage[4][STAGE];
+    __shared__ double s_stage[NW][STAGE];
 
     // worklist: (job, tile) pairs of the whole launch sorted by decreasing line count (longest
     // first), built once per (line lists, grid) on the host; without it blockIdx.y is the job
@@ -1088,6 +1089,7 @@ static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, 
         grid = dim3(total_tiles, 1);
     }
     switch (LS) {
+        case 8: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 8>), grid, dim3(512), 0, s, d_jobs, worklist); break;
         case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4>), grid, dim3(256), 0, s, d_jobs, worklist); break;
         case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2>), grid, dim3(256), 0, s, d_jobs, worklist); break;
         default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1>), grid, dim3(256), 0, s, d_jobs, worklist); break;
@@ -1096,7 +1098,7 @@ static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, 
 
 // grid points one workgroup covers
 int accumulate_tile_points(int R, int LS, int variant) {
-    return variant >= 3 ? 64 * R * (4 / LS) : 256 * R;
+    return variant >= 3 ? 64 * R * ((LS > 4 ? LS : 4) / LS) : 256 * R;
 }
 
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
