@@ -45,6 +45,10 @@ struct lbl_ctx {
     void* host_stage = nullptr;   // pinned staging ring for job descriptors
     size_t host_stage_cap = 0;
     size_t host_stage_head = 0;
+    struct DescSlot { std::vector<char> bytes; void* dptr = nullptr; size_t cap = 0; };
+    DescSlot desc_cache[4];
+    int desc_next = 0;
+    std::vector<char> desc_build;
     int last_jobs = 0;
     int last_blocks_per_job = 0;
     std::vector<int> last_job_lines;
@@ -225,6 +229,7 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) {
     for (auto& v : ctx->ev_rec) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto& sc : ctx->schedules) if (sc.d_list) (void)hipFree(sc.d_list);
+    for (auto& e : ctx->desc_cache) if (e.dptr) (void)hipFree(e.dptr);
     DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->colargs, &ctx->counts, &ctx->bal, &ctx->red};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
@@ -580,10 +585,11 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     const int blocks_per_job = (max_lines + 255) / 256;
     const size_t prep_bytes = (size_t)n_jobs * sizeof(PrepJob), acc_bytes = (size_t)n_jobs * sizeof(AccumJob);
     const size_t cnt_bytes = (size_t)n_jobs * std::max(blocks_per_job, 1) * 3 * sizeof(unsigned int);
-    if ((rc = arena_reserve(ctx, ctx->jobs, prep_bytes + acc_bytes))) return rc;
     if ((rc = arena_reserve(ctx, ctx->counts, cnt_bytes))) return rc;
-    void* stage = nullptr;
-    if ((rc = stage_alloc(ctx, prep_bytes + acc_bytes, &stage))) return rc;
+    // descriptors are built in pageable host memory first: a batch that repeats (the usual case:
+    // same layer, step after step) finds its descriptor block already on the device and skips the copy
+    ctx->desc_build.assign(prep_bytes + acc_bytes, 0);
+    void* stage = ctx->desc_build.data();
     unsigned int* d_counts = (unsigned int*)ctx->counts.ptr;
 
     // Jobs of one batch can have very different windows (a column: W = 5000 at the surface,
@@ -679,9 +685,30 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         bal_off[groups.size()] = tot;
         if ((rc = arena_reserve(ctx, ctx->bal, std::max<size_t>(tot, 256)))) return rc;
     }
-    PrepJob* dp = (PrepJob*)ctx->jobs.ptr;
-    AccumJob* da = (AccumJob*)((char*)ctx->jobs.ptr + prep_bytes);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->jobs.ptr, stage, prep_bytes + acc_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // device copy of the descriptors: reuse an identical block if one is cached (4 slots, round robin)
+    char* d_desc = nullptr;
+    for (auto& e : ctx->desc_cache)
+        if (e.dptr && e.bytes == ctx->desc_build) { d_desc = (char*)e.dptr; break; }
+    if (!d_desc) {
+        auto& e = ctx->desc_cache[ctx->desc_next];
+        ctx->desc_next = (ctx->desc_next + 1) % 4;
+        if (e.cap < ctx->desc_build.size()) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (e.dptr) HIP_TRY(ctx, hipFree(e.dptr));
+            e.dptr = nullptr; e.cap = 0;
+            const size_t want = ctx->desc_build.size() + ctx->desc_build.size() / 4 + 1024;
+            HIP_TRY(ctx, hipMalloc(&e.dptr, want));
+            e.cap = want;
+        }
+        void* pinned = nullptr;
+        if ((rc = stage_alloc(ctx, ctx->desc_build.size(), &pinned))) return rc;
+        memcpy(pinned, ctx->desc_build.data(), ctx->desc_build.size());
+        HIP_TRY(ctx, hipMemcpyAsync(e.dptr, pinned, ctx->desc_build.size(), hipMemcpyHostToDevice, ctx->stream));
+        e.bytes = ctx->desc_build;
+        d_desc = (char*)e.dptr;
+    }
+    PrepJob* dp = (PrepJob*)d_desc;
+    AccumJob* da = (AccumJob*)(d_desc + prep_bytes);
     ctx->last_blocks_per_job = blocks_per_job;
     ctx->last_job_lines.assign(n_jobs, 0);
     for (int j = 0; j < n_jobs; ++j) ctx->last_job_lines[j] = (int)lines[j]->n;
