@@ -95,14 +95,19 @@ int lbl_ctx_stream(lbl_ctx* ctx, void** stream);
 /* Name of the device ("gfx950..."), CU count, HBM bytes. */
 int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 
-/* Tuning knobs for A/B parity and benchmarking (no reference counterpart):
+/* Tuning knobs for A/B parity runs and benchmarking (no reference counterpart):
  *   "accum_variant"          0 IEEE divide + exp per pair | 1 running fraction | 2 + Gaussian recurrence
  *                            (0-2 fetch line records through the scalar cache) |
  *                            3 (default) = 2 with wave-private LDS staging of the records |
  *                            4 = 3 with a balanced single-round partition of (span, line) pairs
  *   "accum_points_per_lane"  0 (auto) | 1 | 2 | 4 | 8
- *   "accum_line_split"       0 (auto) | 1 | 2 | 4 waves of a workgroup share one span of points
- *                            and split its lines (variant 3 only) */
+ *   "accum_line_split"       0 (auto) | 1 | 2 | 4 | 8 waves of a workgroup share one span of points
+ *                            and split its lines (variant 3 only)
+ *   "accum_longest_first"    1 (default): workgroups are dispatched longest first from a cached
+ *                            (job, tile) worklist | 0: positional order
+ *   "accum_tile_order"       positional order only: 1 (default) natural | 0 one contiguous run of
+ *                            tiles per XCD | 2 golden-ratio stride
+ *   "accum_blocks_per_cu"    variant 4 only: resident workgroups per CU, 0 = ask the runtime */
 int lbl_set_option(lbl_ctx* ctx, const char* key, int value);
 
 /* Kernel timing with HIP events recorded on the context stream around every launch of a

@@ -134,14 +134,6 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-class _Handle:
-    __slots__ = ("ptr", "ctx", "__weakref__")
-
-    def __init__(self, ptr, ctx):
-        self.ptr = ptr
-        self.ctx = ctx
-
-
 class Context:
     """One HIP device + one stream (lbl_ctx).  Not thread-safe."""
 
