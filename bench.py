@@ -140,8 +140,8 @@ class _StdoutToStderr:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--variant", type=int, default=None, help="accumulate kernel variant 0..4 (default: library default 3)")
     ap.add_argument("--points-per-lane", type=int, default=None)

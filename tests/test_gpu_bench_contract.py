@@ -1,0 +1,52 @@
+"""GPU: bench.py honours the driver's contract — one JSON line on stdout with the required
+keys — on the default path, and with the RCCL communicator forced on (one rank, pipelined
+all-gather over two buffer sets)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def run_bench(args, env_extra=None):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines          # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_default_contract():
+    d = run_bench(["--steps", "5", "--warmup", "2", "--cpu-seconds", "1"])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["unit"] == "evals/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 1e11 and d["ms_per_step"] > 0
+    assert abs(d["value"] - d["config"]["evals_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["launches"] == 5
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e5 and "sample" in c
+
+
+def test_forced_single_rank_communicator_pipeline():
+    d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--workload", "C1"], {"PYRAD_FORCE_COMM": "1"})
+    assert d["config"]["allgather"].startswith("overlapped") and d["value"] > 0
+    d2 = run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--workload", "C1", "--no-overlap"],
+                   {"PYRAD_FORCE_COMM": "1"})
+    assert d2["config"]["allgather"] == "in-stream" and d2["kernel_ms_per_step"]["allgather"] > 0
