@@ -395,3 +395,43 @@ def cross_section_at_points(lines, T, P, conc, molmass, q_T, q296, grid, points)
             s = s + t
         out[n] = s
     return out
+
+
+# ----------------------------------------------------------------------------
+# measured cross sections ("xsc" molecules): cls:165-233, cls:466-505
+# ----------------------------------------------------------------------------
+def merge_array(newX, oldX, oldY):
+    """cls:165-233 restated with offsets instead of list building.  Abscissae are compared after
+    Python ``round(x, 2)``; the table is copied index-for-index from the first shared value and
+    its last overlapping sample is left out; ``list.index`` failures (ValueError) and running off
+    the table (IndexError) surface as in the reference."""
+    nx = [round(float(v), 2) for v in np.asarray(newX).tolist()]
+    ox = [round(float(v), 2) for v in np.asarray(oldX).tolist()]
+    y = list(np.asarray(oldY).tolist()) if not isinstance(oldY, list) else oldY
+    if max(nx) < min(ox) or min(nx) > max(ox):
+        return np.zeros(len(nx))
+    starts_before = min(nx) <= min(ox)
+    ends_after = max(nx) >= max(ox)
+    dst0 = nx.index(min(ox)) if starts_before else 0
+    src0 = 0 if starts_before else ox.index(min(nx))
+    src1 = (len(ox) - 1) if ends_after else (src0 + len(nx) - 1)
+    tail = len(nx) - ((dst0 + len(ox) - 1) if ends_after else (len(nx) - 1))
+    body = []
+    for i in range(src0, src1):
+        body.append(y[i])                       # IndexError if the table is too short
+    out = np.zeros(dst0 + len(body) + tail)
+    if body:
+        out[dst0:dst0 + len(body)] = body
+    return out
+
+
+def xsc_layer_state(temp_text, pressure_torr_text):
+    """cls:479-481: the layer temperature (int K) and pressure (mbar) an xsc file imposes."""
+    return int(float(temp_text)), float(pressure_torr_text) / 0.75006
+
+
+def xsc_cross_section(layer_x_axis, range_min, range_max, res, wavenumber, intensity):
+    """cls:492-499: table -> 0.01 cm^-1 axis (np.interp only if the file is coarser) -> layer axis."""
+    axis = np.arange(range_min, range_max, .01)
+    table = np.interp(axis, wavenumber, intensity) if res > .01 else intensity
+    return merge_array(layer_x_axis, axis, table)

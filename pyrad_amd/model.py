@@ -9,8 +9,10 @@ Reference map (cls = pyradClasses.py):
     Line cls:237-263 · Isotope cls:266-442 · Molecule cls:445-642 · Layer cls:645-787 ·
     Atmosphere cls:790-821 · getters cls:32-88 · reset protocol cls:38-58 ·
     converters cls:121-156 · integrateSpectrum cls:26-29 · returnPlot cls:824-839.
-Not carried over (out of scope): measured cross-section ("xsc") molecules,
-the HITRAN download, the curve cache, the interactive menu.
+Measured cross-section ("xsc") molecules (cls:466-505, mergeArray cls:165-233) are host-side
+table handling in the reference and here; their array then feeds the same device sweep.
+Not carried over (out of scope): the HITRAN download, the curve cache, the
+interactive menu.
 """
 from __future__ import annotations
 
@@ -60,7 +62,7 @@ HITRAN_GLOBAL_ISO = {m + 1: {i + 1: int(g) for i, g in enumerate(row.split())}
 
 COLOR_LIST = ['xkcd:white', 'xkcd:bright orange', 'xkcd:seafoam green', 'xkcd:bright blue', 'xkcd:salmon',
               'xkcd:light violet', 'xkcd:green yellow']
-EXOTIC_IDS = {}
+EXOTIC_IDS = _data.EXOTIC_IDS          # cls:1024; filled by data.set_xsc_source
 
 
 # ----------------------------------------------------------------------------------------
@@ -208,6 +210,32 @@ def interpolateArray(hiResXAxis, loResXAxis, loResYValues):
 
 def isBetween(test, minValue, maxValue):
     return minValue <= test <= maxValue
+
+
+def mergeArray(newX, oldX, oldY):
+    """cls:165-233: lay a measured cross section (oldX, oldY) onto the layer axis newX by matching
+    abscissae rounded to 0.01 cm^-1; zeros outside the overlap.  Kept as the reference has it:
+    the last overlapping sample is dropped, positions are matched only at the first overlapping
+    point (the copy is then index-for-index), a start value missing from the rounded axis raises
+    ValueError, and a partial overlap returns an array longer than newX."""
+    as_list = lambda v: v if isinstance(v, list) else v.tolist()
+    oldY = as_list(oldY)
+    nx = [round(x, 2) for x in as_list(newX)]
+    ox = [round(x, 2) for x in as_list(oldX)]
+    n_lo, n_hi, o_lo, o_hi = min(nx), max(nx), min(ox), max(ox)
+    if n_hi < o_lo or n_lo > o_hi:
+        return np.zeros(len(nx))
+    if n_lo <= o_lo:
+        lead, src = nx.index(o_lo), 0
+    else:
+        lead, src = 0, ox.index(n_lo)
+    if n_hi >= o_hi:
+        last_new, src_end = lead + len(ox) - 1, len(ox) - 1
+    else:
+        last_new, src_end = len(nx) - 1, src + len(nx) - 1
+    if src < src_end and src_end > len(oldY):
+        raise IndexError("list index out of range")
+    return np.asarray([0] * lead + oldY[src:max(src_end, src)] + [0] * (len(nx) - last_new))
 
 
 def concentration_from_kwargs(**abundance):
@@ -560,9 +588,10 @@ class Molecule(_OpticalMixin, list):
                 self.setConcentration(abundance[key])
             else:
                 print('Invalid concentration type. Use ppm, ppb, percentage, or concentration.')
+        self._xsc_member = None
         if type(shortNameOrMolNum) is dict:
-            raise NotImplementedError("measured cross-section ('xsc') molecules (cls:466-505) are outside the "
-                                      "hot path this build covers (SURVEY.md §8f rank 4)")
+            self._init_from_xsc(shortNameOrMolNum)
+            return
         self.isotopeDepth = isotopeDepth
         self.crossSection = np.copy(layer.crossSection)
         try:
@@ -582,6 +611,39 @@ class Molecule(_OpticalMixin, list):
         self.progressCrossSection = False
         self.exotic = False
 
+    def _init_from_xsc(self, spec):
+        """cls:466-505: a molecule given as {name: xsc file name or index}.  The file fixes the
+        layer's temperature and pressure (Torr / 0.75006 -> mbar), its table is brought to
+        0.01 cm^-1 if coarser and merged onto the layer axis; the molecule holds no isotopologues
+        and its cross section is never invalidated (cls:40)."""
+        name = list(spec.keys())[0]
+        filename = list(spec.values())[0]
+        if type(filename) == int:
+            filename = list(EXOTIC_IDS[name].keys())[filename] + '.txt'
+        source = _data.get_xsc_source()
+        table = source.processXscFile(name, filename)
+        props = source.parseXscFileName(filename)
+        rangeMin, rangeMax = (float(v) for v in props['RANGE'].split('-')[:2])
+        temp = int(float(props['TEMP']))
+        pressure = float(props['PRESSURE']) / _data.TORR_PER_MBAR
+        self.name = name
+        self._xsc_spec = dict(spec)
+        self.exotic = True
+        self._xsc_member = Isotope(name, self)      # the reference's dummyIso: holds the device copy here
+        if temp != self.layer.T:
+            self.layer.changeTemperature(temp)
+        if pressure != self.layer.P:
+            self.layer.changePressure(pressure)
+        xAxis = np.arange(rangeMin, rangeMax, .01)
+        if float(props['RES']) > .01:
+            measured = interpolateArray(xAxis, table['wavenumber'], table['intensity'])
+        else:
+            measured = table['intensity']
+        self.crossSection = mergeArray(self.layer.xAxis, xAxis, measured)
+        self.progressCrossSection = True
+        self._xsc_member.crossSection = self.crossSection
+        self._xsc_member.progressCrossSection = True
+
     def __str__(self):
         return '%s: %s' % (self.name, self.concText)
 
@@ -591,12 +653,24 @@ class Molecule(_OpticalMixin, list):
     def _layer(self):
         return self.layer
 
+    def _members(self):
+        """What the device sweep reads for this molecule: its isotopologues, or the holder of a
+        measured cross section (kept in step with self.crossSection)."""
+        if not self.exotic:
+            return list(self)
+        if self._xsc_member.crossSection is not self.crossSection:
+            self._xsc_member.crossSection = self.crossSection
+            self._xsc_member._dev_xsec_valid = False
+        return [self._xsc_member]
+
     def _sweep_members(self):
-        return [list(self)], [self.concentration]
+        return [self._members()], [self.concentration]
 
     def returnCopy(self, layer=None):
         valueUnit = self.concText.split()
         tempDict = {valueUnit[1]: float(valueUnit[0])}
+        if self.exotic:         # the reference's copy fails on these (no isotopeDepth, cls:539): re-read the file
+            return Molecule(dict(self._xsc_spec), layer if layer is not None else self.layer, **tempDict)
         # a molecule made from its HITRAN number carries the upper-case short name, which is not
         # a MOLECULE_ID key (the reference's copy raises KeyError there): copy by number instead
         newMolecule = Molecule(self.ID if self._by_number else self.name, layer if layer is not None else self.layer,
@@ -629,6 +703,8 @@ class Molecule(_OpticalMixin, list):
 
     def createCrossSection(self):
         """cls:566-571: sum of the isotopologue cross sections (no abundance weighting)."""
+        if self.exotic:
+            return
         _compute_cross_sections(list(self))
         ctx = _ctx()
         n = int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION)
@@ -741,7 +817,7 @@ class Layer(_OpticalMixin, list):
         for m in self:
             if not m.progressCrossSection:
                 m.createCrossSection()
-        return [list(m) for m in self], [m.concentration for m in self]
+        return [m._members() for m in self], [m.concentration for m in self]
 
     def createCrossSection(self):
         """cls:684-689: sum of the molecule cross sections."""
@@ -751,7 +827,10 @@ class Layer(_OpticalMixin, list):
         tmp = []
         try:
             for molecule in self:
-                tmp.append(ctx.buffer(max(n, 1)).upload(getCrossSection(molecule)))
+                xs = np.ascontiguousarray(getCrossSection(molecule), dtype=np.float64)
+                if xs.shape != (n,):        # e.g. a partially overlapping xsc table (mergeArray, cls:216-219)
+                    raise ValueError("operands could not be broadcast together with shapes (%d,) %s" % (n, xs.shape))
+                tmp.append(ctx.buffer(max(n, 1)).upload(xs))
             self.crossSection = _sum_on_device(ctx, tmp, n)
         finally:
             for b in tmp:

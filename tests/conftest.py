@@ -43,3 +43,14 @@ def rel_err(a, b, floor=0.0):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def write_xsc_tree(z, root):
+    """Materialise the xsc files stored in the G8 golden (bytes written by the reference's own
+    writer) under ``root`` in PyRad's data/xsc layout."""
+    import json, os
+    for i, key in enumerate(json.loads(str(z["tree_json"]))):
+        mol, fn = key.split("/")
+        os.makedirs(os.path.join(root, mol), exist_ok=True)
+        with open(os.path.join(root, mol, fn), "wb") as f:
+            f.write(z["tree.%d" % i].tobytes())

@@ -46,6 +46,7 @@ REFERENCE = "/root/reference"
 # harness
 # ----------------------------------------------------------------------------
 _DATA = {}   # global_iso -> dict(lines=SoA, species=str)
+_XSC_IDS = {}   # what the stand-in hands to cls:1024 (EXOTIC_IDS); filled by g8 from the xsc tree
 
 
 def _install_harness():
@@ -53,7 +54,7 @@ def _install_harness():
     utils.RES_MULTIPLIER = 1
     utils.BASE_RESOLUTION = .01 * utils.RES_MULTIPLIER
     utils.VERSION = "1.75"
-    utils.returnXscTemperaturePressureValues = lambda: {}
+    utils.returnXscTemperaturePressureValues = lambda: _XSC_IDS     # cls:1024 keeps this very dict
     utils.writeCurveToFile = lambda *a, **k: None
 
     def readMolParams(iso):
@@ -469,9 +470,158 @@ def g7():
     save("G7_column", **arrays)
 
 
+# ----------------------------------------------------------------------------
+# G8: measured cross-section ("xsc") molecules — ut:611-715, cls:165-233, cls:466-505
+# ----------------------------------------------------------------------------
+def _reference_xsc_functions(xsc_dir):
+    """The reference's OWN xsc file functions, executed unmodified.  pyradUtilities cannot be
+    imported (bs4, network at import), so the named top-level functions are cut out of its
+    source text with ``ast`` and compiled into a namespace that supplies the module globals
+    they read (xscDir, NULL_TAG, BASE_RESOLUTION, logToFile)."""
+    import ast, re
+    path = os.path.join(REFERENCE, "pyradUtilities.py")
+    with open(path) as f:
+        tree = ast.parse(f.read(), path)
+    wanted = {"openReturnLines", "parseXscFileName", "returnXscFileContents", "processXscFile",
+              "returnXscTemperaturePressureValues", "writeXscFile"}
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in wanted]
+    assert {n.name for n in body} == wanted
+    ns = {"os": os, "re": re, "np": np, "xscDir": xsc_dir, "NULL_TAG": '#/null/#',
+          "BASE_RESOLUTION": .01, "logToFile": lambda *a, **k: None}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def g8():
+    import json, shutil, tempfile
+    arrays = {}
+    root = tempfile.mkdtemp(prefix="pyrad_xsc_")
+    try:
+        ns = _reference_xsc_functions(root)
+        # -- file names -> properties (ut:611-641) --------------------------------------------
+        names = ["CFC11_296.0K-760.0Torr_620.0-680.0_0.01_air_12_34.txt",
+                 "CFC12_250.0K-380.5Torr_590.0-710.0_0.05_N2_7_1.txt",
+                 "HFC134a_273.1K-0.0Torr_600.0-700.0_0.01__00_3.txt",
+                 "SF6_295K-700Torr_925-955_0.03_air_1_2.txt",
+                 "CCl4_208.0K-7.5Torr_750.0-812.0_00.txt"]
+        parsed = []
+        for nm in names:
+            try:
+                parsed.append(ns["parseXscFileName"](nm))
+            except Exception as e:                               # no trailing id -> False.replace
+                parsed.append({"raises": type(e).__name__})
+        arrays["names_json"] = np.array(json.dumps(names))
+        arrays["parsed_json"] = np.array(json.dumps(parsed))
+
+        # -- an xsc tree written by the reference's writer, read by its reader -----------------
+        rng = np.random.default_rng(800)
+
+        def table(lo, hi, res):
+            x = np.arange(lo, hi, res)
+            y = 1e-18 * np.exp(-((x - 0.5 * (lo + hi)) / (0.2 * (hi - lo))) ** 2) * (1 + 0.3 * rng.random(x.size))
+            return x, y
+
+        files = [("CFC11", 296.0, 760.0, 620.0, 680.0, .01, "air", "12-34"),
+                 ("CFC12", 250.0, 380.5, 590.0, 710.0, .05, "N2", "7-1"),
+                 ("CFC113", 296.0, 760.0, 590.0, 640.0, .01, "air", "2-2")]     # partial overlap with 600-700
+        with contextlib.redirect_stdout(io.StringIO()):
+            for mol, T, Ptorr, lo, hi, res, broad, ident in files:
+                os.makedirs("%s/%s" % (root, mol), exist_ok=True)
+                x, y = table(lo, hi, res)
+                ns["BASE_RESOLUTION"] = res                       # writeXscFile puts it in the name (ut:538)
+                ns["writeXscFile"](x, y, lo, hi, T, Ptorr, mol, "%s/%s" % (root, mol), broad, ident)
+        ns["BASE_RESOLUTION"] = .01
+        tree = {}
+        for mol in sorted(os.listdir(root)):
+            for fn in sorted(os.listdir("%s/%s" % (root, mol))):
+                with open("%s/%s/%s" % (root, mol, fn), "rb") as f:
+                    tree["%s/%s" % (mol, fn)] = f.read()
+        arrays["tree_json"] = np.array(json.dumps(sorted(tree)))
+        for i, key in enumerate(sorted(tree)):
+            arrays["tree.%d" % i] = np.frombuffer(tree[key], dtype=np.uint8)
+            mol, fn = key.split("/")
+            got = ns["processXscFile"](mol, fn)
+            arrays["read.%d.wavenumber" % i] = np.array(got["wavenumber"])
+            arrays["read.%d.intensity" % i] = np.array(got["intensity"])
+            arrays["read.%d.res" % i] = np.float64(got["res"])
+        ids = ns["returnXscTemperaturePressureValues"]()
+        arrays["exotic_ids_json"] = np.array(json.dumps(ids, sort_keys=True))
+
+        # -- mergeArray / interpolateArray direct (cls:159-233) --------------------------------
+        layer_axis = np.linspace(600, 700, 10000)
+        cases = {
+            "inside_new": (layer_axis, np.arange(620.0, 680.0, .01)),        # table inside the layer range
+            "covers_new": (layer_axis, np.arange(590.0, 710.0, .01)),        # table wider than the layer
+            "disjoint": (layer_axis, np.arange(720.0, 730.0, .01)),
+            "left_partial": (layer_axis, np.arange(590.0, 640.0, .01)),      # starts before, ends inside
+            "right_partial": (layer_axis, np.arange(660.0, 720.0, .01)),     # starts inside, ends after
+            "skipped_value": (layer_axis, np.arange(650.0, 660.0, .01)),     # 650.0 is not on the rounded axis
+            "short_table": (np.linspace(10, 11, 100), np.arange(10.5, 10.52, .01)),
+        }
+        with contextlib.redirect_stdout(io.StringIO()):
+            for name, (nx, oxx) in cases.items():
+                oy = 1.0 + rng.random(oxx.size)
+                arrays["merge.%s.newX" % name] = nx
+                arrays["merge.%s.oldX" % name] = oxx
+                arrays["merge.%s.oldY" % name] = oy
+                try:
+                    arrays["merge.%s.out" % name] = np.asarray(CLS.mergeArray(nx, oxx, oy), dtype=np.float64)
+                except Exception as e:
+                    arrays["merge.%s.raises" % name] = np.array(type(e).__name__)
+            arrays["interp.out"] = CLS.interpolateArray(np.arange(590.0, 710.0, .01), arrays["read.2.wavenumber"],
+                                                        arrays["read.2.intensity"])
+        arrays["merge_cases_json"] = np.array(json.dumps(list(cases)))
+
+        # -- layers holding an xsc molecule, through the reference's own classes ---------------
+        UT.processXscFile = ns["processXscFile"]
+        UT.parseXscFileName = ns["parseXscFileName"]
+        _XSC_IDS.clear(); _XSC_IDS.update(ids)
+        lo, hi = synthetic.layer_window(1013.25, 600, 700)
+        l_co2 = synthetic.make_lines(801, 300, max(lo - 0.01, 0), hi + 0.01)
+        arrays.update(pack_lines("co2.lines", l_co2))
+        layer_cases = [
+            ("E1", dict(T=296, P=1013.25), ("CFC11", "CFC11_296.0K-760.0Torr_620.0-680.0_0.01_air_12_34.txt"), dict(ppb=25)),
+            ("E2", dict(T=296, P=1013.25), ("CFC12", "CFC12_250.0K-380.5Torr_590.0-710.0_0.05_N2_7_1.txt"), dict(ppm=0.5)),
+            ("E3", dict(T=280, P=900.0), ("CFC11", 0), dict(ppb=40)),            # file picked by index
+            ("E4", dict(T=296, P=1013.25), ("CFC113", 0), dict(ppb=10)),         # wrong-length merge (cls:216-219)
+        ]
+        for tag, st, (mol, fn), conc in layer_cases:
+            _reset_reference_state()
+            UT.BASE_RESOLUTION = .01
+            register("co2", l_co2)
+            with contextlib.redirect_stdout(io.StringIO()):
+                layer = CLS.Layer(10.0, st["T"], st["P"], 600, 700, name=tag)
+                layer.addMolecule("co2", ppm=400)
+                try:
+                    m = layer.addMolecule({mol: fn}, **conc)
+                except Exception as e:
+                    arrays["%s.raises" % tag] = np.array(type(e).__name__)
+                    continue
+                arrays["%s.layer_T" % tag] = np.int64(layer.T)
+                arrays["%s.layer_P" % tag] = np.float64(layer.P)
+                arrays["%s.resolution" % tag] = np.float64(layer.resolution)
+                arrays["%s.mol_xsec" % tag] = np.asarray(CLS.getCrossSection(m), dtype=np.float64)
+                arrays["%s.mol_abs_coef" % tag] = np.asarray(CLS.getAbsCoef(m), dtype=np.float64)
+                try:
+                    arrays["%s.abs_coef" % tag] = np.asarray(CLS.getAbsCoef(layer), dtype=np.float64)
+                except ValueError as e:           # a cross section of the wrong length cannot be summed
+                    arrays["%s.abs_coef_raises" % tag] = np.array(type(e).__name__)
+                    arrays["%s.spec_json" % tag] = np.array(json.dumps(dict(T=st["T"], P=st["P"], mol=mol, file=fn, conc=conc)))
+                    continue
+                arrays["%s.transmittance" % tag] = np.asarray(CLS.getTransmittance(layer), dtype=np.float64)
+                arrays["%s.transmission" % tag] = np.asarray(layer.transmission(layer.planck(288)), dtype=np.float64)
+                arrays["%s.layer_xsec" % tag] = np.asarray(CLS.getCrossSection(layer), dtype=np.float64)
+            arrays["%s.spec_json" % tag] = np.array(json.dumps(dict(T=st["T"], P=st["P"], mol=mol, file=fn, conc=conc)))
+        arrays["layer_cases_json"] = np.array(json.dumps([c[0] for c in layer_cases]))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+        _XSC_IDS.clear()
+    save("G8_xsc", **arrays)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REFERENCE):
         sys.exit("needs /root/reference (build container only)")
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for name in which:
         globals()[name]()

@@ -164,5 +164,46 @@ def test_no_source_and_xsc_are_loud(pyrad):
     with pytest.raises(RuntimeError):
         layer.addMolecule('co2', ppm=400)
     source(co2=synthetic.make_lines(1, 10, 595, 705))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):                      # no xsc source installed
         layer.addMolecule({'CFC-11': 'file.txt'}, ppb=1)
+
+
+def test_g8_xsc_molecules(pyrad, tmp_path):
+    """Layers holding a measured cross-section molecule next to CO2 lines (cls:466-505): the file
+    sets the layer's T and P, its table is merged on the host, the sweep runs on the device."""
+    import json
+    from conftest import write_xsc_tree
+    from pyrad_amd import data
+    z = load_golden("G8_xsc")
+    write_xsc_tree(z, str(tmp_path))
+    source(co2=unpack_lines(z, "co2.lines"))
+    data.set_xsc_source(data.XscDir(str(tmp_path)))
+    try:
+        for tag in json.loads(str(z["layer_cases_json"])):
+            spec = json.loads(str(z["%s.spec_json" % tag]))
+            pyrad.Layer.hasAtmosphere = False
+            layer = pyrad.Layer(10.0, spec["T"], spec["P"], 600, 700, name=tag)
+            layer.addMolecule('co2', ppm=400)
+            m = layer.addMolecule({spec["mol"]: spec["file"]}, **spec["conc"])
+            assert m.exotic and len(m) == 0 and m.name == spec["mol"]
+            assert (layer.T, layer.P) == (int(z["%s.layer_T" % tag]), float(z["%s.layer_P" % tag]))
+            assert layer.resolution == float(z["%s.resolution" % tag])
+            assert np.array_equal(np.asarray(pyrad.getCrossSection(m), dtype=np.float64), z["%s.mol_xsec" % tag])
+            if "%s.abs_coef_raises" % tag in z.files:          # a partial overlap gives a wrong-length table
+                with pytest.raises(ValueError):
+                    pyrad.getAbsCoef(layer)
+                continue
+            assert rel_err(pyrad.getAbsCoef(m), z["%s.mol_abs_coef" % tag]) <= RTOL
+            assert rel_err(pyrad.getAbsCoef(layer), z["%s.abs_coef" % tag]) <= RTOL
+            assert rel_err(pyrad.getTransmittance(layer), z["%s.transmittance" % tag]) <= RTOL
+            assert rel_err(layer.transmission(layer.planck(288)), z["%s.transmission" % tag]) <= RTOL
+            assert rel_err(pyrad.getCrossSection(layer), z["%s.layer_xsec" % tag]) <= RTOL
+            # the measured table survives what invalidates line-by-line cross sections (cls:40)
+            before = np.array(m.crossSection)
+            layer.changeTemperature(layer.T)
+            m.setPPB(3)
+            assert m.progressCrossSection and np.array_equal(m.crossSection, before)
+            copy = m.returnCopy()
+            assert copy.exotic and np.array_equal(copy.crossSection, before)
+    finally:
+        data.set_xsc_source(None)
