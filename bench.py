@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
-    ap.add_argument("--variant", type=int, default=None, help="accumulate kernel variant 0..4 (default: library default 3)")
+    ap.add_argument("--variant", type=int, default=None, help="accumulate kernel variant 0..5 (default: library default 5, far-field series)")
     ap.add_argument("--points-per-lane", type=int, default=None)
     ap.add_argument("--line-split", type=int, default=None)
     ap.add_argument("--tile-order", type=int, default=None)
@@ -273,6 +273,22 @@ def main():
     for name in ("line_prep", "regrid", "layer_sweep", "column_sweep", "allgather"):
         n_, ms_ = extra[name]
         prof[name] = (n_ * args.steps // n_extra, ms_ * args.steps / n_extra)      # scaled to the timed step count
+    # the all-direct kernel (variant 3: every (line, grid point) pair evaluated, no series) on the
+    # same resident inputs, untimed, so that the line carries both numbers
+    direct_ms = None
+    if args.variant in (None, 5):
+        ctx.set_option("accum_variant", 3)
+        for _ in range(2):
+            step()
+        barrier()
+        ctx.profile_enable(["xsec_accumulate"])
+        ctx.profile_reset()
+        for _ in range(n_extra):
+            step()
+        barrier()
+        n_d, ms_d = ctx.profile_read()["xsec_accumulate"]
+        direct_ms = ms_d / n_extra
+        ctx.set_option("accum_variant", 5)
     ctx.profile_enable(False)
 
     # max over ranks of the elapsed time, sum over ranks of the evals — through the one comm
@@ -327,13 +343,7 @@ def main():
                          "algorithmic_bytes_per_launch": balg_acc, "avg_launch_ms": t_acc * 1e3, "launches": n_acc,
                          "note": "compulsory traffic only (56 B/line + 8 B/grid point): this kernel is fp64-VALU "
                                  "bound by construction (SURVEY.md §8d), see valu_f64"},
-            "valu_f64": {"instr_per_eval": FP64_INSTR_PER_EVAL,
-                         "achieved_lane_instr_per_s": FP64_INSTR_PER_EVAL * evals_local / t_acc_step if t_acc_step > 0 else 0.0,
-                         "peak_lane_instr_per_s": FP64_VALU_PEAK_INSTR,
-                         "frac": (FP64_INSTR_PER_EVAL * evals_local / t_acc_step / FP64_VALU_PEAK_INSTR) if t_acc_step > 0 else 0.0,
-                         "kernel_evals_per_s": evals_local / t_acc_step if t_acc_step > 0 else 0.0,
-                         "note": "5 fp64 instr per eval is the running-fraction Lorentz loop's minimum; measured "
-                                 "ceiling of that loop alone on this chip: 4.9e12 evals/s (scripts/ubench_fp64.hip)"},
+            "valu_f64": valu_block(evals_local, t_acc_step, direct_ms, args.variant),
             "roofline_sweep": {"bound": "hbm", "kernel": "layer_sweep_kernel",
                                "achieved": balg_sw / t_sw / 1e9 if t_sw > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": (balg_sw / t_sw / 1e9 / HBM_PEAK_GBS) if t_sw > 0 else 0.0,
@@ -358,6 +368,27 @@ def main():
     ctx.close()
     if rank == 0:
         print(json.dumps(result))
+
+
+def valu_block(evals_local, t_acc_step, direct_ms, variant):
+    """fp64 vector-ALU accounting of K2.  The all-direct kernel (variant 3) spends at least 5 fp64
+    instructions per (line, grid point) pair; the default kernel (variant 5) replaces the pairs of
+    distant Lorentz lines by a 30-term series per (line, span), so its pair rate is not bounded by
+    5 instructions per pair and only the direct kernel's rate is priced against the VALU peak."""
+    far_field = variant in (None, 5)
+    out = {"kernel_evals_per_s": evals_local / t_acc_step if t_acc_step > 0 else 0.0,
+           "far_field_series": far_field, "instr_per_eval_direct": FP64_INSTR_PER_EVAL,
+           "peak_lane_instr_per_s": FP64_VALU_PEAK_INSTR}
+    t_direct = direct_ms * 1e-3 if direct_ms else (None if far_field else t_acc_step)
+    if t_direct:
+        rate = evals_local / t_direct
+        out.update({"direct_kernel_ms_per_step": t_direct * 1e3, "direct_kernel_evals_per_s": rate,
+                    "direct_achieved_lane_instr_per_s": FP64_INSTR_PER_EVAL * rate,
+                    "direct_frac": FP64_INSTR_PER_EVAL * rate / FP64_VALU_PEAK_INSTR})
+    out["note"] = ("5 fp64 instr per eval is the running-fraction Lorentz loop's minimum (measured ceiling of that loop "
+                   "alone on this chip: 4.9e12 evals/s, scripts/ubench_fp64.hip); direct_* = the all-direct kernel "
+                   "(accum_variant 3) on the same inputs, timed in an extra untimed pass")
+    return out
 
 
 def load_pmc_traffic(workload):

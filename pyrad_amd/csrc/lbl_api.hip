@@ -53,11 +53,12 @@ struct lbl_ctx {
     int last_blocks_per_job = 0;
     std::vector<int> last_job_lines;
     // tuning knobs (lbl_set_option)
-    int accum_variant = 3;   // 0: IEEE divide + exp per pair; 1: running fraction; 2: + Gaussian recurrence
-                             // (0-2 fetch records through the scalar cache); 3 (default): 2 with wave-private
-                             // LDS staging; 4: 3 with the balanced single-round partition of (span, line)
-                             // pairs (measured: same main-kernel time as 3 plus ~20 us of helper kernels:
-                             // the kernel is throughput-bound per CU, not imbalance-bound)
+    int accum_variant = 5;   // 0: IEEE divide + exp per pair; 1: running fraction; 2: + Gaussian recurrence
+                             // (0-2 fetch records through the scalar cache); 3: 2 with wave-private LDS
+                             // staging (every pair evaluated directly); 4: 3 with the balanced single-round
+                             // partition of (span, line) pairs (measured: same main-kernel time as 3 plus
+                             // ~20 us of helper kernels); 5 (default): 3 with the far-field series for
+                             // Lorentz lines more than 4 half-spans from a span
     int accum_R = 0;         // points per lane, 0 = choose per launch
     int accum_LS = 0;        // waves sharing one span of points (line split), 0 = choose per launch
     int bal_workers[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident wavefronts of the balanced kernel per R (cached)
@@ -304,7 +305,7 @@ void comm_prof_end(lbl_ctx* ctx, void* start) { prof_end(ctx, PROF_GATHER, (hipE
 extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     if (!strcmp(key, "accum_variant")) {
-        if (value < 0 || value > 4) return fail(ctx, LBL_ERR_BAD_ARG, "accum_variant must be 0..4");
+        if (value < 0 || value > 5) return fail(ctx, LBL_ERR_BAD_ARG, "accum_variant must be 0..5");
         ctx->accum_variant = value;
     } else if (!strcmp(key, "accum_points_per_lane")) {
         if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
@@ -471,7 +472,7 @@ static void choose_shape(const lbl_ctx* ctx, long long total_points, long long t
     const bool lds = ctx->accum_variant >= 3;
     int R = ctx->accum_R, LS = lds ? ctx->accum_LS : 1;
     if (!R) {
-        if (ctx->accum_variant >= 4) {
+        if (ctx->accum_variant == 4) {
             R = 4;                       // work is split by lines, not spans: no reason to shrink R on small grids
         } else if (lds) {
             R = 4;
@@ -487,7 +488,10 @@ static void choose_shape(const lbl_ctx* ctx, long long total_points, long long t
     if (!LS) {
         const double lines_per_span = total_points > 0
             ? (double)total_lines / (double)total_points * (double)(2 * min_H + 64LL * R) : 0.0;
-        LS = lines_per_span >= 1024.0 ? 4 : lines_per_span >= 256.0 ? 2 : 1;
+        if (ctx->accum_variant == 5)         // far lines are ~40x cheaper: a span carries less work, split it less
+            LS = lines_per_span >= 4096.0 ? 4 : lines_per_span >= 1024.0 ? 2 : 1;
+        else
+            LS = lines_per_span >= 1024.0 ? 4 : lines_per_span >= 256.0 ? 2 : 1;
     }
     *R_out = R; *LS_out = LS;
 }
@@ -501,7 +505,11 @@ static void choose_shape(const lbl_ctx* ctx, long long total_points, long long t
 static const int2* group_schedule(lbl_ctx* ctx, const std::vector<int>& jobs_in_group, lbl_lines* const* lines,
                                   const lbl_grid* grid, int R, int LS, long long tile_pts, int* total_out) {
     std::vector<uint64_t> key;
-    key.push_back((uint64_t)R << 32 | (uint64_t)LS);
+    const bool far_field = ctx->accum_variant == 5;
+    int far_half_spans = 0;
+    double far_cost = 1.0;
+    if (far_field) accumulate_far_field_params(R, &far_half_spans, &far_cost);
+    key.push_back((uint64_t)R << 32 | (uint64_t)LS << 8 | (uint64_t)far_field);
     for (int j : jobs_in_group) {
         long long sf, sc;
         shard_range(grid[j], &sf, &sc);
@@ -529,7 +537,19 @@ static const int2* group_schedule(lbl_ctx* ctx, const std::vector<int>& jobs_in_
             const long long lo = sf + t * tile_pts, hi = std::min(lo + tile_pts - 1, sf + sc - 1);
             const auto a = std::lower_bound(idx.begin(), idx.end(), lo - H);
             const auto b = std::lower_bound(idx.begin(), idx.end(), hi + H + 1);
-            items.push_back({(int)(b - a), (int)k, (int)t});
+            long long cost = b - a;
+            if (far_field) {
+                // lines that every span of the tile sees as far interior lines cost far_cost each
+                const long long reach = (long long)far_half_spans * 32 * R + 32 * R;
+                const long long span = 64LL * R;
+                const auto fl0 = std::lower_bound(idx.begin(), idx.end(), hi - H + span);   // interior for all spans
+                const auto fl1 = std::lower_bound(idx.begin(), idx.end(), lo - reach);      // far-left for all spans
+                const auto fr0 = std::lower_bound(idx.begin(), idx.end(), hi + reach + 1);
+                const auto fr1 = std::lower_bound(idx.begin(), idx.end(), lo + H - span + 1);
+                const long long n_far = std::max<long long>(fl1 - fl0, 0) + std::max<long long>(fr1 - fr0, 0);
+                cost = (long long)((double)(cost - n_far) + far_cost * (double)n_far + 0.5);
+            }
+            items.push_back({(int)cost, (int)k, (int)t});
         }
     }
     std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.count > y.count; });
@@ -640,7 +660,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         p.log_t0_over_T = std::log(296.0 / iso[j].T);
         p.n_lines = (int32_t)L->n;
     }
-    const bool balanced = ctx->accum_variant >= 4;
+    const bool balanced = ctx->accum_variant == 4;
     // balanced variant scratch, per group: SpanRec[S] | counts u32[S] | prefix u64[S+1] | slab
     std::vector<size_t> bal_off(groups.size() + 1, 0);
     std::vector<int> group_spans(groups.size(), 0), group_workers(groups.size(), 0);
@@ -733,7 +753,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         } else {
             const int2* worklist = nullptr;
             int total_tiles = 0;
-            if (ctx->accum_variant == 3 && ctx->lpt) {
+            if ((ctx->accum_variant == 3 || ctx->accum_variant == 5) && ctx->lpt) {
                 std::vector<int> members(order.begin() + g.first, order.begin() + g.first + g.count);
                 worklist = group_schedule(ctx, members, lines, grid, g.R, g.LS,
                                           accumulate_tile_points(g.R, g.LS, ctx->accum_variant), &total_tiles);

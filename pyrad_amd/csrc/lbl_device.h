@@ -111,6 +111,7 @@ void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStrea
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
                        const int2* worklist, int total_tiles, hipStream_t s);
 int accumulate_tile_points(int R, int LS, int variant);
+void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost);
 // balanced variant (4): span ranges -> prefix sum -> equal shares of (span, line) pairs per wave -> slab reduce
 int balanced_workers(int R, int n_cu);
 void launch_accumulate_balanced(const AccumJob* d_jobs, int n_jobs, int total_spans, int R, int n_workers,

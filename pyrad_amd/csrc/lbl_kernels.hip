@@ -355,6 +355,42 @@ __device__ __forceinline__ void wave_line_ranges(const int32_t* __restrict__ cid
     if (tB >= tC) { iB = iD; iC = iD; }      // span wider than the support: no interior line
 }
 
+// The far-field variant also needs the two indices that bound the NEAR lines, so six lower
+// bounds: lane group q = lane/8 searches target q with a 9-way split per step (8 probes).
+//   [iB, iF1)  far-left interior lines,  c <= fl      [iF2, iC)  far-right interior lines,  c >= fr
+__device__ __forceinline__ void wave_line_ranges_far(const int32_t* __restrict__ cidx, int n_lines, int wlo, int whi, int H,
+                                                     long long fl, long long fr, int lane, int& iA, int& iB, int& iC,
+                                                     int& iD, int& iF1, int& iF2) {
+    const long long tA = (long long)wlo - H, tB = (long long)whi - H;
+    const long long tC = (long long)wlo + H + 1, tD = (long long)whi + H + 1;
+    const int q = lane >> 3, jj = lane & 7;
+    const long long tgt = q == 0 ? tA : q == 1 ? tB : q == 2 ? tC : q == 3 ? tD : q == 4 ? fl + 1 : fr;
+    const unsigned long long gmask = 0xFFull << (q * 8);
+    int lo = 0, hi = (q < 6) ? n_lines : 0;
+    while (__any(hi > lo)) {
+        const long long len = (long long)hi - lo;
+        const int pos = lo + (int)(((long long)(jj + 1) * len) / 9);
+        const bool below = (len > 0) && ((long long)cidx[len > 0 ? pos : 0] < tgt);
+        const int k = __popcll(__ballot(below) & gmask);
+        if (len > 0) {
+            const int p_k = lo + (int)(((long long)(k + 1) * len) / 9);
+            const int p_km1 = lo + (int)(((long long)k * len) / 9);
+            const int new_lo = k > 0 ? p_km1 + 1 : lo;
+            const int new_hi = k < 8 ? p_k : hi;
+            lo = new_lo; hi = new_hi;
+        }
+    }
+    iA = __builtin_amdgcn_readlane(lo, 0);
+    iB = __builtin_amdgcn_readlane(lo, 8);
+    iC = __builtin_amdgcn_readlane(lo, 16);
+    iD = __builtin_amdgcn_readlane(lo, 24);
+    iF1 = __builtin_amdgcn_readlane(lo, 32);
+    iF2 = __builtin_amdgcn_readlane(lo, 40);
+    if (tB >= tC) { iB = iD; iC = iD; }
+    iF1 = min(max(iF1, iB), iC);
+    iF2 = min(max(iF2, iF1), iC);
+}
+
 // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so each XCD gets a
 // contiguous run of tiles: neighbouring tiles read almost the same line records.
 __device__ __forceinline__ int xcd_tile(int b, int n_tiles, int natural = 0) {
@@ -606,11 +642,122 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
     }
 }
 
+// ---- variant 5: far-field series for distant Lorentz lines -------------------------------------
+// Most (line, span) pairs are far apart: with a +-5 cm^-1 window at 0.001 cm^-1 a line reaches
+// 40 spans of 256 points and is more than 8 half-spans away from 75 % of them.  For such a line
+// (centre c, delta = c - xc from the span centre xc, s = delta^2 + a^2) the Lorentz term is a
+// smooth function of u = x - xc over the whole span and its generating function is that of the
+// Chebyshev polynomials of the second kind:
+//     K / ((u - delta)^2 + a^2) = (K/s) / (1 - 2 X t + t^2) = (K/s) sum_n U_n(X) t^n,
+//     X = delta / sqrt(s),  t = u / sqrt(s),  |t| <= rho = h / |delta| <= 1 / FF_FAR.
+// In the scaled variable tau = u/h the coefficients q_n = (K/s) U_n(X) (h/sqrt(s))^n obey
+//     q_0 = K beta,  q_1 = alpha q_0,  q_{n+1} = alpha q_n - beta' q_{n-1},
+//     beta = 1/s,  alpha = 2 h delta beta,  beta' = h^2 beta,
+// i.e. three fp64 instructions per order and LINE instead of five per line and POINT.  One lane
+// takes one line, adds its q_n to per-lane sums C_n; the 64 lanes' sums are then reduced once per
+// span and the polynomial is evaluated at every lane's R points (Horner in tau, |tau| < 1).
+// Truncation after FF_NT terms: |sum_{n>=NT} U_n t^n| <= rho^NT (NT (1-rho) + 1) / (1-rho)^2,
+// relative to a term that is >= (K/s) / (1+rho)^2: with rho = 1/4 and NT = 30 that is 5.7e-17,
+// below half an ulp (measured sweep of threshold/terms: 4/30 beat 8/20, 6/24, 3/40 and 12/16), so the series is as exact as the sum it replaces (it carries fewer roundings:
+// measured 2e-16 against a long-double sum where the direct fp64 sum has 7e-16).
+// Edge lines (support ends inside the span) and near lines keep the direct path; a far line whose
+// Gaussian part still matters on the span (wide Doppler cores) gets its Gaussian pass as usual.
+#ifndef LBL_FF_FAR
+#define LBL_FF_FAR 4
+#define LBL_FF_NT 30
+#endif
+constexpr int FF_FAR = LBL_FF_FAR;   // a line is far when |c - xc| >= FF_FAR * (32 R)
+constexpr int FF_NT = LBL_FF_NT;     // series terms
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// sum over the 64 lanes, same value (and same summation tree) in every lane; all lanes must be active
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_move_f64<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_move_f64<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_move_f64<0x141>(v);      // row_half_mirror
+    v += dpp_move_f64<0x140>(v);      // row_mirror: every lane of a row holds the row's sum
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+// Series coefficients of the far lines m0, m0+stride*k.. (chunks of 64, one line per lane) below m1.
+template <int R>
+__device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec* cold, int m0, int m1, int stride,
+                                                double xc, int wlo, int whi, double x0, double Hf, double* lh, double* lc,
+                                                int lane, double (&C)[FF_NT], WaveAcc<R>& S) {
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    typedef const v2f64 __attribute__((address_space(1)))* GlobalF64x2;
+    const GlobalF64x2 gh = (GlobalF64x2)(unsigned long long)hot;
+    const GlobalF64x2 gc = (GlobalF64x2)(unsigned long long)cold;
+    const double hh = 32.0 * R;
+    v2f64 h0 = {0, 1}, h1 = {0, 0};
+    if (m0 + lane < m1) {
+        const long long r = (long long)(m0 + lane) * 2;
+        h0 = gh[r]; h1 = gh[r + 1];
+    }
+    for (int c0 = m0; c0 < m1; c0 += stride) {
+        const bool valid = c0 + lane < m1;
+        const v2f64 w0 = h0, w1 = h1;
+        if (c0 + stride + lane < m1) {
+            const long long r = (long long)(c0 + stride + lane) * 2;
+            h0 = gh[r]; h1 = gh[r + 1];
+        }
+        const int ci = (int)w0.x;
+        const int dgi = __double2loint(w1.y), fl = __double2hiint(w1.y);
+        const bool gauss = valid && max(0, max(ci - whi, wlo - ci)) < dgi;
+        const unsigned long long gmask = __ballot(gauss);
+        if (gmask) {                                   // rare: a far line with a Gaussian part that reaches the span
+            const unsigned long long emask = __ballot((fl & REC_NO_RECUR) != 0);
+            v2f64 c0v = {0, 0}, c1v = {0, 0};
+            if (gauss) {
+                const long long r = (long long)(c0 + lane) * 2;
+                c0v = gc[r]; c1v = gc[r + 1];
+            }
+            __builtin_amdgcn_wave_barrier();
+            reinterpret_cast<v2f64*>(lh)[lane * 2] = w0;
+            reinterpret_cast<v2f64*>(lh)[lane * 2 + 1] = w1;
+            reinterpret_cast<v2f64*>(lc)[lane * 2] = c0v;
+            reinterpret_cast<v2f64*>(lc)[lane * 2 + 1] = c1v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            chunk_extras<R>(lh, lc, gmask, emask, 0ull, ~0ull, x0, Hf, S);
+            __builtin_amdgcn_wave_barrier();
+        }
+        const double dl = w0.x - xc;
+        const double sq = fma(dl, dl, w0.y);
+        double be = __builtin_amdgcn_rcp(sq);
+        be = fma(fma(-sq, be, 1.0), be, be);
+        be = fma(fma(-sq, be, 1.0), be, be);
+        const double al = (dl * (2.0 * hh)) * be;
+        const double bp = (hh * hh) * be;
+        double qa = (valid ? w1.x : 0.0) * be;
+        C[0] += qa;
+        double qb = al * qa;
+        C[1] += qb;
+#pragma unroll
+        for (int n = 2; n < FF_NT; ++n) {
+            const double qn = fma(al, qb, -(bp * qa));
+            C[n] += qn;
+            qa = qb; qb = qn;
+        }
+    }
+}
+
 // LDS slot of grid-point offset o within a wave's span (padded so that a lane writing its R
 // consecutive points and a lane reading every 64th point are both nearly conflict-free)
 __device__ __forceinline__ int span_slot(int o) { return o + (o >> 4); }
 
-template <int R, int LS>
+template <int R, int LS, bool FF = false>
 __global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), ((R >= 8 && LS <= 4) ? 4 : 1))
 void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* __restrict__ worklist) {
     constexpr int NW = LS > 4 ? LS : 4;              // wavefronts per workgroup (LS = 8: 512 threads)
@@ -648,11 +795,42 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
     double* lh = s_stage[wave];
     double* lc = s_stage[wave] + 256;
 
-    if (active) {
+    if (active && !FF) {
         int iA, iB, iC, iD;
         wave_line_ranges(J.cidx, J.n_lines, wlo, whi, H, lane, iA, iB, iC, iD);
         // this wave's share of the span's lines: every LS-th chunk of 64, starting at chunk `part`
         accumulate_lines<R>(J.hot, J.cold, iA + part * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
+        S.flush();
+    }
+    if (active && FF) {
+        // interior lines at least FF_FAR half-spans from the span centre go through the series; the
+        // chunks of every class are dealt round-robin to the LS waves, each class starting at a
+        // different wave so that the short classes do not all land on wave 0
+        const long long fl = (long long)wlo + 32 * R - 1 - (long long)FF_FAR * 32 * R;
+        const long long fr = (long long)wlo + 32 * R + (long long)FF_FAR * 32 * R;
+        const double xc = (double)wlo + (32.0 * R - 0.5);
+        int iA, iB, iC, iD, iF1, iF2;
+        wave_line_ranges_far(J.cidx, J.n_lines, wlo, whi, H, fl, fr, lane, iA, iB, iC, iD, iF1, iF2);
+        if ((iF1 - iB) + (iC - iF2) > 0) {
+            double C[FF_NT];
+#pragma unroll
+            for (int n = 0; n < FF_NT; ++n) C[n] = 0.0;
+            far_field_lines<R>(J.hot, J.cold, iB + ((part + 1) % LS) * 64, iF1, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S);
+            far_field_lines<R>(J.hot, J.cold, iF2 + ((part + 2) % LS) * 64, iC, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S);
+#pragma unroll
+            for (int n = 0; n < FF_NT; ++n) C[n] = wave_sum_f64(C[n]);
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double tau = ((x0 + (double)k) - xc) * (1.0 / (32.0 * R));
+                double v = C[FF_NT - 1];
+#pragma unroll
+                for (int n = FF_NT - 2; n >= 0; --n) v = fma(v, tau, C[n]);
+                S.acc[k] += v;
+            }
+        }
+        accumulate_lines<R>(J.hot, J.cold, iA + ((part + 3) % LS) * 64, iB, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
+        accumulate_lines<R>(J.hot, J.cold, iF1 + part * 64, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
+        accumulate_lines<R>(J.hot, J.cold, iC + ((part + 2) % LS) * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
         S.flush();
     }
 
@@ -1080,7 +1258,7 @@ static void launch_accum_scalar(const AccumJob* d_jobs, int n_jobs, int max_tile
     }
 }
 
-template <int R>
+template <int R, bool FF>
 static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, int LS, const int2* worklist,
                              int total_tiles, hipStream_t s) {
     dim3 grid(((max_tiles + 7) / 8) * 8, n_jobs);
@@ -1089,11 +1267,18 @@ static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, 
         grid = dim3(total_tiles, 1);
     }
     switch (LS) {
-        case 8: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 8>), grid, dim3(512), 0, s, d_jobs, worklist); break;
-        case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4>), grid, dim3(256), 0, s, d_jobs, worklist); break;
-        case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2>), grid, dim3(256), 0, s, d_jobs, worklist); break;
-        default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1>), grid, dim3(256), 0, s, d_jobs, worklist); break;
+        case 8: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 8, FF>), grid, dim3(512), 0, s, d_jobs, worklist); break;
+        case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4, FF>), grid, dim3(256), 0, s, d_jobs, worklist); break;
+        case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2, FF>), grid, dim3(256), 0, s, d_jobs, worklist); break;
+        default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1, FF>), grid, dim3(256), 0, s, d_jobs, worklist); break;
     }
+}
+
+// far-field threshold (in half-spans of 32 R points) and the cost of a far line relative to a near
+// one (3 instructions per series term and 64 lines against 5 R per line), for the host's schedule
+void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost) {
+    *far_half_spans = FF_FAR;
+    *far_cost = (3.0 * FF_NT + 12.0) / 64.0 / (5.0 * R);
 }
 
 // grid points one workgroup covers
@@ -1104,12 +1289,21 @@ int accumulate_tile_points(int R, int LS, int variant) {
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
                        const int2* worklist, int total_tiles, hipStream_t s) {
     if (n_jobs <= 0 || max_tiles <= 0) return;
+    if (variant >= 5) {
+        switch (R) {
+            case 1: launch_accum_lds<1, true>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 2: launch_accum_lds<2, true>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 4: launch_accum_lds<4, true>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            default: launch_accum_lds<8, true>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+        }
+        return;
+    }
     if (variant >= 3) {
         switch (R) {
-            case 1: launch_accum_lds<1>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-            case 2: launch_accum_lds<2>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-            case 4: launch_accum_lds<4>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-            default: launch_accum_lds<8>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 1: launch_accum_lds<1, false>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 2: launch_accum_lds<2, false>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 4: launch_accum_lds<4, false>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            default: launch_accum_lds<8, false>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
         }
         return;
     }
