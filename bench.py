@@ -337,7 +337,7 @@ def main():
                        "gathered": args.gather, "device": info["name"],
                        "allgather": ("none" if comm is None else "in-stream" if n_sets == 1 else
                                      "overlapped with the next step (2 buffer sets)")},
-            "roofline": {"bound": "hbm", "kernel": "xsec_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "xsec_accumulate_lds_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc.get("xsec_accumulate_kernel"),
                          "algorithmic_bytes_per_launch": balg_acc, "avg_launch_ms": t_acc * 1e3, "launches": n_acc,

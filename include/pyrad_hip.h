@@ -98,11 +98,13 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
 /* Tuning knobs for A/B parity runs and benchmarking (no reference counterpart):
  *   "accum_variant"          0 IEEE divide + exp per pair | 1 running fraction | 2 + Gaussian recurrence
  *                            (0-2 fetch line records through the scalar cache) |
- *                            3 (default) = 2 with wave-private LDS staging of the records |
- *                            4 = 3 with a balanced single-round partition of (span, line) pairs
+ *                            3 = 2 with wave-private LDS staging of the records (every pair direct) |
+ *                            4 = 3 with a balanced single-round partition of (span, line) pairs |
+ *                            5 (default) = 3 with the fp64-exact far-field series for Lorentz lines
+ *                            more than 4 half-spans away from a span of 64*R points
  *   "accum_points_per_lane"  0 (auto) | 1 | 2 | 4 | 8
  *   "accum_line_split"       0 (auto) | 1 | 2 | 4 | 8 waves of a workgroup share one span of points
- *                            and split its lines (variant 3 only)
+ *                            and split its lines (variants 3 and 5)
  *   "accum_longest_first"    1 (default): workgroups are dispatched longest first from a cached
  *                            (job, tile) worklist | 0: positional order
  *   "accum_tile_order"       positional order only: 1 (default) natural | 0 one contiguous run of

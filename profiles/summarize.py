@@ -89,7 +89,12 @@ def main():
         allt = {}
     traffic = {}
     for k, v in pmc["kernels"].items():
-        base = "xsec_accumulate_kernel" if k.startswith("xsec_accumulate") else k
+        # bench.py times the far-field kernel <R, LS, true>; its extra untimed pass runs the
+        # all-direct kernel <R, LS, false> (reported as valu_f64.direct_*)
+        if k.startswith("xsec_accumulate"):
+            base = "xsec_accumulate_kernel" if "true>" in k else "xsec_accumulate_direct_kernel"
+        else:
+            base = k
         traffic[base] = v["hbm_bytes_corrected"]
     allt[wl] = {"source": "%s_%s_pmc.json" % (tag, wl), "hbm_bytes_per_launch": traffic}
     with open(tpath, "w") as f:

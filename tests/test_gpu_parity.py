@@ -413,3 +413,53 @@ def test_random_cells_against_oracle(ctx, orc, seed):
     assert tuple(counts) == tuple(rc)
     assert xs.shape == ref.shape
     check(xs, ref)
+
+
+def test_far_field_series_cases(ctx, orc):
+    """The far-field series of the default kernel (variant 5) on inputs built to hit its corners:
+    lines sitting exactly on the near/far threshold of a span, lines so wide that their Gaussian
+    part still matters on spans that see them as far, twelve decades of line strength, and every
+    launch shape; against the oracle and against the all-direct kernel (variant 3)."""
+    sp = synthetic.SPECIES["co2"]
+    rmin, rmax = 650, 670                                  # 20000 points at 0.001, W = 5000
+    g = orc.layer_grid(1013.25, rmin, rmax, .001, False)
+    rng = np.random.default_rng(77)
+    lo, hi = g["eff_min"], g["eff_max"]
+    base = synthetic.make_lines(78, 1500, lo, hi, decimals=6)
+    # threshold placement: span k of 64R points starts at 64Rk; a line is far when its centre index
+    # is <= start + 32R - 1 - 4*32R or >= start + 32R + 4*32R (R = 4, 2, 1)
+    idx = []
+    for R in (4, 2, 1):
+        for k in (3, 17, 40):
+            s0 = 64 * R * k
+            for off in (-1, 0, 1):
+                idx += [s0 + 32 * R - 1 - 128 * R + off, s0 + 32 * R + 128 * R + off]
+    idx = np.unique(np.clip(np.array(idx), 0, g["n_work"] - 1))
+    edge = {k: rng.choice(v, idx.size) for k, v in base.items()}
+    edge["nu"] = rmin + (idx + 0.4) * .001                  # int((nu - rmin)/res) == idx
+    edge["sw"] = 10.0 ** rng.uniform(-31.0, -19.0, idx.size)
+    wide = {k: rng.choice(v, 40) for k, v in base.items()}
+    wide["nu"] = np.round(rng.uniform(lo, hi, 40), 6)
+    wide["gamma_air"] = rng.uniform(0.18, 0.30, 40)         # a = 180-300 points: Gaussian reach > 1000 points
+    wide["gamma_self"] = wide["gamma_air"] * 1.1
+    lines = {k: np.concatenate([base[k], edge[k], wide[k]]) for k in base}
+    order = np.argsort(lines["nu"], kind="stable")
+    lines = {k: np.ascontiguousarray(v[order]) for k, v in lines.items()}
+    sel = orc.select_window(lines, lo, hi)
+    ref, _ = orc.create_cross_section(sel, 296, 1013.25, 4e-4, sp["molmass"], synthetic.q_value("co2", 296), sp["q296"], g)
+    direct, _, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, rmin, rmax, .001, False, 3)
+    check(direct, ref)
+    for R, LS in ((None, None), (4, 1), (4, 2), (4, 4), (4, 8), (2, 1), (2, 4), (1, 2), (8, 1), (8, 2)):
+        xs, _, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, rmin, rmax, .001, False, 5, R, LS)
+        check(xs, ref)
+        assert rel_err(xs, direct) <= 2e-14, (R, LS)
+    # sharded: the series is centred on spans counted from the shard origin
+    from pyrad_amd import engine
+    mols = [dict(conc=4e-4, isotopologues=[dict(lines=lines, molmass=sp["molmass"],
+                                                q_T=synthetic.q_value("co2", 296), q296=sp["q296"])])]
+    for rank in range(3):
+        part = engine.ResidentLayer(ctx, 10.0, 296, 1013.25, rmin, rmax, mols, .001, False, shard=(3, rank))
+        part.enqueue(surface_T=288)
+        sl = slice(part.first, part.first + part.count)
+        assert rel_err(part.xsec_host(0)[sl], ref[sl]) <= 1e-11
+        part.free()
