@@ -105,8 +105,9 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "accum_points_per_lane"  0 (auto) | 1 | 2 | 4 | 8
  *   "accum_line_split"       0 (auto) | 1 | 2 | 4 | 8 waves of a workgroup share one span of points
  *                            and split its lines (variants 3 and 5)
- *   "accum_longest_first"    1 (default): workgroups are dispatched longest first from a cached
- *                            (job, tile) worklist | 0: positional order
+ *   "accum_longest_first"    workgroups are dispatched from a cached (job, tile) worklist sorted by
+ *                            decreasing cost: 2 (default) with every other tier of n_cu items reversed
+ *                            (snake), 1 plain | 0: positional order
  *   "accum_tile_order"       positional order only: 1 (default) natural | 0 one contiguous run of
  *                            tiles per XCD | 2 golden-ratio stride
  *   "accum_blocks_per_cu"    variant 4 only: resident workgroups per CU, 0 = ask the runtime */
