@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--line-split", type=int, default=None)
     ap.add_argument("--tile-order", type=int, default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
-    ap.add_argument("--longest-first", type=int, default=None, help="0: positional tile order, 1: longest-first worklist, 2 (default): longest-first in snake order")
+    ap.add_argument("--longest-first", type=int, default=None, help="0: positional tile order, 1: longest-first worklist, 2: snake order, 3 (default): bin-packed per CU on single-round launches")
     ap.add_argument("--scale", type=int, default=1, help="experiment: widen the per-GPU range and line count by this factor")
     ap.add_argument("--lines", type=int, default=None, help="experiment: C2 with this many lines instead of 65,536")
     ap.add_argument("--no-cpu-baseline", action="store_true")

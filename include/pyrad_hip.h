@@ -106,8 +106,9 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "accum_line_split"       0 (auto) | 1 | 2 | 4 | 8 waves of a workgroup share one span of points
  *                            and split its lines (variants 3 and 5)
  *   "accum_longest_first"    workgroups are dispatched from a cached (job, tile) worklist sorted by
- *                            decreasing cost: 2 (default) with every other tier of n_cu items reversed
- *                            (snake), 1 plain | 0: positional order
+ *                            decreasing cost: 3 (default) bin-packed per CU when the launch is a single
+ *                            round of workgroups, 2 every other tier of n_cu items reversed (snake),
+ *                            1 plain | 0: positional order (waves then search their line ranges themselves)
  *   "accum_tile_order"       positional order only: 1 (default) natural | 0 one contiguous run of
  *                            tiles per XCD | 2 golden-ratio stride
  *   "accum_blocks_per_cu"    variant 4 only: resident workgroups per CU, 0 = ask the runtime */

@@ -63,10 +63,10 @@ struct lbl_ctx {
     int accum_LS = 0;        // waves sharing one span of points (line split), 0 = choose per launch
     int bal_workers[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident wavefronts of the balanced kernel per R (cached)
     // schedule cache: (job, tile) lists sorted longest first, per launch group
-    struct Schedule { std::vector<uint64_t> key; int2* d_list; int total; };
+    struct Schedule { std::vector<uint64_t> key; int2* d_list; int total; int32_t* d_tabs; std::vector<size_t> tab_off; };
     std::vector<Schedule> schedules;
     uint64_t lines_serial = 0;
-    int lpt = 2;             // 2 (default): longest-first worklist in snake order; 1: plain longest-first; 0: positional
+    int lpt = 3;             // longest-first worklist: 3 (default) bin-packed per CU when the launch is one round; 2 snake; 1 plain; 0 positional
     int tile_order = 1;      // 1: natural order (default; measured 8 % faster on the clustered C2 grid:
                              // all CUs work through one region together); 0: each XCD gets a contiguous run
     int live_objects = 0;
@@ -229,7 +229,7 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& v : ctx->ev_rec) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    for (auto& sc : ctx->schedules) if (sc.d_list) (void)hipFree(sc.d_list);
+    for (auto& sc : ctx->schedules) { if (sc.d_list) (void)hipFree(sc.d_list); if (sc.d_tabs) (void)hipFree(sc.d_tabs); }
     for (auto& e : ctx->desc_cache) if (e.dptr) (void)hipFree(e.dptr);
     DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->colargs, &ctx->counts, &ctx->bal, &ctx->red};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
@@ -312,7 +312,7 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) {
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_points_per_lane must be 0, 1, 2, 4 or 8");
         ctx->accum_R = value;
     } else if (!strcmp(key, "accum_longest_first")) {
-        if (value < 0 || value > 2) return fail(ctx, LBL_ERR_BAD_ARG, "accum_longest_first must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(ctx, LBL_ERR_BAD_ARG, "accum_longest_first must be 0..3");
         ctx->lpt = value;
     } else if (!strcmp(key, "accum_blocks_per_cu")) {
         if (value < 0 || value > 8) return fail(ctx, LBL_ERR_BAD_ARG, "accum_blocks_per_cu must be 0 (auto) .. 8");
@@ -503,8 +503,13 @@ static void choose_shape(const lbl_ctx* ctx, long long total_points, long long t
 // IEEE expression as K1) and counts the lines each tile will walk; the sorted (job, tile) list
 // depends only on the line lists and the grid, so it is built once and reused across calls
 // (temperature, pressure-independent).  It steers the dispatch order only, never a result.
-static const int2* group_schedule(lbl_ctx* ctx, const std::vector<int>& jobs_in_group, lbl_lines* const* lines,
-                                  const lbl_grid* grid, int R, int LS, long long tile_pts, int* total_out) {
+//
+// The same pass tabulates the line ranges of every span of 64*R points (what wave_line_ranges[_far]
+// would search for): 6 lower bounds per span.  A wave then starts with one 32-byte load instead of
+// six dependent probes of the centre-index array, which was most of a wave's lifetime on narrow
+// windows (upper layers of a column: ~10 lines per span).
+static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, const std::vector<int>& jobs_in_group, lbl_lines* const* lines,
+                                               const lbl_grid* grid, int R, int LS, long long tile_pts) {
     std::vector<uint64_t> key;
     const bool far_field = ctx->accum_variant == 5;
     int far_half_spans = 0;
@@ -521,10 +526,14 @@ static const int2* group_schedule(lbl_ctx* ctx, const std::vector<int>& jobs_in_
         key.push_back((uint64_t)sf); key.push_back((uint64_t)sc); key.push_back((uint64_t)grid[j].window);
     }
     for (auto& sc : ctx->schedules)
-        if (sc.key == key) { *total_out = sc.total; return sc.d_list; }
+        if (sc.key == key) return &sc;
     struct Item { int count, job, tile; };
     std::vector<Item> items;
     std::vector<long long> idx;
+    std::vector<int32_t> tabs;
+    std::vector<size_t> tab_off;
+    const long long span = 64LL * R;
+    const long long reach = (long long)far_half_spans * 32 * R;
     for (size_t k = 0; k < jobs_in_group.size(); ++k) {
         const int j = jobs_in_group[k];
         const lbl_lines* L = lines[j];
@@ -533,52 +542,89 @@ static const int2* group_schedule(lbl_ctx* ctx, const std::vector<int>& jobs_in_
         long long sf, sc;
         shard_range(grid[j], &sf, &sc);
         const long long H = std::max<long long>(grid[j].window - 2, 0);
-        const long long n_tiles = (sc + tile_pts - 1) / tile_pts;
-        for (long long t = 0; t < n_tiles; ++t) {
-            const long long lo = sf + t * tile_pts, hi = std::min(lo + tile_pts - 1, sf + sc - 1);
-            const auto a = std::lower_bound(idx.begin(), idx.end(), lo - H);
-            const auto b = std::lower_bound(idx.begin(), idx.end(), hi + H + 1);
-            long long cost = b - a;
+        auto below = [&](long long v) { return (int32_t)(std::lower_bound(idx.begin(), idx.end(), v) - idx.begin()); };
+        // span table (same arithmetic as wave_line_ranges_far)
+        const long long n_spans = (sc + span - 1) / span;
+        tab_off.push_back(tabs.size());
+        tabs.resize(tabs.size() + (size_t)n_spans * 8, 0);
+        int32_t* T = tabs.data() + tab_off.back();
+        for (long long t = 0; t < n_spans; ++t) {
+            const long long lo = sf + t * span, hi = std::min(lo + span - 1, sf + sc - 1);
+            int32_t iA = below(lo - H), iB = below(hi - H), iC = below(lo + H + 1), iD = below(hi + H + 1);
+            if (hi - H >= lo + H + 1) { iB = iD; iC = iD; }
+            int32_t iF1 = iB, iF2 = iC;
             if (far_field) {
-                // lines that every span of the tile sees as far interior lines cost far_cost each
-                const long long reach = (long long)far_half_spans * 32 * R + 32 * R;
-                const long long span = 64LL * R;
-                const auto fl0 = std::lower_bound(idx.begin(), idx.end(), hi - H + span);   // interior for all spans
-                const auto fl1 = std::lower_bound(idx.begin(), idx.end(), lo - reach);      // far-left for all spans
-                const auto fr0 = std::lower_bound(idx.begin(), idx.end(), hi + reach + 1);
-                const auto fr1 = std::lower_bound(idx.begin(), idx.end(), lo + H - span + 1);
-                const long long n_far = std::max<long long>(fl1 - fl0, 0) + std::max<long long>(fr1 - fr0, 0);
-                cost = (long long)((double)(cost - n_far) + far_cost * (double)n_far + 0.5);
+                iF1 = std::min(std::max(below(lo + 32 * R - reach), iB), iC);      // first line with c > fl
+                iF2 = std::min(std::max(below(lo + 32 * R + reach), iF1), iC);     // first line with c >= fr
             }
-            items.push_back({(int)cost, (int)k, (int)t});
+            int32_t* e = T + t * 8;
+            e[0] = iA; e[1] = iB; e[2] = iC; e[3] = iD; e[4] = iF1; e[5] = iF2;
+        }
+        // cost of every tile (a workgroup's points): lines it walks, far lines at their series price
+        const long long n_tiles = (sc + tile_pts - 1) / tile_pts;
+        const long long spans_per_tile = tile_pts / span;
+        for (long long t = 0; t < n_tiles; ++t) {
+            double cost = 0.0;
+            for (long long q = t * spans_per_tile; q < std::min((t + 1) * spans_per_tile, n_spans); ++q) {
+                // wave-instructions of one span: near line 5R + ~0.6 Gaussian passes of 48, masked edge
+                // line 8R, series line ~1.6, fixed part ~600 (variants without the series: all direct)
+                const int32_t* e = T + q * 8;
+                const double n_far = (double)((e[4] - e[1]) + (e[2] - e[5]));
+                const double n_edge = (double)((e[1] - e[0]) + (e[3] - e[2]));
+                const double n_near = (double)(e[5] - e[4]);
+                cost += n_near * (5.0 * R + 29.0) + n_edge * 8.0 * R + n_far * far_cost * 5.0 * R + 600.0;
+            }
+            items.push_back({(int)(cost + 0.5), (int)k, (int)t});
         }
     }
     std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.count > y.count; });
-    if (ctx->lpt >= 2) {
+    const size_t n_cu = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+    if (ctx->lpt == 2) {
         // snake order: on a small grid every workgroup is resident from the first cycle, nothing is
         // dispatched dynamically, and CU k receives items k, k + n_cu, k + 2 n_cu, ...: reversing
-        // every other tier of n_cu items pairs the heaviest of one tier with the lightest of the
-        // next (C2: 0.083 -> 0.076 ms; no effect once a launch has several rounds of workgroups)
-        const size_t tier = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
-        for (size_t b = tier; b < items.size(); b += 2 * tier)
-            std::reverse(items.begin() + b, items.begin() + std::min(items.size(), b + tier));
+        // every other tier of n_cu items pairs the heaviest of one tier with the lightest of the next
+        for (size_t b = n_cu; b < items.size(); b += 2 * n_cu)
+            std::reverse(items.begin() + b, items.begin() + std::min(items.size(), b + n_cu));
+    } else if (ctx->lpt >= 3 && items.size() <= 4 * n_cu) {
+        // single round: pack the items into n_cu bins longest-first (each to the least loaded bin
+        // that still has a free slot), then emit bin-interleaved so that the dispatcher's round
+        // robin over the CUs rebuilds the bins
+        const size_t slots = (items.size() + n_cu - 1) / n_cu;
+        std::vector<std::vector<Item>> bins(n_cu);
+        std::vector<long long> load(n_cu, 0);
+        for (const Item& it : items) {
+            size_t best = n_cu;
+            for (size_t b = 0; b < n_cu; ++b)
+                if (bins[b].size() < slots && (best == n_cu || load[b] < load[best])) best = b;
+            bins[best].push_back(it);
+            load[best] += it.count;
+        }
+        std::vector<Item> out;
+        out.reserve(items.size());
+        for (size_t t = 0; t < slots; ++t)
+            for (size_t b = 0; b < n_cu; ++b)
+                if (t < bins[b].size()) out.push_back(bins[b][t]);
+        items.swap(out);
     }
     std::vector<int2> host(items.size());
     for (size_t i = 0; i < items.size(); ++i) { host[i].x = items[i].job; host[i].y = items[i].tile; }
     int2* d_list = nullptr;
+    int32_t* d_tabs = nullptr;
     if (hipMalloc((void**)&d_list, std::max<size_t>(host.size(), 1) * sizeof(int2)) != hipSuccess) return nullptr;
-    if (!host.empty() && hipMemcpy(d_list, host.data(), host.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(d_list);
+    if (hipMalloc((void**)&d_tabs, std::max<size_t>(tabs.size(), 8) * sizeof(int32_t)) != hipSuccess) { (void)hipFree(d_list); return nullptr; }
+    if ((!host.empty() && hipMemcpy(d_list, host.data(), host.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) ||
+        (!tabs.empty() && hipMemcpy(d_tabs, tabs.data(), tabs.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)) {
+        (void)hipFree(d_list); (void)hipFree(d_tabs);
         return nullptr;
     }
     if (ctx->schedules.size() >= 16) {                    // small cache: drop the oldest entry
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(ctx->schedules.front().d_list);
+        (void)hipFree(ctx->schedules.front().d_tabs);
         ctx->schedules.erase(ctx->schedules.begin());
     }
-    ctx->schedules.push_back({key, d_list, (int)host.size()});
-    *total_out = (int)host.size();
-    return d_list;
+    ctx->schedules.push_back({key, d_list, (int)host.size(), d_tabs, tab_off});
+    return &ctx->schedules.back();
 }
 
 struct DbgOut { long long* index; double* lhw; double* ghw; double* inten; int32_t* regime; };
@@ -625,16 +671,17 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     // Jobs of one batch can have very different windows (a column: W = 5000 at the surface,
     // 50 at 10 mbar).  A wave must not own more points than a line's support is wide, so jobs are
     // grouped by the largest R their window allows and every group gets its own launch shape.
+    const int r_default = ctx->accum_variant >= 3 ? 4 : 8;       // what choose_shape starts from
     auto r_cap = [&](int j) {
         const long long H = std::max<long long>(grid[j].window - 2, 0);
-        int r = 8;
+        int r = r_default;                        // windows that allow more than the default share its group
         while (r > 1 && 64LL * r > 2 * H + 1) r >>= 1;
         return ctx->accum_R ? 8 : r;              // a forced R keeps one group
     };
     std::vector<int> order(n_jobs);
     for (int j = 0; j < n_jobs; ++j) order[j] = j;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return r_cap(a) > r_cap(b); });
-    struct Group { int first, count, R, LS, max_tiles; };
+    struct Group { int first, count, R, LS, max_tiles; const int2* worklist; int total_tiles; const int32_t* tabs; std::vector<size_t> tab_off; };
     std::vector<Group> groups;
     for (int k = 0; k < n_jobs;) {
         int e = k;
@@ -646,8 +693,16 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             mh = std::min<long long>(mh, std::max<long long>(grid[order[e]].window - 2, 0));
             ++e;
         }
-        Group g{k, e - k, 0, 0, 0};
+        Group g{k, e - k, 0, 0, 0, nullptr, 0, nullptr, {}};
         choose_shape(ctx, pts, lns, mh, &g.R, &g.LS);
+        if ((ctx->accum_variant == 3 || ctx->accum_variant == 5) && ctx->lpt) {
+            // cached host schedule of this group: dispatch order + the line ranges of every span
+            std::vector<int> members(order.begin() + k, order.begin() + e);
+            const lbl_ctx::Schedule* sc = group_schedule(ctx, members, lines, grid, g.R, g.LS,
+                                                         accumulate_tile_points(g.R, g.LS, ctx->accum_variant));
+            if (!sc) return fail(ctx, LBL_ERR_OOM, "schedule allocation failed");
+            g.worklist = sc->d_list; g.total_tiles = sc->total; g.tabs = sc->d_tabs; g.tab_off = sc->tab_off;
+        }
         groups.push_back(g);
         k = e;
     }
@@ -693,6 +748,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             a.n_tiles = (int32_t)((sc + tile_pts - 1) / tile_pts);
             a.flush_every = (a.H + 64 * g.R + 1 <= 40000) ? 32 : 16;
             a.pad = ctx->tile_order;
+            a.span_tab = g.tabs ? g.tabs + g.tab_off[(size_t)(k - g.first)] : nullptr;
             g.max_tiles = std::max(g.max_tiles, a.n_tiles);
             if (balanced) {
                 const size_t gi = (size_t)(&g - &groups[0]);
@@ -761,14 +817,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             launch_accumulate_balanced(da + g.first, g.count, (int)S, g.R, group_workers[gi], spans, cnts, prefix, slab,
                                        ctx->stream);
         } else {
-            const int2* worklist = nullptr;
-            int total_tiles = 0;
-            if ((ctx->accum_variant == 3 || ctx->accum_variant == 5) && ctx->lpt) {
-                std::vector<int> members(order.begin() + g.first, order.begin() + g.first + g.count);
-                worklist = group_schedule(ctx, members, lines, grid, g.R, g.LS,
-                                          accumulate_tile_points(g.R, g.LS, ctx->accum_variant), &total_tiles);
-            }
-            launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, ctx->accum_variant, worklist, total_tiles,
+            launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, ctx->accum_variant, g.worklist, g.total_tiles,
                               ctx->stream);
         }
         prof_end(ctx, PROF_ACCUM, ev);

@@ -59,6 +59,10 @@ struct AccumJob {
     int32_t pad;           // LS variant: tile order (0 XCD-chunked, 1 natural)
     int32_t span_first;    // balanced variant: first global span id of this job
     int32_t n_spans;
+    // LDS variants with a host schedule: line ranges of every span of 64*R points of this job's
+    // shard, 8 ints per span {iA, iB, iC, iD, iF1, iF2, 0, 0} (see wave_line_ranges[_far]); NULL:
+    // the wave searches the centre indices itself
+    const int32_t* span_tab;
 };
 
 // Balanced variant: spans (64*R consecutive grid points) of all jobs of a launch group are

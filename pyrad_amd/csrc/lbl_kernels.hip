@@ -850,9 +850,13 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
     double* lh = s_stage[wave];
     double* lc = s_stage[wave] + 256;
 
+    // line ranges of this span: tabulated by the host with the schedule, else searched here
+    const int32_t* tab = nullptr;
+    if (active && J.span_tab) tab = J.span_tab + (size_t)((wlo - J.p_begin) / (64 * R)) * 8;
     if (active && !FF) {
         int iA, iB, iC, iD;
-        wave_line_ranges(J.cidx, J.n_lines, wlo, whi, H, lane, iA, iB, iC, iD);
+        if (tab) { iA = uniform_i32(tab[0]); iB = uniform_i32(tab[1]); iC = uniform_i32(tab[2]); iD = uniform_i32(tab[3]); }
+        else wave_line_ranges(J.cidx, J.n_lines, wlo, whi, H, lane, iA, iB, iC, iD);
         // this wave's share of the span's lines: every LS-th chunk of 64, starting at chunk `part`
         accumulate_lines<R>(J.hot, J.cold, iA + part * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
         S.flush();
@@ -865,8 +869,13 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         const long long fr = (long long)wlo + 32 * R + (long long)FF_FAR * 32 * R;
         const double xc = (double)wlo + (32.0 * R - 0.5);
         int iA, iB, iC, iD, iF1, iF2;
-        wave_line_ranges_far(J.cidx, J.n_lines, wlo, whi, H, fl, fr, lane, iA, iB, iC, iD, iF1, iF2);
-        if ((iF1 - iB) + (iC - iF2) > 0) {
+        if (tab) {           // wave-uniform values: keep them in scalar registers
+            iA = uniform_i32(tab[0]); iB = uniform_i32(tab[1]); iC = uniform_i32(tab[2]); iD = uniform_i32(tab[3]);
+            iF1 = uniform_i32(tab[4]); iF2 = uniform_i32(tab[5]);
+        }
+        else wave_line_ranges_far(J.cidx, J.n_lines, wlo, whi, H, fl, fr, lane, iA, iB, iC, iD, iF1, iF2);
+        const bool any_far = (iF1 - iB) + (iC - iF2) > 0;
+        if (any_far) {
             double C[FF_NT];
 #pragma unroll
             for (int n = 0; n < FF_NT; ++n) C[n] = 0.0;
@@ -882,9 +891,14 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
                 S.acc[k] += v;
             }
         }
-        accumulate_lines<R>(J.hot, J.cold, iA + ((part + 3) % LS) * 64, iB, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
-        accumulate_lines<R>(J.hot, J.cold, iF1 + part * 64, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
-        accumulate_lines<R>(J.hot, J.cold, iC + ((part + 2) % LS) * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
+        // the direct classes: left-edge, near and right-edge lines.  Without far lines (narrow window)
+        // they are one contiguous run and go through the first stream alone (one prologue, not three).
+        const int s0 = iA + (any_far ? ((part + 3) % LS) : part) * 64;
+        accumulate_lines<R>(J.hot, J.cold, s0, any_far ? iB : iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
+        if (any_far) {
+            accumulate_lines<R>(J.hot, J.cold, iF1 + part * 64, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
+            accumulate_lines<R>(J.hot, J.cold, iC + ((part + 2) % LS) * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
+        }
         S.flush();
     }
 
