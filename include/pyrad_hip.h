@@ -188,6 +188,17 @@ int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* xsec, const 
                         lbl_buffer* I_in, double surface_T,
                         lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out);
 
+/* One step of a single-isotopologue layer (the gas cell of pyradClasses.py:648 with one
+ * addMolecule, isotopeDepth 1): lbl_xsec_accumulate_dev for the one line list followed by
+ * lbl_layer_sweep_dev with n_iso = n_mol = 1, in ONE launch sequence: when the work grid is
+ * the base grid the sweep of a grid point runs in the accumulate kernel's output stage, right
+ * after that point's cross section is final (same arithmetic, bit-identical results, no
+ * separate sweep launch and no re-read of the cross section).  P and T come from `iso`, the
+ * axis and the shard from `grid`; `xsec` receives the cross section as usual. */
+int lbl_layer_step_dev(lbl_ctx* ctx, lbl_lines* lines, const lbl_iso_params* iso, const lbl_grid* grid,
+                       lbl_buffer* xsec, double conc, double depth, lbl_buffer* I_in, double surface_T,
+                       lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out);
+
 /* Column fold of Layer.transmission over layers bottom to top (pyradClasses.py:784-787):
  *   I <- trans_l * I + (1 - trans_l) * B(nu_j, layer_T[l]),  I_0 = I_in or B(nu_j, surface_T). */
 int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const* trans, const double* layer_T,

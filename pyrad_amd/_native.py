@@ -81,6 +81,8 @@ SIGNATURES = {
     "lbl_layer_sweep_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int, _D,
                                       C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                       C.c_int64, C.c_int64, _P, C.c_double, _P, _P, _P]),
+    "lbl_layer_step_dev": (C.c_int, [_P, _P, C.POINTER(IsoParams), C.POINTER(Grid), _P, C.c_double, C.c_double,
+                                     _P, C.c_double, _P, _P, _P]),
     "lbl_column_sweep_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), _D, C.c_double, C.c_double, C.c_int64,
                                        C.c_int64, C.c_int64, _P, C.c_double, _P]),
     "lbl_optical_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
@@ -278,6 +280,13 @@ class Context:
             float(range_max), int(n), int(first), int(count), I_in.h if I_in is not None else None,
             float(surface_T), abs_coef.h if abs_coef is not None else None, trans.h if trans is not None else None,
             I_out.h if I_out is not None else None))
+
+    def layer_step_dev(self, lines: "Lines", iso: IsoParams, grid: Grid, xsec, conc, depth, I_in=None, surface_T=0.0,
+                       abs_coef=None, trans=None, I_out=None):
+        """Accumulate + sweep of a single-isotopologue layer in one launch sequence."""
+        h = lambda b: b.h if b is not None else None
+        self.check(self.lib.lbl_layer_step_dev(self.h, lines.h, C.byref(iso), C.byref(grid), xsec.h, float(conc),
+                                               float(depth), h(I_in), float(surface_T), h(abs_coef), h(trans), h(I_out)))
 
     def column_sweep_dev(self, trans, layer_T, range_min, range_max, n, I_out, I_in=None, surface_T=0.0,
                          first=0, count=0):

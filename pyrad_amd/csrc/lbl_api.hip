@@ -472,6 +472,31 @@ static void choose_shape(const lbl_ctx* ctx, long long total_points, long long t
     const long long cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
     const bool lds = ctx->accum_variant >= 3;
     int R = ctx->accum_R, LS = lds ? ctx->accum_LS : 1;
+    auto lines_per_span = [&](int r) {
+        return total_points > 0 ? (double)total_lines / (double)total_points * (double)(2 * min_H + 64LL * r) : 0.0;
+    };
+    if (ctx->accum_variant == 5 && !R && !LS) {
+        // far-field kernel: R = 4 and as little line split as the line count asks for, unless the grid
+        // is too small to give every SIMD two wavefronts: then split more, then shrink the spans
+        // (C1, 10^4 points: R = 1 with 8 waves per span is 4x faster than R = 4 unsplit)
+        const long long want_waves = 8 * cus;
+        int best_R = 1, best_LS = 1;
+        bool found = false;
+        for (int r = 4; r >= 1 && !found; r >>= 1) {
+            if (r > 1 && 64LL * r > 2 * min_H + 1) continue;
+            const long long spans = std::max<long long>((total_points + 64LL * r - 1) / (64LL * r), 1);
+            const double lps = lines_per_span(r);
+            int by_lines = lps >= 4096.0 ? 4 : lps >= 1024.0 ? 2 : 1;
+            int by_fill = 1;
+            while (by_fill < 8 && spans * by_fill < want_waves) by_fill <<= 1;
+            int cap = 1;                                   // at least one 64-line chunk per wave of a span
+            while (cap < 8 && lps >= 128.0 * cap) cap <<= 1;
+            best_R = r; best_LS = std::max(by_lines, std::min(by_fill, cap));
+            found = spans * best_LS >= want_waves || r == 1;
+        }
+        *R_out = best_R; *LS_out = best_LS;
+        return;
+    }
     if (!R) {
         if (ctx->accum_variant == 4) {
             R = 4;                       // work is split by lines, not spans: no reason to shrink R on small grids
@@ -487,12 +512,11 @@ static void choose_shape(const lbl_ctx* ctx, long long total_points, long long t
         while (R > 1 && 64LL * R > 2 * min_H + 1) R >>= 1;
     }
     if (!LS) {
-        const double lines_per_span = total_points > 0
-            ? (double)total_lines / (double)total_points * (double)(2 * min_H + 64LL * R) : 0.0;
+        const double lps = lines_per_span(R);
         if (ctx->accum_variant == 5)         // far lines are ~40x cheaper: a span carries less work, split it less
-            LS = lines_per_span >= 4096.0 ? 4 : lines_per_span >= 1024.0 ? 2 : 1;
+            LS = lps >= 4096.0 ? 4 : lps >= 1024.0 ? 2 : 1;
         else
-            LS = lines_per_span >= 1024.0 ? 4 : lines_per_span >= 256.0 ? 2 : 1;
+            LS = lps >= 1024.0 ? 4 : lps >= 256.0 ? 2 : 1;
     }
     *R_out = R; *LS_out = LS;
 }
@@ -630,7 +654,8 @@ static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, const std::vector<i
 struct DbgOut { long long* index; double* lhw; double* ghw; double* inten; int32_t* regime; };
 
 static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines, const lbl_iso_params* iso,
-                              const lbl_grid* grid, double* const* out_dev, const DbgOut* dbg, bool prep_only) {
+                              const lbl_grid* grid, double* const* out_dev, const DbgOut* dbg, bool prep_only,
+                              const FusedSweep* fuse = nullptr) {
     if (n_jobs <= 0) return LBL_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // layout of the scratch arenas
@@ -749,6 +774,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             a.flush_every = (a.H + 64 * g.R + 1 <= 40000) ? 32 : 16;
             a.pad = ctx->tile_order;
             a.span_tab = g.tabs ? g.tabs + g.tab_off[(size_t)(k - g.first)] : nullptr;
+            if (fuse && n_jobs == 1) a.fuse = *fuse;
             g.max_tiles = std::max(g.max_tiles, a.n_tiles);
             if (balanced) {
                 const size_t gi = (size_t)(&g - &groups[0]);
@@ -990,6 +1016,45 @@ extern "C" int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* x
     prof_end(ctx, PROF_SWEEP, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
+}
+
+extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, lbl_lines* lines, const lbl_iso_params* iso, const lbl_grid* grid,
+                                  lbl_buffer* xsec, double conc, double depth, lbl_buffer* I_in, double surface_T,
+                                  lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (!lines || !iso || !grid || !xsec) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    int rc;
+    const int64_t n = grid->n_base;
+    if ((rc = check_buf(ctx, xsec, n, "xsec", true))) return rc;
+    if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
+    if ((rc = check_buf(ctx, abs_coef, n, "abs_coef", false))) return rc;
+    if ((rc = check_buf(ctx, trans, n, "trans", false))) return rc;
+    if ((rc = check_buf(ctx, I_out, n, "I_out", false))) return rc;
+    if (I_out && !I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "I_out needs I_in or surface_T > 0");
+    double* out = xsec->d;
+    const bool fusable = (ctx->accum_variant == 3 || ctx->accum_variant == 5) && !needs_regrid(*grid);
+    if (fusable) {
+        FusedSweep f;
+        memset(&f, 0, sizeof f);
+        f.conc = conc; f.P = iso->P; f.T = iso->T; f.depth = depth;
+        f.start = grid->range_min; f.stop = grid->range_max; f.step = axis_step(grid->range_min, grid->range_max, n);
+        planck_constants(&f.pa, &f.pb);
+        f.surface_T = surface_T;
+        f.I_in = I_in ? I_in->d : nullptr;
+        f.abs_coef = abs_coef ? abs_coef->d : nullptr;
+        f.trans = trans ? trans->d : nullptr;
+        f.I_out = I_out ? I_out->d : nullptr;
+        f.n = n; f.on = 1;
+        return enqueue_accumulate(ctx, 1, &lines, iso, grid, &out, nullptr, false, &f);
+    }
+    // a work grid that needs the regrid kernel, or a kernel variant without the fused stage: two steps
+    if ((rc = enqueue_accumulate(ctx, 1, &lines, iso, grid, &out, nullptr, false))) return rc;
+    const int32_t mol0 = 0;
+    long long sf, sc;
+    shard_range(*grid, &sf, &sc);
+    const bool whole = sc == grid->n_work;
+    return lbl_layer_sweep_dev(ctx, 1, &xsec, &mol0, 1, &conc, iso->P, iso->T, depth, grid->range_min, grid->range_max, n,
+                               whole ? 0 : sf, whole ? 0 : sc, I_in, surface_T, abs_coef, trans, I_out);
 }
 
 extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const* trans, const double* layer_T,

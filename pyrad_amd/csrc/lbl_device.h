@@ -44,6 +44,18 @@ enum : int32_t {
 };
 
 // One accumulate job = one isotopologue of one layer (Isotope.createCrossSection).
+// Sweep of a single-isotopologue layer fused into the accumulate kernel's output stage
+// (lbl_layer_step_dev): the arithmetic of layer_sweep_kernel for n_iso = n_mol = 1.
+struct FusedSweep {
+    double conc, P, T, depth;
+    double start, stop, step;       // xAxis = linspace(start, stop, n)
+    double pa, pb, surface_T;
+    const double* I_in;
+    double* abs_coef; double* trans; double* I_out;
+    long long n;
+    int32_t on, pad;
+};
+
 struct AccumJob {
     const HotRec* hot;
     const ColdRec* cold;
@@ -63,6 +75,7 @@ struct AccumJob {
     // shard, 8 ints per span {iA, iB, iC, iD, iF1, iF2, 0, 0} (see wave_line_ranges[_far]); NULL:
     // the wave searches the centre indices itself
     const int32_t* span_tab;
+    FusedSweep fuse;       // fuse.on: sweep every point right after its cross section is final
 };
 
 // Balanced variant: spans (64*R consecutive grid points) of all jobs of a launch group are

@@ -807,6 +807,27 @@ __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec
     }
 }
 
+// One grid point of the fused layer sweep for a single-isotopologue layer: exactly the
+// arithmetic (and operation order) of layer_sweep_kernel with n_iso = n_mol = 1.
+__device__ __forceinline__ void fused_sweep_point(const FusedSweep& A, long long j, double xsec) {
+#pragma clang fp contract(off)
+    double xs = 0.0;
+    xs += xsec;
+    double kk = 0.0;
+    kk += xs * A.conc * A.P / 1E4 / kB / A.T;
+    if (A.abs_coef) A.abs_coef[j] = kk;
+    const double tr = exp(-kk * A.depth);
+    if (A.trans) A.trans[j] = tr;
+    if (A.I_out) {
+        const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
+        const double B = planck_wn(nu, A.T, A.pa, A.pb);
+        const double Iin = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.pa, A.pb);
+        const double transmitted = tr * Iin;
+        const double emitted = (1.0 - tr) * B;
+        A.I_out[j] = transmitted + emitted;
+    }
+}
+
 // LDS slot of grid-point offset o within a wave's span (padded so that a lane writing its R
 // consecutive points and a lane reading every 64th point are both nearly conflict-free)
 __device__ __forceinline__ int span_slot(int o) { return o + (o >> 4); }
@@ -918,7 +939,10 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
             const int o = i * 64 + lane;
             double t = mine[span_slot(o)];
             for (int q = 1; q < LS; ++q) t += s_stage[wave + q][span_slot(o)];
-            if (wlo + o < n_end) out[wlo + o] = t;
+            if (wlo + o < n_end) {
+                out[wlo + o] = t;
+                if (J.fuse.on) fused_sweep_point(J.fuse, wlo + o, t);
+            }
         }
     }
 }

@@ -178,7 +178,13 @@ class ResidentLayer:
                                  abs_coef=self.abs_coef, trans=self.trans,
                                  I_out=self.I_out if want_I else None, first=first, count=count)
 
-    def enqueue(self, surface_T=288.0, I_in=None):
+    def enqueue(self, surface_T=288.0, I_in=None, fused=True):
+        if fused and len(self.jobs) == 1 and not (self.world > 1 and self.count == 0):
+            # one line list: the sweep rides in the accumulate kernel's output stage
+            lines, iso, grid, xsec = self.jobs[0]
+            self.ctx.layer_step_dev(lines, iso, grid, xsec, self.conc[0], self.depth, I_in=I_in, surface_T=surface_T,
+                                    abs_coef=self.abs_coef, trans=self.trans, I_out=self.I_out)
+            return
         self.enqueue_xsec()
         self.enqueue_sweep(I_in=I_in, surface_T=surface_T)
 

@@ -463,3 +463,43 @@ def test_far_field_series_cases(ctx, orc):
         sl = slice(part.first, part.first + part.count)
         assert rel_err(part.xsec_host(0)[sl], ref[sl]) <= 1e-11
         part.free()
+
+
+def test_fused_layer_step_is_bit_identical(ctx, orc):
+    """lbl_layer_step_dev (sweep in the accumulate kernel's output stage) against the two-launch
+    path on the same resident layer: native 0.001 grid (fused), a dynamic-resolution layer that
+    needs the regrid kernel (falls back to two launches inside the entry point), a shard, and a
+    caller-supplied incoming spectrum."""
+    from pyrad_amd import engine
+    sp = synthetic.SPECIES["co2"]
+    for rmin, rmax, base, dyn, P in ((640, 660, .001, False, 1013.25), (600, 700, .01, True, 10132.5)):
+        g = orc.layer_grid(P, rmin, rmax, base, dyn)
+        lines = synthetic.make_lines(91, 900, g["eff_min"], g["eff_max"])
+        conc = orc.concentration(ppm=400)
+        mols = [dict(conc=conc, isotopologues=[dict(lines=lines, molmass=sp["molmass"],
+                                                    q_T=synthetic.q_value("co2", 280), q296=sp["q296"])])]
+        xa = orc.x_axis(rmin, rmax, base)
+        for shard in ((None, (3, 1)) if not dyn else (None,)):       # shards are cut on the work grid: no regrid there
+            L = engine.ResidentLayer(ctx, 12.5, 280, P, rmin, rmax, mols, base, dyn, shard=shard)
+            sl = slice(L.first, L.first + L.count) if shard else slice(0, L.n)
+            I0 = ctx.buffer(L.n).upload(np.linspace(0.1, 0.2, L.n))
+            for I_in in (None, I0):
+                L.enqueue(surface_T=288.0, I_in=I_in, fused=False)
+                two = {k: v[sl].copy() for k, v in L.results().items()}
+                xs_two = L.xsec_host(0)[sl].copy()
+                for b in (L.abs_coef, L.trans, L.I_out, L.jobs[0][3]):
+                    b.fill(0.0)
+                L.enqueue(surface_T=288.0, I_in=I_in, fused=True)
+                one = L.results()
+                assert np.array_equal(L.xsec_host(0)[sl], xs_two)
+                for k in two:
+                    assert np.array_equal(one[k][sl], two[k]), (k, rmin, shard, I_in is not None)
+            ref = orc.layer_properties(dict(depth=12.5, T=280, P=P, range_min=rmin, range_max=rmax, base_resolution=base,
+                                            dynamic_resolution=dyn,
+                                            molecules=[dict(species="co2", conc=dict(ppm=400), lines=lines)]))
+            ref_I = orc.transmission(ref["transmittance"], orc.planckWavenumber(xa, 288), orc.planckWavenumber(xa, 280))
+            L.enqueue(surface_T=288.0)
+            r = L.results()
+            check(r["abs_coef"][sl], ref["abs_coef"][sl])
+            check(r["transmission"][sl], ref_I[sl])
+            I0.free(); L.free()
