@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--line-split", type=int, default=None)
     ap.add_argument("--tile-order", type=int, default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
+    ap.add_argument("--column-layer-arrays", type=int, default=0,
+                    help="C5: 1 also writes every layer's absorption coefficient and transmittance arrays (default 0: "
+                         "the column step keeps them in registers and writes the outgoing spectrum only)")
     ap.add_argument("--longest-first", type=int, default=None, help="0: positional tile order, 1: longest-first worklist, 2: snake order, 3 (default): bin-packed per CU on single-round launches")
     ap.add_argument("--scale", type=int, default=1, help="experiment: widen the per-GPU range and line count by this factor")
     ap.add_argument("--lines", type=int, default=None, help="experiment: C2 with this many lines instead of 65,536")
@@ -241,7 +244,7 @@ def main():
             comm.fence_dev(k % n_sets)          # the gather that last used this set (step k-2) is done
         slot = (k % n_sets) if n_sets > 1 else None
         if is_column:
-            L.enqueue()
+            L.enqueue(layer_arrays=bool(args.column_layer_arrays))
             if comm is not None:
                 L.enqueue_allgather(comm, overlap_slot=slot)
         else:

@@ -206,6 +206,20 @@ int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const* trans, c
                          int64_t first, int64_t count,
                          lbl_buffer* I_in, double surface_T, lbl_buffer* I_out);
 
+/* Column step straight from the cross sections: for every grid point, layer after layer (bottom
+ * to top), the absorption coefficient and transmittance exactly as lbl_layer_sweep_dev computes
+ * them, then the fold of lbl_column_sweep_dev - one pass over the cross sections instead of one
+ * sweep launch per layer plus the fold.  Flattened per-layer inputs: layer l owns n_iso[l]
+ * consecutive entries of xsec / iso_mol (molecule index 0-based inside the layer, non-decreasing)
+ * and n_mol[l] consecutive entries of conc.  abs_coef / trans: NULL, or arrays of n_layers buffers
+ * of which any entry may be NULL (that layer's array is then not written). */
+int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_iso, lbl_buffer* const* xsec,
+                        const int32_t* iso_mol, const int32_t* n_mol, const double* conc,
+                        const double* P, const double* T, const double* depth,
+                        double range_min, double range_max, int64_t n, int64_t first, int64_t count,
+                        lbl_buffer* I_in, double surface_T,
+                        lbl_buffer* const* abs_coef, lbl_buffer* const* trans, lbl_buffer* I_out);
+
 /* Elementwise optical properties of a transmittance array (pyradClasses.py:73-76, 330-340,
  * 596-606, 718-732): kind 0 emissivity/emittance = 1 - T; 1 absorbance = log10(1/T);
  * 2 optical depth = -ln T. */

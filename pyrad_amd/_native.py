@@ -85,6 +85,9 @@ SIGNATURES = {
                                      _P, C.c_double, _P, _P, _P]),
     "lbl_column_sweep_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), _D, C.c_double, C.c_double, C.c_int64,
                                        C.c_int64, C.c_int64, _P, C.c_double, _P]),
+    "lbl_column_step_dev": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.POINTER(_P), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), _D, _D, _D, _D, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                                      C.c_int64, _P, C.c_double, C.POINTER(_P), C.POINTER(_P), _P]),
     "lbl_optical_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "lbl_sum_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.c_int64, _P]),
     "lbl_planck_dev": (C.c_int, [_P, C.c_double, C.c_double, C.c_int64, C.c_double, _P]),
@@ -287,6 +290,24 @@ class Context:
         h = lambda b: b.h if b is not None else None
         self.check(self.lib.lbl_layer_step_dev(self.h, lines.h, C.byref(iso), C.byref(grid), xsec.h, float(conc),
                                                float(depth), h(I_in), float(surface_T), h(abs_coef), h(trans), h(I_out)))
+
+    def column_step_dev(self, layers, range_min, range_max, n, I_out, I_in=None, surface_T=0.0, first=0, count=0):
+        """layers: bottom to top, each dict(xsec=[Buffer], iso_mol=[int], conc=[float], P, T, depth,
+        trans=Buffer|None, abs_coef=Buffer|None)."""
+        nl = len(layers)
+        xs = [b for L in layers for b in L["xsec"]]
+        im = [int(m) for L in layers for m in L["iso_mol"]]
+        cc = [float(c) for L in layers for c in L["conc"]]
+        arr = lambda typ, vals: (typ * max(len(vals), 1))(*vals)
+        n_iso = arr(C.c_int32, [len(L["xsec"]) for L in layers])
+        n_mol = arr(C.c_int32, [len(L["conc"]) for L in layers])
+        hb = lambda b: b.h if b is not None else None
+        self.check(self.lib.lbl_column_step_dev(
+            self.h, nl, n_iso, arr(_P, [b.h for b in xs]), arr(C.c_int32, im), n_mol, arr(C.c_double, cc),
+            arr(C.c_double, [float(L["P"]) for L in layers]), arr(C.c_double, [float(L["T"]) for L in layers]),
+            arr(C.c_double, [float(L["depth"]) for L in layers]), float(range_min), float(range_max), int(n),
+            int(first), int(count), hb(I_in), float(surface_T),
+            arr(_P, [hb(L.get("abs_coef")) for L in layers]), arr(_P, [hb(L.get("trans")) for L in layers]), I_out.h))
 
     def column_sweep_dev(self, trans, layer_T, range_min, range_max, n, I_out, I_in=None, surface_T=0.0,
                          first=0, count=0):

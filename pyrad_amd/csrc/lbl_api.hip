@@ -1097,6 +1097,64 @@ extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* cons
     return LBL_OK;
 }
 
+extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_iso, lbl_buffer* const* xsec,
+                                   const int32_t* iso_mol, const int32_t* n_mol, const double* conc, const double* P,
+                                   const double* T, const double* depth, double range_min, double range_max, int64_t n,
+                                   int64_t first, int64_t count, lbl_buffer* I_in, double surface_T,
+                                   lbl_buffer* const* abs_coef, lbl_buffer* const* trans, lbl_buffer* I_out) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (n_layers < 0 || n_layers > kMaxLayers) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d layers", kMaxLayers);
+    if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
+    if (first < 0 || count < 0 || first + count > n) return fail(ctx, LBL_ERR_BAD_ARG, "swept range outside [0, n)");
+    if (count == 0) { first = 0; count = n; }
+    if (n_layers > 0 && (!n_iso || !n_mol || !P || !T || !depth)) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    int rc;
+    if ((rc = check_buf(ctx, I_out, n, "I_out", true))) return rc;
+    if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
+    if (!I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "need I_in or surface_T > 0");
+    void* stage = nullptr;
+    if ((rc = stage_alloc(ctx, sizeof(ColumnStepArgs), &stage))) return rc;
+    if ((rc = arena_reserve(ctx, ctx->colargs, sizeof(ColumnStepArgs)))) return rc;
+    ColumnStepArgs* a = (ColumnStepArgs*)stage;
+    memset(a, 0, sizeof *a);
+    int iso0 = 0, mol0 = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (n_iso[l] < 0 || n_mol[l] < 0 || iso0 + n_iso[l] > kMaxColumnIso || mol0 + n_mol[l] > kMaxColumnIso)
+            return fail(ctx, LBL_ERR_BAD_ARG, "at most %d isotopologues per column", kMaxColumnIso);
+        if (!(T[l] > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "layer %d: T must be > 0", l);
+        if ((n_iso[l] > 0 && (!xsec || !iso_mol)) || (n_mol[l] > 0 && !conc)) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+        a->layer_iso0[l] = iso0; a->layer_mol0[l] = mol0;
+        for (int i = 0; i < n_iso[l]; ++i) {
+            if ((rc = check_buf(ctx, xsec[iso0 + i], n, "xsec", true))) return rc;
+            const int32_t m = iso_mol[iso0 + i];
+            if (m < 0 || m >= n_mol[l] || (i > 0 && m < iso_mol[iso0 + i - 1]))
+                return fail(ctx, LBL_ERR_BAD_ARG, "layer %d: iso_mol must be non-decreasing and < n_mol", l);
+            a->xsec[iso0 + i] = xsec[iso0 + i]->d;
+            a->iso_mol[iso0 + i] = m;
+        }
+        for (int m = 0; m < n_mol[l]; ++m) a->conc[mol0 + m] = conc[mol0 + m];
+        a->P[l] = P[l]; a->T[l] = T[l]; a->depth[l] = depth[l];
+        if (abs_coef && abs_coef[l]) { if ((rc = check_buf(ctx, abs_coef[l], n, "abs_coef", true))) return rc; a->abs_coef[l] = abs_coef[l]->d; }
+        if (trans && trans[l]) { if ((rc = check_buf(ctx, trans[l], n, "trans", true))) return rc; a->trans[l] = trans[l]->d; }
+        iso0 += n_iso[l]; mol0 += n_mol[l];
+    }
+    a->layer_iso0[n_layers] = iso0; a->layer_mol0[n_layers] = mol0;
+    a->n_layers = n_layers;
+    a->start = range_min; a->stop = range_max; a->step = axis_step(range_min, range_max, n);
+    planck_constants(&a->pa, &a->pb);
+    a->surface_T = surface_T;
+    a->I_in = I_in ? I_in->d : nullptr;
+    a->I_out = I_out->d;
+    a->n = n; a->first = first; a->count = count;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->colargs.ptr, a, sizeof(ColumnStepArgs), hipMemcpyHostToDevice, ctx->stream));
+    hipEvent_t ev = prof_begin(ctx, PROF_COLUMN);
+    launch_column_step((const ColumnStepArgs*)ctx->colargs.ptr, count, ctx->stream);
+    prof_end(ctx, PROF_COLUMN, ev);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBL_OK;
+}
+
 extern "C" int lbl_sum_dev(lbl_ctx* ctx, int n_in, lbl_buffer* const* in, int64_t n, lbl_buffer* out) {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (n_in < 0 || n_in > kMaxIso) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d inputs", kMaxIso);

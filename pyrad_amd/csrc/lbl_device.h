@@ -113,6 +113,24 @@ struct SweepArgs {
     long long first, count;         // swept sub-range
 };
 constexpr int kMaxLayers = 128;
+constexpr int kMaxColumnIso = 512;      // isotopologue cross sections of a whole column
+// Column step from the cross sections: per layer the arithmetic of layer_sweep_kernel (absorption
+// coefficient, transmittance), folded bottom to top like column_sweep_kernel, in one pass.
+struct ColumnStepArgs {
+    const double* xsec[kMaxColumnIso];
+    int32_t iso_mol[kMaxColumnIso];     // molecule of the isotopologue, 0-based inside its layer
+    double conc[kMaxColumnIso];         // [layer_mol0[l] + m]
+    int32_t layer_iso0[kMaxLayers + 1]; // isotopologues of layer l: [layer_iso0[l], layer_iso0[l+1])
+    int32_t layer_mol0[kMaxLayers + 1];
+    double P[kMaxLayers], T[kMaxLayers], depth[kMaxLayers];
+    double* trans[kMaxLayers];          // optional per-layer transmittance outputs
+    double* abs_coef[kMaxLayers];       // optional per-layer absorption coefficients
+    int32_t n_layers;
+    double start, stop, step, pa, pb, surface_T;
+    const double* I_in; double* I_out;
+    long long n;
+    long long first, count;
+};
 struct ColumnArgs {
     const double* trans[kMaxLayers];
     double layer_T[kMaxLayers];
@@ -137,6 +155,7 @@ void launch_accumulate_balanced(const AccumJob* d_jobs, int n_jobs, int total_sp
 void launch_regrid(const double* work, long long n_work, double* out, long long n_base, double start, double stop,
                    hipStream_t s);
 void launch_layer_sweep(const SweepArgs& a, hipStream_t s);
+void launch_column_step(const ColumnStepArgs* d_args, long long count, hipStream_t s);
 void launch_column_sweep(const ColumnArgs* d_args, long long n, hipStream_t s);
 void launch_planck(double* out, long long n, double start, double stop, double T, double pa, double pb, hipStream_t s);
 int band_partial_count(long long n);

@@ -1266,6 +1266,40 @@ __global__ __launch_bounds__(256) void column_sweep_kernel(const ColumnArgs* __r
     }
 }
 
+// K5b: column step straight from the cross sections.  For every grid point the layers are visited
+// bottom to top: absorption coefficient and transmittance exactly as layer_sweep_kernel computes
+// them, then the fold of column_sweep_kernel.  One pass over the cross sections replaces one sweep
+// launch per layer plus the fold, and the per-layer arrays are written only if asked for.
+__global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* __restrict__ Ap) {
+#pragma clang fp contract(off)
+    const ColumnStepArgs& A = *Ap;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long jend = A.first + A.count;
+    for (long long j = A.first + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < jend; j += stride) {
+        const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
+        double I = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.pa, A.pb);
+        for (int l = 0; l < A.n_layers; ++l) {
+            double kk = 0.0;
+            int i = A.layer_iso0[l];
+            const int iend = A.layer_iso0[l + 1];
+            const int n_mol = A.layer_mol0[l + 1] - A.layer_mol0[l];
+            for (int m = 0; m < n_mol; ++m) {
+                double xs = 0.0;
+                while (i < iend && A.iso_mol[i] == m) { xs += A.xsec[i][j]; ++i; }
+                kk += xs * A.conc[A.layer_mol0[l] + m] * A.P[l] / 1E4 / kB / A.T[l];
+            }
+            if (A.abs_coef[l]) A.abs_coef[l][j] = kk;
+            const double tr = exp(-kk * A.depth[l]);
+            if (A.trans[l]) A.trans[l][j] = tr;
+            const double B = planck_wn(nu, A.T[l], A.pa, A.pb);
+            const double transmitted = tr * I;
+            const double emitted = (1.0 - tr) * B;
+            I = transmitted + emitted;
+        }
+        A.I_out[j] = I;
+    }
+}
+
 __global__ __launch_bounds__(256) void planck_kernel(double* __restrict__ out, long long n, double start,
                                                      double stop, double step, double T, double pa, double pb) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1424,6 +1458,11 @@ static int sweep_blocks(long long n) {
 void launch_layer_sweep(const SweepArgs& a, hipStream_t s) {
     if (a.count <= 0) return;
     hipLaunchKernelGGL(layer_sweep_kernel, dim3(sweep_blocks(a.count)), dim3(256), 0, s, a);
+}
+
+void launch_column_step(const ColumnStepArgs* d_args, long long count, hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(column_step_kernel, dim3(sweep_blocks(count)), dim3(256), 0, s, d_args);
 }
 
 void launch_column_sweep(const ColumnArgs* d_args, long long count, hipStream_t s) {

@@ -238,11 +238,23 @@ class ResidentColumn:
         self.evals = sum(L.evals for L in self.layers)
         self.n_lines = sum(L.n_lines for L in self.layers)
 
-    def enqueue(self):
+    def enqueue(self, layer_arrays=True, fused=True):
+        """One column step.  ``fused``: a single pass over all cross sections (lbl_column_step_dev)
+        instead of one sweep per layer plus the fold; ``layer_arrays`` False skips writing the
+        per-layer absorption coefficient / transmittance arrays (only the outgoing spectrum)."""
         self.ctx.xsec_accumulate_dev(self.jobs)
+        first, count = (0, 0) if self.world == 1 else (self.first, self.count)
+        if fused:
+            if self.world > 1 and self.count == 0:
+                return
+            desc = [dict(xsec=[j[3] for j in L.jobs], iso_mol=L.iso_mol, conc=L.conc, P=L.P, T=L.T, depth=L.depth,
+                         trans=L.trans if layer_arrays else None, abs_coef=L.abs_coef if layer_arrays else None)
+                    for L in self.layers]
+            self.ctx.column_step_dev(desc, self.layers[0].range_min, self.layers[0].range_max, self.n, self.I_toa,
+                                     surface_T=self.surface_T, first=first, count=count)
+            return
         for L in self.layers:
             L.enqueue_sweep(want_I=False)
-        first, count = (0, 0) if self.world == 1 else (self.first, self.count)
         if self.world > 1 and self.count == 0:
             return
         self.ctx.column_sweep_dev([L.trans for L in self.layers], [L.T for L in self.layers],

@@ -366,6 +366,19 @@ def test_resident_column_c5_shape_vs_oracle(ctx, orc):
     xa = orc.x_axis(650, 662, .001)
     check(got["toa"], orc.column_transmission(trs, Ts, xa, col["surface_T"]))
     assert column.evals == sum(L.evals for L in column.layers) > 0
+    # the one-pass column step (default) against one sweep per layer + fold: same bits; and
+    # without materialising the per-layer arrays
+    column.enqueue(fused=False)
+    two = column.results()
+    assert np.array_equal(two["toa"], got["toa"])
+    for a, b in zip(two["transmittance"], got["transmittance"]):
+        assert np.array_equal(a, b)
+    for L in column.layers:
+        L.trans.fill(-1.0)
+    column.I_toa.fill(0.0)
+    column.enqueue(layer_arrays=False)
+    lean = column.results()
+    assert np.array_equal(lean["toa"], got["toa"]) and np.all(lean["transmittance"][0] == -1.0)
     # sharded by grid range (3 ranks on this one GPU): same spectrum
     toa = np.zeros(column.n)
     for rank in range(3):
