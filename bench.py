@@ -320,12 +320,23 @@ def main():
         # algorithmic bytes per launch of the dominant kernel: every line's 7 fp64
         # HITRAN fields once + every grid point written once
         balg_acc = 56.0 * layer.n_lines + 8.0 * pts
+        fused_sweep = (not is_column) and len(layer.jobs) == 1      # lbl_layer_step_dev: k, T, I_out leave K2 too
+        if fused_sweep:
+            balg_acc += 24.0 * pts
         t_acc = (ms_acc / max(n_acc, 1)) * 1e-3
         t_acc_step = (ms_acc / max(args.steps, 1)) * 1e-3       # all K2 launches of one step
         achieved = balg_acc / t_acc / 1e9 if t_acc > 0 else 0.0
         n_mol_arrays = len(layer.layers[0].jobs) if is_column else len(layer.jobs)
         # per sweep launch: M xsec reads + k, T (, I_out) writes; I_in is computed in-kernel
         balg_sw = 8.0 * pts * (n_mol_arrays + (2 if is_column else 3))
+        sweep_kernel = "layer_sweep_kernel"
+        if is_column:
+            # one column_step_kernel launch per step: every layer's cross sections read once, the outgoing
+            # spectrum written (+ two arrays per layer when --column-layer-arrays 1)
+            n_sw, ms_sw = prof["column_sweep"]
+            n_layers = len(layer.layers)
+            balg_sw = 8.0 * pts * (n_mol_arrays * n_layers + 1 + (2 * n_layers if args.column_layer_arrays else 0))
+            sweep_kernel = "column_step_kernel"
         if is_column:
             balg_acc = balg_acc / max(n_acc // max(args.steps, 1), 1)     # K2 is launched once per window group
         t_sw = (ms_sw / max(n_sw, 1)) * 1e-3
@@ -344,16 +355,19 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc.get("xsec_accumulate_kernel"),
                          "algorithmic_bytes_per_launch": balg_acc, "avg_launch_ms": t_acc * 1e3, "launches": n_acc,
-                         "note": "compulsory traffic only (56 B/line + 8 B/grid point): this kernel is fp64-VALU "
-                                 "bound by construction (SURVEY.md §8d), see valu_f64"},
+                         "note": "compulsory traffic only (56 B/line + 8 B/grid point, + 24 B/grid point when the layer "
+                                 "sweep is fused in): this kernel is fp64-VALU bound by construction (SURVEY.md §8d), "
+                                 "see valu_f64"},
             "valu_f64": valu_block(evals_local, t_acc_step, direct_ms, args.variant),
-            "roofline_sweep": {"bound": "hbm", "kernel": "layer_sweep_kernel",
+            "roofline_sweep": {"fused_into": "xsec_accumulate_lds_kernel (lbl_layer_step_dev)"} if n_sw == 0 and not is_column else
+                              {"bound": "hbm", "kernel": sweep_kernel,
                                "achieved": balg_sw / t_sw / 1e9 if t_sw > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": (balg_sw / t_sw / 1e9 / HBM_PEAK_GBS) if t_sw > 0 else 0.0,
-                               "traffic": pmc.get("layer_sweep_kernel"),
+                               "traffic": pmc.get(sweep_kernel),
                                "algorithmic_bytes_per_launch": balg_sw, "avg_launch_ms": t_sw * 1e3, "launches": n_sw},
             "kernel_ms_per_step": {"line_prep": ms_prep / args.steps, "xsec_accumulate": ms_acc / args.steps,
-                                   "layer_sweep": ms_sw / args.steps, "allgather": ms_ag / args.steps},
+                                   ("column_step" if is_column else "layer_sweep"): ms_sw / args.steps,
+                                   "allgather": ms_ag / args.steps},
             "setup_s": t_setup,
         }
         if not args.no_cpu_baseline and world == 1:
