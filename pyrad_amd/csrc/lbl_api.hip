@@ -1149,7 +1149,7 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->colargs.ptr, a, sizeof(ColumnStepArgs), hipMemcpyHostToDevice, ctx->stream));
     hipEvent_t ev = prof_begin(ctx, PROF_COLUMN);
-    launch_column_step((const ColumnStepArgs*)ctx->colargs.ptr, count, ctx->stream);
+    launch_column_step((const ColumnStepArgs*)ctx->colargs.ptr, count, ctx->stream, (first & 1) == 0);
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;

@@ -1270,33 +1270,64 @@ __global__ __launch_bounds__(256) void column_sweep_kernel(const ColumnArgs* __r
 // bottom to top: absorption coefficient and transmittance exactly as layer_sweep_kernel computes
 // them, then the fold of column_sweep_kernel.  One pass over the cross sections replaces one sweep
 // launch per layer plus the fold, and the per-layer arrays are written only if asked for.
+// NP grid points per thread (2: 16-byte loads, two independent fold chains in flight).
+template <int NP>
 __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* __restrict__ Ap) {
 #pragma clang fp contract(off)
     const ColumnStepArgs& A = *Ap;
-    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long stride = (long long)gridDim.x * blockDim.x * NP;
     const long long jend = A.first + A.count;
-    for (long long j = A.first + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < jend; j += stride) {
-        const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
-        double I = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.pa, A.pb);
+    for (long long j0 = A.first + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * NP; j0 < jend; j0 += stride) {
+        double nu[NP], I[NP];
+        bool live[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            live[p] = j0 + p < jend;
+            const long long j = live[p] ? j0 + p : j0;
+            nu[p] = linspace_at(j, A.n, A.start, A.stop, A.step);
+            I[p] = A.I_in ? A.I_in[j] : planck_wn(nu[p], A.surface_T, A.pa, A.pb);
+        }
+        const bool pair = NP == 2 && live[NP - 1];
         for (int l = 0; l < A.n_layers; ++l) {
-            double kk = 0.0;
+            double kk[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) kk[p] = 0.0;
             int i = A.layer_iso0[l];
             const int iend = A.layer_iso0[l + 1];
             const int n_mol = A.layer_mol0[l + 1] - A.layer_mol0[l];
             for (int m = 0; m < n_mol; ++m) {
-                double xs = 0.0;
-                while (i < iend && A.iso_mol[i] == m) { xs += A.xsec[i][j]; ++i; }
-                kk += xs * A.conc[A.layer_mol0[l] + m] * A.P[l] / 1E4 / kB / A.T[l];
+                double xs[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) xs[p] = 0.0;
+                while (i < iend && A.iso_mol[i] == m) {
+                    if (pair) {
+                        const double2 v = *reinterpret_cast<const double2*>(A.xsec[i] + j0);
+                        xs[0] += v.x; xs[NP - 1] += v.y;
+                    } else {
+                        xs[0] += A.xsec[i][j0];
+                    }
+                    ++i;
+                }
+                const double f = A.conc[A.layer_mol0[l] + m];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) kk[p] += xs[p] * f * A.P[l] / 1E4 / kB / A.T[l];
             }
-            if (A.abs_coef[l]) A.abs_coef[l][j] = kk;
-            const double tr = exp(-kk * A.depth[l]);
-            if (A.trans[l]) A.trans[l][j] = tr;
-            const double B = planck_wn(nu, A.T[l], A.pa, A.pb);
-            const double transmitted = tr * I;
-            const double emitted = (1.0 - tr) * B;
-            I = transmitted + emitted;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (!live[p]) continue;
+                const long long j = j0 + p;
+                if (A.abs_coef[l]) A.abs_coef[l][j] = kk[p];
+                const double tr = exp(-kk[p] * A.depth[l]);
+                if (A.trans[l]) A.trans[l][j] = tr;
+                const double B = planck_wn(nu[p], A.T[l], A.pa, A.pb);
+                const double transmitted = tr * I[p];
+                const double emitted = (1.0 - tr) * B;
+                I[p] = transmitted + emitted;
+            }
         }
-        A.I_out[j] = I;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            if (live[p]) A.I_out[j0 + p] = I[p];
     }
 }
 
@@ -1460,9 +1491,13 @@ void launch_layer_sweep(const SweepArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(layer_sweep_kernel, dim3(sweep_blocks(a.count)), dim3(256), 0, s, a);
 }
 
-void launch_column_step(const ColumnStepArgs* d_args, long long count, hipStream_t s) {
+void launch_column_step(const ColumnStepArgs* d_args, long long count, hipStream_t s, bool aligned2) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(column_step_kernel, dim3(sweep_blocks(count)), dim3(256), 0, s, d_args);
+    if (aligned2) {      // first point even: two points per thread with 16-byte loads
+        hipLaunchKernelGGL(column_step_kernel<2>, dim3(sweep_blocks((count + 1) / 2)), dim3(256), 0, s, d_args);
+        return;
+    }
+    hipLaunchKernelGGL(column_step_kernel<1>, dim3(sweep_blocks(count)), dim3(256), 0, s, d_args);
 }
 
 void launch_column_sweep(const ColumnArgs* d_args, long long count, hipStream_t s) {
