@@ -206,7 +206,9 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t* __restrict__ a, in
     return lo;
 }
 
-// exp(x) for -800 <= x <= 700 without the range tests of the library routine (22 -> 17 instructions):
+// exp(x) for x <= 700 without the range tests of the library routine (22 -> 17 instructions); exact
+// to the library's accuracy for x >= -745, 0 (through v_ldexp_f64) below, finite garbage-free
+// down to about -1e18, so callers clamp only when their argument can be more extreme:
 // n = rint(x log2 e), r = x - n ln2 (two-part), degree-11 polynomial on |r| <= ln2/2 (the
 // coefficients of the ROCm device library's double-precision exp), scaled by 2^n with v_ldexp_f64,
 // which also delivers the gradual underflow.  Callers clamp the argument.
@@ -250,8 +252,11 @@ __device__ __forceinline__ void gauss_term(double KG, double b, bool recur, doub
             acc[k] += (!MASKED || fabs(d) <= Hf) ? t : 0.0;
         }
     } else {
-        double g = KG * exp_clamped(fmax(-b * (d0 * d0), -800.0));
-        double rr = exp_clamped(fmax(fmin(-b * (2.0 * d0 + 1.0), 700.0), -800.0));
+        // b <= 4 and |d0| < 2^31 here: the arguments stay far inside the range where the reduction of
+        // exp_clamped is finite (a hopeless argument only has to underflow to 0); only the growth of r
+        // towards the centre needs its cap
+        double g = KG * exp_clamped(-b * (d0 * d0));
+        double rr = exp_clamped(fmin(-b * (2.0 * d0 + 1.0), 700.0));
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             if (MASKED) {
