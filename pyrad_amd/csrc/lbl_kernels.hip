@@ -22,6 +22,7 @@
 // The kernel is fp64-VALU bound (about 5 fp64 instructions per line x grid-point pair), not
 // HBM bound: its compulsory traffic is 64 B per line and 8 B per grid point.
 #include "lbl_device.h"
+#include <cstdlib>
 
 namespace lbl {
 
@@ -518,15 +519,17 @@ __device__ __forceinline__ HotVals lds_hot(const double* __restrict__ lh, int j)
 // plain-divide lines are handled after the chunk from bit masks, so the hot loop has no branch.
 template <int R, bool MASKED>
 __device__ __forceinline__ void rf_segment(const double* __restrict__ lh, int j0, int j1, double x0, double Hf,
-                                           WaveAcc<R>& S) {
-    int j = j0;
+                                           WaveAcc<R>& S, int step = 1, int phase = 0) {
+    // records j0 <= j < j1 with j % step == phase (step = line split of the span, a power of two)
+    int j = j0 + ((phase - j0) & (step - 1));
     while (j < j1) {
-        const int nb = min(S.every - S.cnt, j1 - j);
+        const int left = (j1 - j + step - 1) / step;
+        const int nb = min(S.every - S.cnt, left);
         HotVals nxt = lds_hot(lh, j);
 #pragma unroll 2
         for (int t = 0; t < nb; ++t) {
             const HotVals cur = nxt;
-            nxt = lds_hot(lh, min(j + t + 1, 63));
+            nxt = lds_hot(lh, min(j + (t + 1) * step, 63));
             const double d0 = x0 - cur.cf;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
@@ -539,7 +542,7 @@ __device__ __forceinline__ void rf_segment(const double* __restrict__ lh, int j0
                 S.D[k] *= den;
             }
         }
-        j += nb;
+        j += nb * step;
         S.cnt += nb;
         if (S.cnt >= S.every) S.flush();
     }
@@ -606,7 +609,12 @@ __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, cons
 template <int R>
 __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRec* cold, int mA, int mD, int iB, int iC,
                                                  int wlo, int whi, double x0, double Hf, double* lh, double* lc, int lane,
-                                                 WaveAcc<R>& S, int stride = 64) {
+                                                 WaveAcc<R>& S, int stride = 64, int step = 1, int phase = 0) {
+    // step > 1 (with stride = 64): every wave of the span walks ALL chunks but takes only the records
+    // j % step == phase of each, so the split is exact to a line.  Dealing whole chunks left one wave
+    // of a two-way split with 128 of a span's ~210 near lines and the other with 82.
+    const unsigned long long stripe = step == 1 ? ~0ull : step == 2 ? (0x5555555555555555ull << phase)
+                                    : step == 4 ? (0x1111111111111111ull << phase) : (0x0101010101010101ull << phase);
     // global address space made explicit: a flat load would also count on lgkmcnt and every
     // LDS wait would then drain the prefetch of the next chunk
     typedef double v2f64 __attribute__((ext_vector_type(2)));
@@ -626,10 +634,11 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
         const int ci = (int)h0.x;
         const int dgi = __double2loint(h1.y), fl = __double2hiint(h1.y);
         const bool valid = c0 + lane < c1;
-        const bool gauss = valid && max(0, max(ci - whi, wlo - ci)) < dgi;
+        const bool mine = (stripe >> lane) & 1ull;
+        const bool gauss = valid && mine && max(0, max(ci - whi, wlo - ci)) < dgi;
         const bool direct = valid && (fl & REC_DIRECT_DIV) != 0;
         const unsigned long long gmask = __ballot(gauss);
-        const unsigned long long dmask = __ballot(direct);
+        const unsigned long long dmask = __ballot(direct) & stripe;
         const unsigned long long emask = __ballot((fl & REC_NO_RECUR) != 0);
         v2f64 w0 = h0, w1 = h1;
         if (direct) { w0.y = 1.0; w1.x = 0.0; }          // a2 = 1, KL = 0 in the hot loop's copy
@@ -640,7 +649,7 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
         // cold halves only for the records that will use them (about one in eight); they
         // land while the Lorentz loop below runs
         v2f64 c0v = {0, 0}, c1v = {0, 0};
-        if (gauss || direct) {
+        if (gauss || (direct && mine)) {
             const long long r = (long long)(c0 + lane) * 2;
             c0v = gc[r]; c1v = gc[r + 1];
         }
@@ -652,11 +661,11 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
         const int a0 = 0, a1 = max(min(iB, c1), c0) - c0;
         const int b1 = max(min(iC, c1), c0) - c0;
         const int e1 = c1 - c0;
-        rf_segment<R, true>(lh, a0, a1, x0, Hf, S);
-        rf_segment<R, false>(lh, a1, b1, x0, Hf, S);
-        rf_segment<R, true>(lh, b1, e1, x0, Hf, S);
+        rf_segment<R, true>(lh, a0, a1, x0, Hf, S, step, phase);
+        rf_segment<R, false>(lh, a1, b1, x0, Hf, S, step, phase);
+        rf_segment<R, true>(lh, b1, e1, x0, Hf, S, step, phase);
         if (gmask | dmask) {
-            if (gauss || direct) {
+            if (gauss || (direct && mine)) {
                 reinterpret_cast<v2f64*>(lc)[lane * 2] = c0v;
                 reinterpret_cast<v2f64*>(lc)[lane * 2 + 1] = c1v;
             }
@@ -919,11 +928,11 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         }
         // the direct classes: left-edge, near and right-edge lines.  Without far lines (narrow window)
         // they are one contiguous run and go through the first stream alone (one prologue, not three).
-        const int s0 = iA + (any_far ? ((part + 3) % LS) : part) * 64;
-        accumulate_lines<R>(J.hot, J.cold, s0, any_far ? iB : iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
+        // (the LS waves of a span interleave these classes line by line; series chunks are dealt whole)
+        accumulate_lines<R>(J.hot, J.cold, iA, any_far ? iB : iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64, LS, part);
         if (any_far) {
-            accumulate_lines<R>(J.hot, J.cold, iF1 + part * 64, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
-            accumulate_lines<R>(J.hot, J.cold, iC + ((part + 2) % LS) * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
+            accumulate_lines<R>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64, LS, part);
+            accumulate_lines<R>(J.hot, J.cold, iC, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64, LS, part);
         }
         S.flush();
     }
@@ -1428,11 +1437,13 @@ static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, 
         if (total_tiles <= 0) return;
         grid = dim3(total_tiles, 1);
     }
+    // diagnostics only (scripts/cost_fit.py): unused dynamic LDS to limit the workgroups resident per CU
+    static const int pad = getenv("LBL_DIAG_LDS_PAD") ? atoi(getenv("LBL_DIAG_LDS_PAD")) : 0;
     switch (LS) {
-        case 8: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 8, FF>), grid, dim3(512), 0, s, d_jobs, worklist); break;
-        case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4, FF>), grid, dim3(256), 0, s, d_jobs, worklist); break;
-        case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2, FF>), grid, dim3(256), 0, s, d_jobs, worklist); break;
-        default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1, FF>), grid, dim3(256), 0, s, d_jobs, worklist); break;
+        case 8: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 8, FF>), grid, dim3(512), pad, s, d_jobs, worklist); break;
+        case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
+        case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
+        default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
     }
 }
 

@@ -14,16 +14,24 @@ import sys
 T = sys.argv[1]
 p = T + '/pyrad_amd/csrc/lbl_kernels.hip'
 s = open(p).read()
-s = s.replace("template <int R, int LS>\n__global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_kernel",
-              "__device__ unsigned long long g_dbg[4 * 65536 * 3];\n\ntemplate <int R, int LS>\n__global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_lds_kernel")
+head = "#ifndef LBL_FF_MIN_WAVES"
+if head not in s:
+    head = "template <int R, int LS, bool FF = false>\n__global__"
+assert head in s
+s = s.replace(head, "__device__ unsigned long long g_dbg[4 * 65536 * 3];\n\n" + head, 1)
 s = s.replace("    int job = blockIdx.y, tile;\n", "    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();\n    int job = blockIdx.y, tile;\n", 1)
-marker = "            if (wlo + o < n_end) out[wlo + o] = t;\n        }\n    }\n}\n"
+marker = """                if (J.fuse.on) fused_sweep_point(J.fuse, wlo + o, t);
+            }
+        }
+    }
+}
+"""
 assert marker in s
 s = s.replace(marker, marker[:-2] + '''    if (lane == 0 && blockIdx.x < 65536) {
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const size_t k = ((size_t)blockIdx.x * 4 + wave) * 3;
+        const size_t k = ((size_t)blockIdx.x * 4 + (wave & 3)) * 3;
         g_dbg[k] = t_start; g_dbg[k + 1] = __builtin_amdgcn_s_memrealtime(); g_dbg[k + 2] = ((unsigned long long)xcc << 32) | hwid;
     }
 }

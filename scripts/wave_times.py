@@ -17,7 +17,7 @@ L = engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"]
 for _ in range(3):
     L.enqueue_xsec()
 ctx.sync()
-nb = 8 * ((L.n // (64 * int(os.environ.get("R", "2")) * (4 // int(os.environ.get("LS", "4")))) + 8) // 8)
+nb = 8 * ((L.n // (64 * int(os.environ.get("R", "4")) * (4 // int(os.environ.get("LS", "2")))) + 8) // 8)
 n = nb * 4 * 3
 buf = (C.c_uint64 * n)()
 ctx.lib.lbl_debug_times.restype = C.c_int
@@ -47,3 +47,30 @@ u, c = np.unique(cuid, return_counts=True)
 print("distinct CUs", len(u), "waves per CU min/median/max", c.min(), int(np.median(c)), c.max())
 last = np.array([end[cuid == x].max() for x in u])
 print("per-CU finish time percentiles", np.percentile(last, [0, 10, 50, 90, 100]).round(1))
+
+# dispatch: does every tier of n_cu consecutive workgroups (worklist order) land on distinct CUs?
+wg_cu = cuid.reshape(-1, 4)[:, 0] if len(cuid) % 4 == 0 else None
+if wg_cu is not None:
+    ncu = len(u)
+    tiers = [wg_cu[i:i + ncu] for i in range(0, len(wg_cu), ncu)]
+    print("tiers of", ncu, "workgroups -> distinct CUs per tier:", [len(set(t.tolist())) for t in tiers])
+    per_cu_wgs = np.array([np.sum(wg_cu == x) for x in u])
+    print("workgroups per CU min/median/max", per_cu_wgs.min(), int(np.median(per_cu_wgs)), per_cu_wgs.max())
+busy = np.array([np.sum((end - start)[cuid == x]) for x in u]) / 4.0     # wave-us per SIMD of the CU
+print("per-CU resident wave time / 4 SIMDs: percentiles", np.percentile(busy, [0, 10, 50, 90, 100]).round(1))
+# SIMD level: how many waves does each SIMD hold, and when does it finish?
+sid = cuid * 4 + simd
+us, cs = np.unique(sid, return_counts=True)
+print("SIMDs used", len(us), "waves per SIMD histogram", dict(zip(*np.unique(cs, return_counts=True))))
+fin = np.array([end[sid == x].max() for x in us])
+print("per-SIMD finish time percentiles", np.percentile(fin, [0, 10, 50, 90, 100]).round(1))
+for k in sorted(set(cs.tolist())):
+    f = fin[cs == k]
+    print("  SIMDs with %d waves: %4d, finish median %.1f max %.1f" % (k, len(f), np.median(f), f.max()))
+work = end - start
+tot = np.array([work[sid == x].sum() for x in us])
+print("sum of wave durations per SIMD percentiles", np.percentile(tot, [0, 10, 50, 90, 100]).round(1))
+for x in sorted(set(xcc.tolist())):
+    m = xcc == x
+    print("XCC %d: waves %4d, wave duration median %.1f, finish median %.1f max %.1f, sum of durations %.0f"
+          % (x, m.sum(), np.median(work[m]), np.median(end[m]), end[m].max(), work[m].sum()))
