@@ -953,11 +953,21 @@ class Atmosphere(list):
         ctx = _ctx()
         n = int((first.rangeMax - first.rangeMin) / utils.BASE_RESOLUTION)
         _compute_cross_sections([iso for L in layers for m in L for iso in m])
-        trans, tmp = [], []
+        for L in layers:
+            for m in L:
+                if not m.progressCrossSection:
+                    m.createCrossSection()
+        # one pass over every layer's device-resident cross sections (lbl_column_step_dev)
+        desc = []
+        for L in layers:
+            xs, iso_mol = [], []
+            for k, m in enumerate(L):
+                for iso in m._members():
+                    xs.append(iso._device_xsec_current(ctx, n))
+                    iso_mol.append(k)
+            desc.append(dict(xsec=xs, iso_mol=iso_mol, conc=[m.concentration for m in L], P=L.P, T=L.T, depth=L.depth))
+        tmp = []
         try:
-            for L in layers:
-                t = ctx.buffer(max(n, 1)).upload(L.transmittance)
-                trans.append(t); tmp.append(t)
             out = ctx.buffer(max(n, 1)); tmp.append(out)
             I_in = None
             if surfaceSpectrum is not None:
@@ -965,8 +975,8 @@ class Atmosphere(list):
                 tmp.append(I_in)
             elif surfaceTemperature is None:
                 raise ValueError("give surfaceSpectrum or surfaceTemperature")
-            ctx.column_sweep_dev(trans, [L.T for L in layers], first.rangeMin, first.rangeMax, n, out, I_in=I_in,
-                                 surface_T=float(surfaceTemperature or 0.0))
+            ctx.column_step_dev(desc, first.rangeMin, first.rangeMax, n, out, I_in=I_in,
+                                surface_T=float(surfaceTemperature or 0.0))
             return out.download(n)
         finally:
             for b in tmp:
