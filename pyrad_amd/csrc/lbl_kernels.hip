@@ -2,11 +2,12 @@
 //
 //   K1 line_prep_kernel        pyradClasses.py:252-263, 378-390; pyradLineshape.py:59-71;
 //                              pyradIntensity.py:16-32
-//   K2 xsec_accumulate_kernel  pyradLineshape.py:39, 52, 72-74 and the scatter loop
+//   K2 xsec_accumulate_*       pyradLineshape.py:39, 52, 72-74 and the scatter loop
 //                              pyradClasses.py:392-400, restated as an owner-computes gather
 //   K3 regrid_kernel           np.interp of pyradClasses.py:401-405 (only when res != BASE)
 //   K4 layer_sweep_kernel      pyradClasses.py:566-571, 583, 707-716, 784-787; pyradPlanck.py:38-44
 //   K5 column_sweep_kernel     fold of pyradClasses.py:784-787 over layers
+//   K5b column_step_kernel     K4's arithmetic per layer + that fold, straight from the cross sections
 //   K6 band_integral kernels   pyradClasses.py:26-29
 //   K7 line_survey_kernel      pyradClasses.py:409-428
 //
@@ -14,13 +15,19 @@
 // grid index and samples the half-profile at integer multiples of the resolution, so the
 // contribution of line l to grid point j depends only on |j - c_l|.  That makes the gather
 // form exact: every lane owns R consecutive grid points in registers, a wavefront walks the
-// (sorted) lines whose support reaches its 64*R points, line records arrive through the
-// scalar cache (one s_load_dwordx16 per line, wave-uniform) and each grid point is written
-// once with a plain coalesced store.  No atomics, no LDS traffic in the inner loop, and a
-// fixed summation order (line order) per grid point, so two runs are bit-identical.
+// (sorted) lines whose support reaches its 64*R points, and each grid point is written once
+// with a plain coalesced store.  No atomics, and a fixed summation order per grid point, so two
+// runs are bit-identical.
 //
-// The kernel is fp64-VALU bound (about 5 fp64 instructions per line x grid-point pair), not
-// HBM bound: its compulsory traffic is 64 B per line and 8 B per grid point.
+// K2 variants (lbl_set_option "accum_variant"):
+//   0-2  xsec_accumulate_kernel      line records through the scalar cache (the first version)
+//   3    xsec_accumulate_lds_kernel  records streamed through wave-private LDS, every pair direct
+//   4    ..._balanced_kernel         3 with an exactly balanced partition of (span, line) pairs
+//   5    xsec_accumulate_lds_kernel<.., FF = true>  (default) 3 + far-field series for distant
+//        Lorentz lines; optionally the layer sweep of a single-line-list layer in the output stage
+//
+// K2 is fp64-VALU bound, not HBM bound: its compulsory traffic is 56 B per line and 8 B per grid
+// point against 5 fp64 instructions per directly evaluated (line, grid point) pair.
 #include "lbl_device.h"
 #include <cstdlib>
 
