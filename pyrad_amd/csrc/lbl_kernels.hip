@@ -953,13 +953,17 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
     for (int k = 0; k < R; ++k) mine[span_slot(lane * R + k)] = S.acc[k];
     if (LS > 1) __syncthreads();
     else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-    if (part == 0 && active) {
+    if (active) {
+        // the LS waves of a span share its output rows (and the fused sweep of their points); every
+        // point is summed over the waves in the same order whichever wave stores it
         double* __restrict__ out = J.out;
+        const int w0 = wave - part;                      // first wave of this span
 #pragma unroll
         for (int i = 0; i < R; ++i) {
+            if (LS > 1 && (i % LS) != part) continue;        // row i belongs to wave i % LS of the span
             const int o = i * 64 + lane;
-            double t = mine[span_slot(o)];
-            for (int q = 1; q < LS; ++q) t += s_stage[wave + q][span_slot(o)];
+            double t = s_stage[w0][span_slot(o)];
+            for (int q = 1; q < LS; ++q) t += s_stage[w0 + q][span_slot(o)];
             if (wlo + o < n_end) {
                 out[wlo + o] = t;
                 if (J.fuse.on) fused_sweep_point(J.fuse, wlo + o, t);
