@@ -118,3 +118,53 @@ def test_c3_full_size_layer_sampled_parity(ctx):
     r2 = L.results()
     assert all(np.array_equal(r[k], r2[k]) for k in r)
     L.free()
+
+
+def test_c5_full_size_column_sampled_parity(ctx):
+    """BASELINE config 5 at full size: 30 layers x (H2O + CO2 + O3), 2.4e6 points, P 1013 -> 10 mbar
+    (windows from W = 5000 down to 50 in one batch).  The outgoing spectrum of the one-pass column
+    step and the transmittance of three layers against the oracle at sampled grid points; fused and
+    unfused column paths bit-identical; bit-identical rerun."""
+    from oracle import pyrad_oracle as orc
+    from pyrad_amd import engine
+    from pyrad_amd.model import concentration_from_kwargs
+    col = synthetic.config_c5()
+    cfgs = []
+    for c in col["layers"]:
+        mols = []
+        for mol in c["molecules"]:
+            sp = synthetic.SPECIES[mol["species"]]
+            mols.append(dict(conc=concentration_from_kwargs(**mol["conc"]),
+                             isotopologues=[dict(lines=mol["lines"], molmass=sp["molmass"],
+                                                 q_T=synthetic.q_value(mol["species"], c["T"]), q296=sp["q296"])]))
+        cfgs.append(dict(c, molecules=mols))
+    column = engine.ResidentColumn(ctx, cfgs, col["surface_T"])
+    assert len(column.layers) == 30 and column.n == 2400000 and column.evals > 2.5e10
+    column.enqueue()
+    got = column.results()
+    rng = np.random.default_rng(5)
+    pts = np.unique(np.concatenate([[0, column.n - 1], rng.integers(0, column.n, 10)]))
+    xa = orc.x_axis(col["layers"][0]["range_min"], col["layers"][0]["range_max"], .001)[pts]
+    I = orc.planckWavenumber(xa, col["surface_T"])
+    for li, c in enumerate(col["layers"]):
+        g = orc.layer_grid(c["P"], c["range_min"], c["range_max"], c["base_resolution"], c["dynamic_resolution"])
+        k = np.zeros(len(pts))
+        for mi, mol in enumerate(c["molecules"]):
+            sp = synthetic.SPECIES[mol["species"]]
+            conc = cfgs[li]["molecules"][mi]["conc"]
+            sel = orc.select_window(mol["lines"], g["eff_min"], g["eff_max"])
+            xs = orc.cross_section_at_points(sel, c["T"], c["P"], conc, sp["molmass"],
+                                             synthetic.q_value(mol["species"], c["T"]), sp["q296"], g, pts)
+            k = k + orc.abs_coef(xs, conc, c["P"], c["T"])
+        tr = orc.transmittance(k, c["depth"])
+        if li in (0, 14, 29):
+            assert rel_err(got["transmittance"][li][pts], tr) <= RTOL, li
+        I = orc.transmission(tr, I, orc.planckWavenumber(xa, c["T"]))
+    assert rel_err(got["toa"][pts], I) <= RTOL
+    assert np.all(np.isfinite(got["toa"])) and np.all(got["toa"] > 0)
+    column.enqueue(fused=False)
+    two = column.results()
+    assert np.array_equal(two["toa"], got["toa"])
+    column.enqueue()
+    assert np.array_equal(column.results()["toa"], got["toa"])
+    column.free()

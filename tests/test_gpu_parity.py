@@ -315,6 +315,25 @@ def test_error_paths(ctx):
         ctx.xsec_accumulate(lines, iso, gz)          # W = 0: the reference raises IndexError (cls:393)
     xs, counts = ctx.xsec_accumulate({k: v[:0] for k, v in lines.items()}, iso, engine.native_grid(g))
     assert xs.shape == (g["n_base"],) and not xs.any() and counts == (0, 0, 0)   # empty line list
+    # the fused entry points validate like the kernels they combine
+    n = g["n_base"]
+    xb, out = ctx.buffer(n), ctx.buffer(n)
+    L = ctx.lines(lines)
+    with pytest.raises(nat.LblError):               # I_out without I_in or a surface temperature
+        ctx.layer_step_dev(L, iso, engine.native_grid(g), xb, 4e-4, 10.0, I_out=out)
+    with pytest.raises(nat.LblError):               # output buffer shorter than the base grid
+        ctx.layer_step_dev(L, iso, engine.native_grid(g), ctx.buffer(n - 1), 4e-4, 10.0)
+    layer = dict(xsec=[xb, xb], iso_mol=[1, 0], conc=[1e-3, 2e-3], P=1000.0, T=280.0, depth=5.0)
+    with pytest.raises(nat.LblError):               # iso_mol must be non-decreasing
+        ctx.column_step_dev([layer], 600, 700, n, out, surface_T=288.0)
+    with pytest.raises(nat.LblError):               # neither I_in nor surface_T
+        ctx.column_step_dev([dict(layer, iso_mol=[0, 1])], 600, 700, n, out)
+    with pytest.raises(nat.LblError):               # more layers than the kernel's argument block holds
+        ctx.column_step_dev([dict(layer, iso_mol=[0, 1])] * 129, 600, 700, n, out, surface_T=288.0)
+    ctx.column_step_dev([], 600, 700, n, out, surface_T=288.0)      # no layers: the surface spectrum itself
+    from oracle import pyrad_oracle as orc
+    check(out.download(n), orc.planckWavenumber(orc.x_axis(600, 700, .01), 288.0))
+    L.free(); xb.free(); out.free()
 
 
 def test_rccl_comm_single_rank_inplace_allgather_and_overlap(ctx):
