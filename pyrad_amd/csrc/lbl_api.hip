@@ -661,7 +661,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     // layout of the scratch arenas
     std::vector<size_t> line_off(n_jobs), work_off(n_jobs);
     size_t tot_lines = 0, tot_work = 0;
-    long long total_points = 0, min_H = 1LL << 40;
+    long long min_H = 1LL << 40;
     int max_lines = 0;
     for (int j = 0; j < n_jobs; ++j) {
         if (!lines[j] || lines[j]->ctx != ctx) return fail(ctx, LBL_ERR_STATE, "job %d: line list missing or from another context", j);
@@ -673,7 +673,6 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         tot_lines += (size_t)lines[j]->n;
         work_off[j] = tot_work;
         if (needs_regrid(grid[j])) tot_work += (size_t)grid[j].n_work;
-        { long long f, c; shard_range(grid[j], &f, &c); total_points += c; }
         min_H = std::min<long long>(min_H, std::max<long long>(grid[j].window - 2, 0));
         max_lines = std::max<int>(max_lines, (int)lines[j]->n);
     }
