@@ -467,15 +467,15 @@ extern "C" int lbl_lines_count(const lbl_lines* lines, int64_t* n) {
 //      2 from 256 (the four waves of a workgroup then finish together and workgroups are
 //      short, which balances the clustered line density), else 1.
 // The scalar-cache variants (0-2) keep their original rule: about 3 waves per SIMD.
-static void choose_shape(const lbl_ctx* ctx, long long total_points, long long total_lines, long long min_H,
+static void choose_shape(const lbl_ctx* ctx, int variant, long long total_points, long long total_lines, long long min_H,
                          int* R_out, int* LS_out) {
     const long long cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    const bool lds = ctx->accum_variant >= 3;
+    const bool lds = variant >= 3;
     int R = ctx->accum_R, LS = lds ? ctx->accum_LS : 1;
     auto lines_per_span = [&](int r) {
         return total_points > 0 ? (double)total_lines / (double)total_points * (double)(2 * min_H + 64LL * r) : 0.0;
     };
-    if (ctx->accum_variant == 5 && !R && !LS) {
+    if (ctx->accum_variant == 5 && !R && !LS) {   // (also for its groups without far lines, which run variant 3's kernel)
         // far-field kernel: R = 4 and as little line split as the line count asks for, unless the grid
         // is too small to give every SIMD two wavefronts: then split more, then shrink the spans
         // (C1, 10^4 points: R = 1 with 8 waves per span is 4x faster than R = 4 unsplit)
@@ -498,7 +498,7 @@ static void choose_shape(const lbl_ctx* ctx, long long total_points, long long t
         return;
     }
     if (!R) {
-        if (ctx->accum_variant == 4) {
+        if (variant == 4) {
             R = 4;                       // work is split by lines, not spans: no reason to shrink R on small grids
         } else if (lds) {
             R = 4;
@@ -513,7 +513,7 @@ static void choose_shape(const lbl_ctx* ctx, long long total_points, long long t
     }
     if (!LS) {
         const double lps = lines_per_span(R);
-        if (ctx->accum_variant == 5)         // far lines are ~40x cheaper: a span carries less work, split it less
+        if (variant == 5)         // far lines are ~40x cheaper: a span carries less work, split it less
             LS = lps >= 4096.0 ? 4 : lps >= 1024.0 ? 2 : 1;
         else
             LS = lps >= 1024.0 ? 4 : lps >= 256.0 ? 2 : 1;
@@ -532,10 +532,10 @@ static void choose_shape(const lbl_ctx* ctx, long long total_points, long long t
 // would search for): 6 lower bounds per span.  A wave then starts with one 32-byte load instead of
 // six dependent probes of the centre-index array, which was most of a wave's lifetime on narrow
 // windows (upper layers of a column: ~10 lines per span).
-static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, const std::vector<int>& jobs_in_group, lbl_lines* const* lines,
-                                               const lbl_grid* grid, int R, int LS, long long tile_pts) {
+static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::vector<int>& jobs_in_group,
+                                               lbl_lines* const* lines, const lbl_grid* grid, int R, int LS, long long tile_pts) {
     std::vector<uint64_t> key;
-    const bool far_field = ctx->accum_variant == 5;
+    const bool far_field = variant == 5;
     int far_half_spans = 0;
     double far_cost = 1.0;
     if (far_field) accumulate_far_field_params(R, &far_half_spans, &far_cost);
@@ -702,28 +702,43 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         while (r > 1 && 64LL * r > 2 * H + 1) r >>= 1;
         return ctx->accum_R ? 8 : r;              // a forced R keeps one group
     };
+    // Far-field kernel: a window narrower than (threshold + 1) half-spans has no far line on any span;
+    // such jobs run the all-direct kernel (same arithmetic there, 60-90 instead of 105-123 VGPRs, so
+    // 5-8 instead of 4 waves per SIMD: narrow-window spans are latency bound).
+    int far_half_spans = 0;
+    { double fc; accumulate_far_field_params(4, &far_half_spans, &fc); }
+    auto has_far = [&](int j) {
+        if (ctx->accum_variant != 5) return 0;
+        const long long H = std::max<long long>(grid[j].window - 2, 0);
+        const long long r = ctx->accum_R ? ctx->accum_R : r_cap(j);
+        return H >= 32 * r * (far_half_spans + 1) ? 1 : 0;
+    };
+    auto group_key = [&](int j) { return r_cap(j) * 2 + has_far(j); };
     std::vector<int> order(n_jobs);
     for (int j = 0; j < n_jobs; ++j) order[j] = j;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return r_cap(a) > r_cap(b); });
-    struct Group { int first, count, R, LS, max_tiles; const int2* worklist; int total_tiles; const int32_t* tabs; std::vector<size_t> tab_off; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return group_key(a) > group_key(b); });
+    struct Group { int first, count, R, LS, max_tiles, variant; const int2* worklist; int total_tiles; const int32_t* tabs; std::vector<size_t> tab_off; };
     std::vector<Group> groups;
     for (int k = 0; k < n_jobs;) {
         int e = k;
-        long long pts = 0, lns = 0, mh = 1LL << 40;
-        while (e < n_jobs && r_cap(order[e]) == r_cap(order[k])) {
+        long long pts = 0, lns = 0, mh = 1LL << 40, mxh = 0;
+        while (e < n_jobs && group_key(order[e]) == group_key(order[k])) {
             long long f, c;
             shard_range(grid[order[e]], &f, &c);
             pts += c; lns += lines[order[e]]->n;
-            mh = std::min<long long>(mh, std::max<long long>(grid[order[e]].window - 2, 0));
+            const long long H = std::max<long long>(grid[order[e]].window - 2, 0);
+            mh = std::min(mh, H); mxh = std::max(mxh, H);
             ++e;
         }
-        Group g{k, e - k, 0, 0, 0, nullptr, 0, nullptr, {}};
-        choose_shape(ctx, pts, lns, mh, &g.R, &g.LS);
-        if ((ctx->accum_variant == 3 || ctx->accum_variant == 5) && ctx->lpt) {
+        Group g{k, e - k, 0, 0, 0, ctx->accum_variant, nullptr, 0, nullptr, {}};
+        choose_shape(ctx, g.variant, pts, lns, mh, &g.R, &g.LS);
+        // with the R actually chosen (a small grid may have shrunk it): does any job of the group have far lines?
+        if (ctx->accum_variant == 5 && mxh < 32LL * g.R * (far_half_spans + 1)) g.variant = 3;
+        if ((g.variant == 3 || g.variant == 5) && ctx->lpt) {
             // cached host schedule of this group: dispatch order + the line ranges of every span
             std::vector<int> members(order.begin() + k, order.begin() + e);
-            const lbl_ctx::Schedule* sc = group_schedule(ctx, members, lines, grid, g.R, g.LS,
-                                                         accumulate_tile_points(g.R, g.LS, ctx->accum_variant));
+            const lbl_ctx::Schedule* sc = group_schedule(ctx, g.variant, members, lines, grid, g.R, g.LS,
+                                                         accumulate_tile_points(g.R, g.LS, g.variant));
             if (!sc) return fail(ctx, LBL_ERR_OOM, "schedule allocation failed");
             g.worklist = sc->d_list; g.total_tiles = sc->total; g.tabs = sc->d_tabs; g.tab_off = sc->tab_off;
         }
@@ -754,7 +769,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     std::vector<size_t> bal_off(groups.size() + 1, 0);
     std::vector<int> group_spans(groups.size(), 0), group_workers(groups.size(), 0);
     for (Group& g : groups) {
-        const long long tile_pts = accumulate_tile_points(g.R, g.LS, ctx->accum_variant);
+        const long long tile_pts = accumulate_tile_points(g.R, g.LS, g.variant);
         for (int k = g.first; k < g.first + g.count; ++k) {
             const int j = order[k];
             const PrepJob& p = hp[j];
@@ -842,7 +857,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             launch_accumulate_balanced(da + g.first, g.count, (int)S, g.R, group_workers[gi], spans, cnts, prefix, slab,
                                        ctx->stream);
         } else {
-            launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, ctx->accum_variant, g.worklist, g.total_tiles,
+            launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, g.variant, g.worklist, g.total_tiles,
                               ctx->stream);
         }
         prof_end(ctx, PROF_ACCUM, ev);
