@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--line-split", type=int, default=None)
     ap.add_argument("--tile-order", type=int, default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
+    ap.add_argument("--profile-every", type=int, default=4,
+                    help="HIP events around the dominant kernel in every n-th timed step only (default 4; 1 = every step)")
     ap.add_argument("--column-layer-arrays", type=int, default=0,
                     help="C5: 1 also writes every layer's absorption coefficient and transmittance arrays (default 0: "
                          "the column step keeps them in registers and writes the outgoing spectrum only)")
@@ -263,16 +265,24 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # HIP events bracket only the dominant kernel inside the timed region (two markers per step);
-    # the other kernel classes are timed in a short untimed pass afterwards
-    ctx.profile_enable(["xsec_accumulate"])
+    # HIP events bracket only the dominant kernel inside the timed region, and only in every
+    # --profile-every-th step: a pair of event records costs the stream ~5 us, 12 % of a C2 step if
+    # every launch carries one.  The other kernel classes are timed in a short untimed pass afterwards.
+    ctx.profile_enable(False)
     ctx.profile_reset()
+    every = max(1, args.profile_every)
+    n_sampled = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        sampled = k % every == 0
+        if sampled or (k % every == 1):
+            ctx.profile_enable(["xsec_accumulate"] if sampled else False)
+        n_sampled += sampled
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
     prof = ctx.profile_read()
     ctx.profile_enable(["line_prep", "regrid", "layer_sweep", "column_sweep"] + (["allgather"] if n_sets == 1 else []))
     ctx.profile_reset()
@@ -332,7 +342,7 @@ def main():
         if fused_sweep:
             balg_acc += 24.0 * pts
         t_acc = (ms_acc / max(n_acc, 1)) * 1e-3
-        t_acc_step = (ms_acc / max(args.steps, 1)) * 1e-3       # all K2 launches of one step
+        t_acc_step = (ms_acc / max(n_sampled, 1)) * 1e-3        # all K2 launches of one (sampled) step
         achieved = balg_acc / t_acc / 1e9 if t_acc > 0 else 0.0
         n_mol_arrays = len(layer.layers[0].jobs) if is_column else len(layer.jobs)
         # per sweep launch: M xsec reads + k, T (, I_out) writes; I_in is computed in-kernel
@@ -346,7 +356,7 @@ def main():
             balg_sw = 8.0 * pts * (n_mol_arrays * n_layers + 1 + (2 * n_layers if args.column_layer_arrays else 0))
             sweep_kernel = "column_step_kernel"
         if is_column:
-            balg_acc = balg_acc / max(n_acc // max(args.steps, 1), 1)     # K2 is launched once per window group
+            balg_acc = balg_acc / max(n_acc // max(n_sampled, 1), 1)      # K2 is launched once per window group
         t_sw = (ms_sw / max(n_sw, 1)) * 1e-3
         pmc = load_pmc_traffic(args.workload if (args.scale == 1 and args.lines is None and world == 1) else None)
         result = {
@@ -363,6 +373,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc.get("xsec_accumulate_kernel"),
                          "algorithmic_bytes_per_launch": balg_acc, "avg_launch_ms": t_acc * 1e3, "launches": n_acc,
+                         "launches_timed": "every launch of every %d-th timed step (%d of %d steps)" % (every, n_sampled, args.steps),
                          "note": "compulsory traffic only (56 B/line + 8 B/grid point, + 24 B/grid point when the layer "
                                  "sweep is fused in): this kernel is fp64-VALU bound by construction (SURVEY.md §8d), "
                                  "see valu_f64"},
@@ -373,7 +384,7 @@ def main():
                                "frac": (balg_sw / t_sw / 1e9 / HBM_PEAK_GBS) if t_sw > 0 else 0.0,
                                "traffic": pmc.get(sweep_kernel),
                                "algorithmic_bytes_per_launch": balg_sw, "avg_launch_ms": t_sw * 1e3, "launches": n_sw},
-            "kernel_ms_per_step": {"line_prep": ms_prep / args.steps, "xsec_accumulate": ms_acc / args.steps,
+            "kernel_ms_per_step": {"line_prep": ms_prep / args.steps, "xsec_accumulate": ms_acc / max(n_sampled, 1),
                                    ("column_step" if is_column else "layer_sweep"): ms_sw / args.steps,
                                    "allgather": ms_ag / args.steps},
             "setup_s": t_setup,

@@ -39,7 +39,7 @@ def test_default_contract():
     assert abs(d["value"] - d["config"]["evals_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["launches"] == 5
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["launches"] == 2      # steps 0 and 4 of 5 carry events
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e5 and "sample" in c
 
