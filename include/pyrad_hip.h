@@ -123,6 +123,9 @@ int lbl_set_option(lbl_ctx* ctx, const char* key, int value);
 int lbl_profile_enable(lbl_ctx* ctx, int on);
 int lbl_profile_read(lbl_ctx* ctx, int kind, int64_t* launches, double* total_ms);
 int lbl_profile_reset(lbl_ctx* ctx);
+/* Create events ahead of time so that timed launches only record them (an event created on first
+ * use costs the timed region ~10 us). */
+int lbl_profile_reserve(lbl_ctx* ctx, int n_events);
 
 /* ---- device buffers (float64) ------------------------------------------------------- */
 int lbl_buffer_create(lbl_ctx* ctx, int64_t n, lbl_buffer** out);

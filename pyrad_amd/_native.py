@@ -62,6 +62,7 @@ SIGNATURES = {
     "lbl_profile_enable": (C.c_int, [_P, C.c_int]),
     "lbl_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), _D]),
     "lbl_profile_reset": (C.c_int, [_P]),
+    "lbl_profile_reserve": (C.c_int, [_P, C.c_int]),
     "lbl_buffer_create": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "lbl_buffer_destroy": (C.c_int, [_P]),
     "lbl_buffer_size": (C.c_int, [_P, C.POINTER(C.c_int64)]),
@@ -209,6 +210,9 @@ class Context:
             for k in kinds:
                 mask |= 1 << self.PROFILE_KINDS[k]
         self.check(self.lib.lbl_profile_enable(self.h, mask))
+
+    def profile_reserve(self, n_events: int):
+        self.check(self.lib.lbl_profile_reserve(self.h, int(n_events)))
 
     def profile_reset(self):
         self.check(self.lib.lbl_profile_reset(self.h))

@@ -269,6 +269,17 @@ extern "C" int lbl_profile_enable(lbl_ctx* ctx, int on) {
     return LBL_OK;
 }
 
+extern "C" int lbl_profile_reserve(lbl_ctx* ctx, int n_events) {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    while ((int)ctx->ev_pool.size() < n_events) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
+    return LBL_OK;
+}
+
 extern "C" int lbl_profile_reset(lbl_ctx* ctx) {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
