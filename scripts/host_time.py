@@ -1,3 +1,5 @@
+"""Diagnostic (GPU): host enqueue time per C2 step against the end-to-end time per step, with and
+without the one-rank RCCL all-gather pipeline (no profiling events): is the loop GPU- or host-bound?"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.argv = ["x"]
