@@ -560,8 +560,12 @@ static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const 
         key.push_back(bits_a); key.push_back(bits_b);
         key.push_back((uint64_t)sf); key.push_back((uint64_t)sc); key.push_back((uint64_t)grid[j].window);
     }
-    for (auto& sc : ctx->schedules)
-        if (sc.key == key) return &sc;
+    for (size_t i = 0; i < ctx->schedules.size(); ++i)
+        if (ctx->schedules[i].key == key) {
+            // least recently used at the front: an entry handed out in this call is never the next to go
+            std::rotate(ctx->schedules.begin() + i, ctx->schedules.begin() + i + 1, ctx->schedules.end());
+            return &ctx->schedules.back();
+        }
     struct Item { int count, job, tile; };
     std::vector<Item> items;
     std::vector<long long> idx;

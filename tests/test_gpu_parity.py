@@ -564,3 +564,19 @@ def test_far_field_random_against_direct_kernel(ctx, seed):
     assert tuple(c3) == tuple(c5)
     assert np.all(np.isfinite(series)) and np.all(series >= 0)
     assert rel_err(series, direct) <= 5e-14, (seed, g["W"], R, LS)
+
+
+def test_schedule_cache_survives_eviction(ctx):
+    """The host schedule (dispatch order + per-span line ranges) is cached per (line lists, grid), 16
+    entries, least recently used out first: 40 different grids in one context, revisited in another
+    order, give the same bits as on first sight."""
+    lines = synthetic.make_lines(321, 700, 630, 700)
+    first = {}
+    for i in range(40):
+        rmin = 640.0 + 0.25 * i
+        xs, _, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, rmin, rmin + 8.0, .001, False)
+        first[i] = xs
+    for i in list(range(0, 40, 3)) + [39, 0, 20]:
+        rmin = 640.0 + 0.25 * i
+        xs, _, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, rmin, rmin + 8.0, .001, False)
+        assert np.array_equal(xs, first[i]), i
