@@ -777,6 +777,10 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         p.Q_T = iso[j].Q_T; p.Q_296 = iso[j].Q_296;
         p.range_min = grid[j].range_min; p.resolution = grid[j].resolution;
         p.log_t0_over_T = std::log(296.0 / iso[j].T);
+        p.P_over_p0 = iso[j].P / p0;
+        { const double m = iso[j].molmass / 1000.0 / avo; p.ghw_factor = std::sqrt(2.0 * kB * iso[j].T / m / (cLight * cLight)); }
+        p.q_ratio = iso[j].Q_296 / iso[j].Q_T;
+        p.inv_T = 1.0 / iso[j].T; p.inv_res = 1.0 / grid[j].resolution; p.inv_res2 = p.inv_res * p.inv_res;
         p.n_lines = (int32_t)L->n;
     }
     const bool balanced = ctx->accum_variant == 4;

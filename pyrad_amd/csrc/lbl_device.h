@@ -12,6 +12,8 @@ constexpr double kB = 1.38064852E-23;
 constexpr double cLight = 299792458.0;
 constexpr double hPlanck = 6.62607004e-34;
 constexpr double kPi = 3.141592653589793;
+constexpr double kInvPi = 0.3183098861837907;            // 1/pi
+constexpr double kInvSqrtPi = 0.5641895835477563;        // 1/sqrt(pi)
 constexpr double t0 = 296.0;
 constexpr double p0 = 1013.25;
 constexpr double avo = 6.022140857E23;
@@ -92,6 +94,12 @@ struct PrepJob {
     double T, P, q_frac, molmass, Q_T, Q_296;
     double range_min, resolution;
     double log_t0_over_T;   // ln(296/T), computed once per job on the host
+    // per-job constants of the reference's expressions, evaluated once on the host in the reference's
+    // operation order (same IEEE results as on the device), and reciprocals of the per-job divisors
+    double P_over_p0;       // P / p0                                   (cls:254, 258)
+    double ghw_factor;      // sqrt(2 k T / m / c^2), m = molmass/1000/avo (cls:263, 296)
+    double q_ratio;         // Q_296 / Q_T                              (int:30-32)
+    double inv_T, inv_res, inv_res2;
     int32_t n_lines;
     int32_t pad;
 };

@@ -92,42 +92,43 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
     int regime = -1;
     if (i < J.n_lines) {
         const double nu = J.nu[i];
-        const double T = J.T, P = J.P, q = J.q_frac;
+        const double T = J.T, q = J.q_frac;
+        const double Pp0 = J.P_over_p0;                                   // P / p0, evaluated on the host
         // Line.broadenedLine (pyradClasses.py:252-254)
-        const double broadened = nu + J.delta_air[i] * P / p0;
+        const double broadened = nu + J.delta_air[i] * J.P / p0;
         // Line.lorentzHW (pyradClasses.py:256-259)
         // (t0/T)**n evaluated as exp(n ln(t0/T)) with the logarithm hoisted to the host (one per job)
-        const double lhw = ((1.0 - q) * J.gamma_air[i] + q * J.gamma_self[i]) * (P / p0) * exp(J.n_air[i] * J.log_t0_over_T);
-        // Isotope.molMass (pyradClasses.py:294-296), Line.gaussianHW (pyradClasses.py:261-263)
-        const double m = J.molmass / 1000.0 / avo;
-        const double ghw = broadened * sqrt(2.0 * kB * T / m / (cLight * cLight));
+        const double lhw = ((1.0 - q) * J.gamma_air[i] + q * J.gamma_self[i]) * Pp0 * exp(J.n_air[i] * J.log_t0_over_T);
+        // Isotope.molMass (pyradClasses.py:294-296), Line.gaussianHW (pyradClasses.py:261-263): the
+        // square root depends on the job only (host)
+        const double ghw = broadened * J.ghw_factor;
         const double ratio = lhw / ghw;                                   // pyradClasses.py:378
         // pyradIntensity.intensityFactor (pyradIntensity.py:16-32) at the SHIFTED wavenumber
-        // (pyradClasses.py:388)
+        // (pyradClasses.py:388).  Divisions by the per-job T and t0 are multiplications by their
+        // reciprocals: at most one ulp in an exponent of order 1-50.
         const double c2 = cLight * hPlanck * 100.0 / kB;                  // pyradIntensity.py:13
         const double E = J.elower[i];
-        const double stim = (1.0 - exp(-c2 * broadened / T)) / (1.0 - exp(-c2 * broadened / t0));
+        const double stim = (1.0 - exp(-c2 * broadened * J.inv_T)) / (1.0 - exp(-c2 * broadened * (1.0 / t0)));
         // exp(-c2 E/T) / exp(-c2 E/t0) as one exponential of the difference (exactly 1 at T = t0,
         // like the quotient; elsewhere within |c2 E (1/T - 1/t0)| ulps of it, < 1e-14 relative)
-        const double boltz = exp(c2 * E / t0 - c2 * E / T);
-        const double A = J.sw[i] * (J.Q_296 / J.Q_T) * stim * boltz;
+        const double boltz = exp(c2 * E * (1.0 / t0) - c2 * E * J.inv_T);
+        const double A = J.sw[i] * J.q_ratio * stim * boltz;
         // centre index from the UNSHIFTED wavenumber, truncation toward zero (pyradClasses.py:390)
         const double fidx = (nu - J.range_min) / J.resolution;
         long long idx = (long long)fidx;
         if (idx > 2000000000LL) idx = 2000000000LL;
         if (idx < -2000000000LL) idx = -2000000000LL;
 
-        const double res = J.resolution;
         double hw, KL, KG;
         if (ratio < .01) {                // Gaussian only (pyradClasses.py:379-381)
             regime = 0;
             hw = ghw;
             KL = 0.0;
-            KG = A / hw / sqrt(kPi);                                      // pyradLineshape.py:39
+            KG = A / hw * kInvSqrtPi;                                     // pyradLineshape.py:39 (/ sqrt(pi) as a product)
         } else if (ratio > 100.0) {       // Lorentz only (pyradClasses.py:382-384)
             regime = 1;
             hw = lhw;
-            KL = A * (hw / kPi);                                          // pyradLineshape.py:52
+            KL = A * (hw * kInvPi);                                       // pyradLineshape.py:52 (/ pi as a product)
             KG = 0.0;
         } else {                          // pseudo-Voigt (pyradClasses.py:385-387, pyradLineshape.py:58-76)
             regime = 2;
@@ -139,15 +140,15 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
             const double x = l / f;
             const double eta = 1.36603 * x - .47719 * x * x + .11116 * x * x * x;
             hw = f / 2.0;
-            KL = eta * (A * (hw / kPi));
-            KG = (1.0 - eta) * (A / hw / sqrt(kPi));
+            KL = eta * (A * (hw * kInvPi));
+            KG = (1.0 - eta) * (A / hw * kInvSqrtPi);
         }
-        const double a = hw / res;
+        const double a = hw * J.inv_res;
         HotRec r;
         ColdRec rc;
         r.cf = (double)idx;
         r.a2 = a * a;
-        r.KL = KL / (res * res);
+        r.KL = KL * J.inv_res2;
         rc.KG = KG;
         rc.b = 1.0 / r.a2;
         r.flags = 0;
