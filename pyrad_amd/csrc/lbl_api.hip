@@ -537,12 +537,15 @@ static void choose_shape(const lbl_ctx* ctx, int variant, long long total_points
 // the CUs idle for the last third of the kernel).  The host knows every line's centre index (same
 // IEEE expression as K1) and counts the lines each tile will walk; the sorted (job, tile) list
 // depends only on the line lists and the grid, so it is built once and reused across calls
-// (temperature, pressure-independent).  It steers the dispatch order only, never a result.
+// (temperature, pressure-independent).  The dispatch order never changes a result.
 //
 // The same pass tabulates the line ranges of every span of 64*R points (what wave_line_ranges[_far]
 // would search for): 6 lower bounds per span.  A wave then starts with one 32-byte load instead of
 // six dependent probes of the centre-index array, which was most of a wave's lifetime on narrow
-// windows (upper layers of a column: ~10 lines per span).
+// windows (upper layers of a column: ~10 lines per span).  These ranges DO decide which lines a
+// span visits: they are the lower bounds of the very centre indices K1 writes, because the host
+// evaluates the same correctly rounded IEEE expression (nu - range_min) / resolution on the same
+// doubles (host and device code are built without fast-math), and truncation is shared.
 static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::vector<int>& jobs_in_group,
                                                lbl_lines* const* lines, const lbl_grid* grid, int R, int LS, long long tile_pts) {
     std::vector<uint64_t> key;
