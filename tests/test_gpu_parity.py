@@ -580,3 +580,32 @@ def test_schedule_cache_survives_eviction(ctx):
         rmin = 640.0 + 0.25 * i
         xs, _, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, rmin, rmin + 8.0, .001, False)
         assert np.array_equal(xs, first[i]), i
+
+
+def test_host_span_tables_agree_with_device_search(ctx):
+    """The host tabulates every span's line ranges from its own evaluation of the centre index; the
+    kernel without a schedule (positional order) searches the indices K1 wrote.  Line centres placed
+    on grid points and one ulp either side of them (where truncation decides the index), window
+    edges and far-threshold boundaries included: both paths must give the same bits."""
+    rng = np.random.default_rng(99)
+    rmin, rmax, res = 650.0, 662.0, .001
+    n = 3000
+    k = rng.integers(-5200, 17200, n).astype(np.float64)            # also centres outside the grid, within the window
+    nu = rmin + k * res
+    nudge = rng.integers(-2, 3, n)
+    for _ in range(2):
+        nu = np.where(nudge > 0, np.nextafter(nu, np.inf), np.where(nudge < 0, np.nextafter(nu, -np.inf), nu))
+        nudge = nudge - np.sign(nudge)
+    base = synthetic.make_lines(98, n, 640, 670)
+    lines = dict(base, nu=np.sort(nu))
+    keep = np.concatenate([[True], np.diff(lines["nu"]) > 0])
+    lines = {f: v[keep] for f, v in lines.items()}
+    for R, LS in ((None, None), (4, 1), (2, 2), (1, 4)):
+        ctx.set_option("accum_longest_first", 0)
+        try:
+            a, ca, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, rmin, rmax, res, False, 5, R, LS)
+        finally:
+            ctx.set_option("accum_longest_first", 3)
+        b, cb, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, rmin, rmax, res, False, 5, R, LS)
+        assert tuple(ca) == tuple(cb)
+        assert np.array_equal(a, b), (R, LS)
