@@ -415,7 +415,7 @@ def merge_array(newX, oldX, oldY):
     dst0 = nx.index(min(ox)) if starts_before else 0
     src0 = 0 if starts_before else ox.index(min(nx))
     src1 = (len(ox) - 1) if ends_after else (src0 + len(nx) - 1)
-    tail = len(nx) - ((dst0 + len(ox) - 1) if ends_after else (len(nx) - 1))
+    tail = max(len(nx) - ((dst0 + len(ox) - 1) if ends_after else (len(nx) - 1)), 0)   # [0] * negative == [] (cls:229)
     body = []
     for i in range(src0, src1):
         body.append(y[i])                       # IndexError if the table is too short

@@ -557,6 +557,10 @@ def g8():
             "right_partial": (layer_axis, np.arange(660.0, 720.0, .01)),     # starts inside, ends after
             "skipped_value": (layer_axis, np.arange(650.0, 660.0, .01)),     # 650.0 is not on the rounded axis
             "short_table": (np.linspace(10, 11, 100), np.arange(10.5, 10.52, .01)),
+            # the table overhangs a short axis on the left and ends with it: the zero padding count goes negative
+            "overhang_a": (np.array([600.00, 600.01]), np.array([599.97, 599.98, 599.99, 600.00])),
+            "overhang_b": (np.array([600.00, 600.01]), np.array([599.98, 599.99, 600.00, 600.01])),
+            "overhang_c": (600.0 + 0.01 * np.arange(5), 599.95 + 0.01 * np.arange(9)),
         }
         with contextlib.redirect_stdout(io.StringIO()):
             for name, (nx, oxx) in cases.items():
