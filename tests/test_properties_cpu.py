@@ -73,3 +73,54 @@ def test_merge_array_model_equals_oracle(lo, n_new, off, n_old, seed):
     assert outcome[0][0] == outcome[1][0]
     if outcome[0][0] == "ok":
         assert np.array_equal(outcome[0][1], outcome[1][1])
+
+
+@settings(max_examples=80, deadline=None)
+@given(seed=st.integers(0, 10**6), n=st.integers(0, 300), lo=st.floats(500.0, 700.0), width=st.floats(0.0, 120.0))
+def test_select_window_and_concentration_equal_oracle(seed, n, lo, width):
+    rng = np.random.default_rng(seed)
+    lines = {f: np.sort(rng.uniform(480.0, 840.0, n)) if f == "nu" else rng.random(n) for f in
+             ("nu", "sw", "a", "elower", "gamma_air", "gamma_self", "delta_air", "n_air")}
+    if n:                      # exact boundary hits: the selection is strict on both sides (ut:437-438)
+        lines["nu"][0] = lo
+        lines["nu"][-1] = max(lo + width, lines["nu"][-1])
+        lines["nu"].sort()
+    a, b = engine.select_window(lines, lo, lo + width), orc.select_window(lines, lo, lo + width)
+    for f in lines:
+        assert np.array_equal(a[f], b[f]), f
+    v = float(rng.uniform(0.0, 500.0))
+    for key in ("ppm", "ppb", "percentage", "perc", "%", "concentration"):
+        assert model.concentration_from_kwargs(**{key: v}) == orc.concentration(**{key: v}), key
+
+
+@settings(max_examples=25, deadline=None)
+@given(seed=st.integers(0, 10**6), n=st.integers(0, 120), lo=st.integers(5, 30), span=st.integers(1, 4))
+def test_data_dir_round_trip_equals_memory_source(tmp_path_factory, seed, n, lo, span):
+    """A PyRad data/ tree written from a line list and read back gives what the in-memory source gives
+    for the same window (strict bounds, last duplicate wins, 100 cm^-1 segment files)."""
+    from pyrad_amd import data, synthetic
+    rng = np.random.default_rng(seed)
+    rmin, rmax = 100.0 * lo + 37.5, 100.0 * (lo + span) - 12.25
+    nu = np.round(np.sort(rng.uniform(rmin - 60.0, rmax + 60.0, n)), 6)
+    if n > 3:
+        nu[1] = nu[0]                       # a duplicated wavenumber: the later row wins (ut:447)
+    lines = {f: nu if f == "nu" else rng.random(n) for f in synthetic.FIELDS}
+    root = str(tmp_path_factory.mktemp("pyr"))
+    q = {T: 100.0 + T for T in (250, 296)}
+    params = synthetic.mol_params("co2")
+    data.PyradDataDir.write_tree(root, 7, lines, q, params)
+    if n:
+        for seg in data.PyradDataDir.segments(rmin, rmax):        # empty segments exist as empty files in PyRad
+            path = "%s/7/%s.pyr" % (root, seg)
+            import os
+            if not os.path.isfile(path):
+                open(path, "w").close()
+    disk = data.PyradDataDir(root)
+    mem = data.MemorySource()
+    mem.register(7, lines, q, params)
+    if n == 0:
+        return
+    a, b = disk.gatherData(7, rmin, rmax), mem.gatherData(7, rmin, rmax)
+    for f in synthetic.FIELDS:
+        assert np.array_equal(a[f], b[f]), f
+    assert disk.getQData(7) == q and disk.readMolParams(7)[0] == params[0]
