@@ -207,3 +207,43 @@ def test_g8_xsc_molecules(pyrad, tmp_path):
             assert copy.exotic and np.array_equal(copy.crossSection, before)
     finally:
         data.set_xsc_source(None)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_lazy_protocol_random_sequences(pyrad, seed):
+    """The dirty-flag protocol (cls:32-88, 543-560, 734-755) under random sequences of the mutators the
+    interactive menu offers: after every operation the layer's absorption coefficient and transmittance
+    equal those of a layer built from scratch in the current state."""
+    rng = np.random.default_rng(4000 + seed)
+    lines = dict(co2=synthetic.make_lines(41, 500, 580, 720), h2o=synthetic.make_lines(42, 300, 580, 720))
+    source(**lines)
+
+    def fresh(state):
+        pyrad.Layer.hasAtmosphere = False
+        L = pyrad.Layer(state["depth"], state["T"], state["P"], state["rmin"], state["rmax"])
+        L.addMolecule('co2', ppm=state["co2"])
+        L.addMolecule('h2o', percentage=state["h2o"])
+        return pyrad.getAbsCoef(L), pyrad.getTransmittance(L)
+
+    state = dict(depth=10.0, T=296, P=1013.25, rmin=600, rmax=700, co2=400.0, h2o=1.0)
+    layer = pyrad.Layer(state["depth"], state["T"], state["P"], state["rmin"], state["rmax"])
+    co2 = layer.addMolecule('co2', ppm=state["co2"])
+    h2o = layer.addMolecule('h2o', percentage=state["h2o"])
+    for step in range(12):
+        op = int(rng.integers(0, 6))
+        if op == 0:
+            state["T"] = int(rng.integers(200, 330)); layer.changeTemperature(state["T"])
+        elif op == 1:
+            state["depth"] = float(rng.uniform(1.0, 5000.0)); layer.changeDepth(state["depth"])
+        elif op == 2:
+            state["co2"] = float(rng.uniform(100.0, 900.0)); co2.setPPM(state["co2"])
+        elif op == 3:
+            state["h2o"] = float(rng.uniform(0.01, 3.0)); h2o.setPercentage(state["h2o"])
+        elif op == 4:
+            state["P"] = float(rng.choice([1013.25, 700.0, 300.0, 120.0])); layer.changePressure(state["P"])
+        else:
+            state["rmin"] = int(rng.choice([600, 620])); state["rmax"] = state["rmin"] + int(rng.choice([60, 80]))
+            layer.changeRange(state["rmin"], state["rmax"])
+        k, t = pyrad.getAbsCoef(layer), pyrad.getTransmittance(layer)
+        kf, tf = fresh(state)
+        assert np.array_equal(k, kf) and np.array_equal(t, tf), (seed, step, op, state)
