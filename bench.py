@@ -13,7 +13,8 @@ sweep (K4) and, for N > 1, the single RCCL all-gather of the per-rank spectrum s
 Workload at N = 1: BASELINE.json configs[1] — CO2, 500-900 cm^-1 at 0.001 cm^-1 (4e5 grid
 points, W = 5000), 65,536 seeded synthetic lines, 1013.25 mbar, 296 K (SURVEY.md §8d "C2").
 For N > 1 the wavenumber grid is sharded by contiguous range and grows with N (weak
-scaling): N x 400 cm^-1, N x 65,536 lines, every rank owns 4e5 grid points.
+scaling): N x 400 cm^-1, N x 65,536 lines, every rank owns 4e5 grid points.  `--strong` keeps the
+workload fixed and shards it instead (`--workload C3 --strong` is BASELINE config 4).
 
 Rank 0 prints ONE JSON line.  `value` = exact (line, grid-point) contributions of the
 reference's scatter loop (pyradClasses.py:392-400) summed over all ranks and steps / the
@@ -157,6 +158,9 @@ def main():
                          "the column step keeps them in registers and writes the outgoing spectrum only)")
     ap.add_argument("--longest-first", type=int, default=None, help="0: positional tile order, 1: longest-first worklist, 2: snake order, 3 (default): bin-packed per CU on single-round launches")
     ap.add_argument("--scale", type=int, default=1, help="experiment: widen the per-GPU range and line count by this factor")
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: shard the FIXED workload across the ranks (BASELINE config 4 with --workload C3) instead of "
+                         "growing the grid with N; the line then says \"scaling\": \"strong\"")
     ap.add_argument("--lines", type=int, default=None, help="experiment: C2 with this many lines instead of 65,536")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -200,7 +204,9 @@ def main():
             uid = rdzv.broadcast("rccl_unique_id", nat.Comm.unique_id() if rank == 0 else None)
             comm = nat.Comm(ctx, uid, world, rank)
 
-    cfg, desc = build_workload(args.workload, world * args.scale)
+    cfg, desc = build_workload(args.workload, (1 if args.strong else world) * args.scale)
+    if args.strong and world > 1:
+        desc += " [fixed workload, grid sharded x%d]" % world
     if args.scale != 1:
         desc += " [--scale %d: not a BASELINE configuration]" % args.scale
     if args.lines is not None and args.workload == "C2":
@@ -376,7 +382,7 @@ def main():
         result = {
             "metric": "line*gridpoint evals/sec (whole job)", "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "grid_points_per_gpu": int(pts), "lines_per_gpu": int(layer.n_lines),
                        "window_W": int(g["W"]), "evals_per_step": evals_total, "parallelism": "grid-range x%d" % world,
