@@ -7,14 +7,21 @@
 
 A step is one pass of the hot path over one batch of synthetic input already resident in
 HBM: per-line preparation (K1), owner-computes accumulation of every line onto the
-wavenumber grid (K2), the fused absorption-coefficient / transmittance / Planck-emission
-sweep (K4) and, for N > 1, the single RCCL all-gather of the per-rank spectrum shards.
+wavenumber grid with the absorption-coefficient / transmittance / Planck-emission sweep folded
+into its output stage (K2), and, for N > 1, the single RCCL all-gather of the per-rank spectrum
+shards.
 
-Workload at N = 1: BASELINE.json configs[1] — CO2, 500-900 cm^-1 at 0.001 cm^-1 (4e5 grid
-points, W = 5000), 65,536 seeded synthetic lines, 1013.25 mbar, 296 K (SURVEY.md §8d "C2").
-For N > 1 the wavenumber grid is sharded by contiguous range and grows with N (weak
-scaling): N x 400 cm^-1, N x 65,536 lines, every rank owns 4e5 grid points.  `--strong` keeps the
-workload fixed and shards it instead (`--workload C3 --strong` is BASELINE config 4).
+Workload (BASELINE.json): N = 1 -> configs[2], the CO2+H2O+CH4 mixed cell, 100-2500 cm^-1 at
+0.001 cm^-1 (2.4e6 grid points, W = 5000), 3 x 131,072 seeded synthetic lines, 1013.25 mbar,
+296 K (SURVEY.md §8d "C3") - the configuration the metric's 1/2/4/8 ladder is quoted on.
+N > 1 -> configs[3]: the SAME fixed workload with the wavenumber grid sharded by contiguous
+range across the N ranks ("scaling": "strong"); shard boundaries are cost-balanced from the line
+positions.  `--workload C1|C2|C5` select the other configurations, `--weak` grows the grid with N
+instead (every rank owns a whole C-sized grid).
+
+`python bench.py --gpus N` with N > 1 and no launcher environment starts its own N ranks (fresh
+child processes, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before anything touches the GPU
+and relays rank 0's line; under torch.distributed.run it uses the ranks it is given.
 
 Rank 0 prints ONE JSON line.  `value` = exact (line, grid-point) contributions of the
 reference's scatter loop (pyradClasses.py:392-400) summed over all ranks and steps / the
@@ -81,7 +88,7 @@ def cpu_baseline(cfg, seconds_target=15.0):
     from oracle import pyrad_oracle as orc
     from oracle import c_oracle
     from pyrad_amd import synthetic
-    mol = cfg["molecules"][0]
+    mol = cfg["molecules"][0]            # a multi-molecule cell is sampled through its first molecule's line list
     sp = synthetic.SPECIES[mol["species"]]
     grid = orc.layer_grid(cfg["P"], cfg["range_min"], cfg["range_max"], cfg["base_resolution"],
                           cfg.get("dynamic_resolution", True))
@@ -111,16 +118,77 @@ def cpu_baseline(cfg, seconds_target=15.0):
     t0 = time.perf_counter()
     _, _, evals_c = c_oracle.create_cross_section_work(sub_c, cfg["T"], cfg["P"], conc, sp["molmass"], qT, sp["q296"], grid)
     t_c = time.perf_counter() - t0
+    # the vectorised NumPy restatement (slice adds instead of the per-point Python loop): what a
+    # NumPy-literate rewrite of the reference's loop reaches on one core
+    n_v = int(min(len(lines["nu"]), max(n_sample * 20, 2000)))
+    pick_v = np.sort(rng.choice(len(lines["nu"]), size=n_v, replace=False))
+    sub_v = {k: v[pick_v] for k, v in lines.items()}
+    lq_v = orc.line_quantities(sub_v, cfg["T"], cfg["P"], conc, sp["molmass"], grid["range_min"], grid["resolution"])
+    evals_v = orc.eval_count(lq_v["index"], grid["W"], grid["n_work"])
+    t0 = time.perf_counter()
+    orc.create_cross_section(sub_v, cfg["T"], cfg["P"], conc, sp["molmass"], qT, sp["q296"], grid, regrid=False)
+    t_v = time.perf_counter() - t0
     return {
+        "vectorised_value": evals_v / t_v,
+        "vectorised_sample": "vectorised NumPy restatement (oracle.create_cross_section, 1 core): %d lines, %d evals in %.2f s" % (
+            n_v, evals_v, t_v),
         "value": evals / t_py, "unit": "line*gridpoint evals/s", "cores": 1, "kind": "port",
         "sample": "%d of %d lines drawn uniformly (seed 0) from the bench workload, %d evals in %.1f s; faithful "
-                  "Python/NumPy scalar restatement of pyradClasses.py:361-400 (oracle.create_cross_section_scalar); "
+                  "Python/NumPy scalar restatement of pyradClasses.py:361-400 (oracle.create_cross_section_scalar) on the %s "
+                  "line list of the workload; "
                   "host has %d logical cores, 1 used (the reference is single-threaded)" % (
-                      n_sample, len(lines["nu"]), evals, t_py, os.cpu_count() or 0),
+                      n_sample, len(lines["nu"]), evals, t_py, mol["species"], os.cpu_count() or 0),
         "c_port_value": evals_c / t_c,
         "c_port_sample": "plain-C restatement (oracle/lbl_oracle.c, gcc -O2, 1 core): %d lines, %d evals in %.2f s" % (
             n_c, evals_c, t_c),
     }
+
+
+def api_path(cfg, reps=5):
+    """The drop-in route: pyrad_amd.model's Layer -> addMolecule -> getAbsCoef -> transmission on the
+    bench workload, host arrays in and out (PCIe included).  ms_per_call = one getAbsCoef after
+    changeTemperature has invalidated every cross section (line prep + accumulate + fused sweep on
+    the resident line lists, then ONE download, the absorption coefficient)."""
+    from pyrad_amd import model, data, settings, engine
+    keep = (settings.RES_MULTIPLIER, data._source, model.Layer.hasAtmosphere)
+    try:
+        settings.set_resolution_multiplier(cfg["base_resolution"] / .01)
+        data.set_source(data.synthetic_source({m["species"]: m["lines"] for m in cfg["molecules"]}))
+        model.Layer.hasAtmosphere = False
+        t0 = time.perf_counter()
+        layer = model.Layer(cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"],
+                            dynamicResolution=cfg.get("dynamic_resolution", True))
+        for m in cfg["molecules"]:
+            layer.addMolecule(m["species"], **m["conc"])
+        t_build = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        k = model.getAbsCoef(layer)                         # first call: uploads the lines, builds the schedule
+        t_first = time.perf_counter() - t0
+        evals = sum(engine.eval_count(iso._lines["nu"], cfg["range_min"], layer.resolution, layer._grid()["W"],
+                                      layer._grid()["n_work"]) for m in layer for iso in m)
+        t_call, t_trans = [], []
+        surf = layer.planck(288)
+        for _ in range(reps):
+            layer.changeTemperature(cfg["T"])               # marks every cross section dirty (cls:741-743)
+            t0 = time.perf_counter()
+            k = model.getAbsCoef(layer)
+            t_call.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            spec = layer.transmission(surf)
+            t_trans.append(time.perf_counter() - t0)
+        ms_call = 1e3 * float(np.median(t_call))
+        return {"ms_per_call": ms_call, "evals_per_s": evals / (ms_call * 1e-3),
+                "ms_transmission": 1e3 * float(np.median(t_trans)),
+                "ms_build_layer": 1e3 * t_build, "ms_first_call": 1e3 * t_first, "bytes_downloaded_per_call": 8 * int(k.size),
+                "what": "model.getAbsCoef(layer) after layer.changeTemperature (recompute on resident line lists + download "
+                        "of the absorption coefficient); ms_transmission = layer.transmission(host spectrum): upload, fold "
+                        "with the resident transmittance, download; medians of %d; checks: %d points, finite %s" % (
+                            reps, spec.size, bool(np.isfinite(spec).all() and np.isfinite(k).all()))}
+    finally:
+        settings.set_resolution_multiplier(keep[0])
+        data.set_source(keep[1])
+        model.Layer.hasAtmosphere = keep[2]
+        engine.shutdown()
 
 
 class _StdoutToStderr:
@@ -138,12 +206,74 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
+# ------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a launcher starts N ranks itself
+# ------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_plan(n_ranks: int, argv, environ, port: int | None = None):
+    """[(argv, env)] for the N child ranks: the torchrun contract (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT), one rendezvous key for the file exchange of the RCCL unique id, and
+    the dmabuf IPC setting RCCL needs on this driver.  Pure host logic (tests/test_bench_launcher_cpu.py)."""
+    port = port or _free_port()
+    base = dict(environ)
+    base.update(WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                PYRAD_RENDEZVOUS_KEY="bench_%d_%d" % (os.getpid(), port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    plan = []
+    for r in range(n_ranks):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        plan.append(([sys.executable, os.path.abspath(__file__)] + list(argv), env))
+    return plan
+
+
+def run_ranks(plan, timeout_s: float = 3000.0) -> int:
+    """Start the ranks, wait for all of them, relay rank 0's stdout (the one JSON line).  A rank that
+    fails ends the others (they would wait for it in the rendezvous) and its status is returned."""
+    import subprocess
+    procs = []
+    for r, (argv, env) in enumerate(plan):
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    t0 = time.time()
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+            if bad or time.time() - t0 > timeout_s:
+                rc = bad[0] if bad else 124
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                break
+            time.sleep(0.05)
+        out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+        for p in procs:
+            try:
+                p.wait(30)
+            except Exception:
+                p.kill()
+        rc = rc or next((p.returncode for p in procs if p.returncode), 0)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
+    ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5"],
+                    help="BASELINE configuration (default C3: the mixed cell the metric is quoted on)")
     ap.add_argument("--variant", type=int, default=None, help="accumulate kernel variant 0..5 (default: library default 5, far-field series)")
     ap.add_argument("--points-per-lane", type=int, default=None)
     ap.add_argument("--line-split", type=int, default=None)
@@ -158,29 +288,44 @@ def main():
                          "the column step keeps them in registers and writes the outgoing spectrum only)")
     ap.add_argument("--longest-first", type=int, default=None, help="0: positional tile order, 1: longest-first worklist, 2: snake order, 3 (default): bin-packed per CU on single-round launches")
     ap.add_argument("--scale", type=int, default=1, help="experiment: widen the per-GPU range and line count by this factor")
-    ap.add_argument("--strong", action="store_true",
-                    help="N > 1: shard the FIXED workload across the ranks (BASELINE config 4 with --workload C3) instead of "
-                         "growing the grid with N; the line then says \"scaling\": \"strong\"")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: grow the grid with N (every rank owns one whole C-sized grid) instead of sharding the FIXED "
+                         "workload (the default, BASELINE config 4; \"scaling\": \"strong\")")
+    ap.add_argument("--strong", action="store_true", help="accepted for compatibility: strong scaling is the default")
+    ap.add_argument("--shards", default="balanced", choices=["balanced", "equal"],
+                    help="N > 1: cost-balanced contiguous shard boundaries from the line positions (default) or equal widths")
+    ap.add_argument("--shard-of", default=None, metavar="G,r",
+                    help="experiment on ONE GPU: run only shard r of a G-way sharding of the workload (no communicator): "
+                         "what rank r of G would compute per step")
+    ap.add_argument("--unfused", action="store_true", help="accumulate launch + separate sweep launch (A/B)")
     ap.add_argument("--lines", type=int, default=None, help="experiment: C2 with this many lines instead of 65,536")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api-path", action="store_true", help="skip the pyrad_amd.model (drop-in API) timing leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather", default="abs_coef", choices=["abs_coef", "all"])
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-gather in stream instead of pipelined")
     ap.add_argument("--check", action="store_true", help="also compare one shard against the oracle (slow)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    # No launcher environment and N > 1: this process only starts the N ranks (it never touches the
+    # GPU, so nothing that has initialised HIP is forked or replaced) and relays rank 0's line.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(run_ranks(spawn_plan(args.gpus, sys.argv[1:], os.environ)))
 
     from pyrad_amd import _native as nat, engine, dist
     rank, local_rank, world = dist.env_world()
     if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d"
-                  % (args.gpus, world, args.gpus), file=sys.stderr)
-        if world == 1:
-            raise SystemExit(2)
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; use "
+                         "--nproc-per-node %d (or no launcher: bench.py starts its own ranks)" % (args.gpus, world, args.gpus))
     ndev = nat.device_count()
     if ndev < 1:
         raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
-    ctx = nat.Context(local_rank if local_rank < ndev else 0)
+    if local_rank >= ndev:
+        raise SystemExit("bench.py: rank %d (LOCAL_RANK %d) has no GPU of its own: %d device(s) visible, one process "
+                         "per GPU is required" % (rank, local_rank, ndev))
+    ctx = nat.Context(local_rank)
     info = ctx.device_info()
     if args.variant is not None:
         ctx.set_option("accum_variant", args.variant)
@@ -204,9 +349,11 @@ def main():
             uid = rdzv.broadcast("rccl_unique_id", nat.Comm.unique_id() if rank == 0 else None)
             comm = nat.Comm(ctx, uid, world, rank)
 
-    cfg, desc = build_workload(args.workload, (1 if args.strong else world) * args.scale)
-    if args.strong and world > 1:
-        desc += " [fixed workload, grid sharded x%d]" % world
+    strong = not args.weak
+    cfg, desc = build_workload(args.workload, (1 if strong else world) * args.scale)
+    if world > 1:
+        desc += (" [fixed workload, grid sharded x%d, %s shards]" % (world, args.shards)) if strong else \
+                (" [grid grows with N: x%d]" % world)
     if args.scale != 1:
         desc += " [--scale %d: not a BASELINE configuration]" % args.scale
     if args.lines is not None and args.workload == "C2":
@@ -217,12 +364,23 @@ def main():
     # With a communicator the steps are software-pipelined over two buffer sets: the all-gather of
     # step k (communicator stream) overlaps the kernels of step k+1 (context stream, other set).
     n_sets = 2 if (comm is not None and not args.no_overlap) else 1
-    shard = (world, rank) if world > 1 else None
     if args.workload == "C5":
         layer_cfgs = [dict(c, molecules=molecules_of(c)) for c in cfg["layers"]]
-        layers = [engine.ResidentColumn(ctx, layer_cfgs, cfg["surface_T"], shard=shard) for _ in range(n_sets)]
     else:
         mols = molecules_of(cfg)
+        layer_cfgs = [dict(cfg, molecules=mols)]
+    shard = None
+    shard_world, shard_rank = world, rank
+    if args.shard_of:
+        shard_world, shard_rank = (int(v) for v in args.shard_of.split(","))
+        desc += " [ONLY shard %d of %d, %s bounds: a one-GPU experiment, not a BASELINE configuration]" % (
+            shard_rank, shard_world, args.shards)
+    if shard_world > 1:
+        shard = (engine.balanced_shards(layer_cfgs, shard_world, shard_rank) if args.shards == "balanced"
+                 else (shard_world, shard_rank))
+    if args.workload == "C5":
+        layers = [engine.ResidentColumn(ctx, layer_cfgs, cfg["surface_T"], shard=shard) for _ in range(n_sets)]
+    else:
         layers = [engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"],
                                        mols, cfg["base_resolution"], cfg.get("dynamic_resolution", True),
                                        shard=shard) for _ in range(n_sets)]
@@ -234,7 +392,7 @@ def main():
         if args.workload == "C5":
             L.enqueue(layer_arrays=bool(args.column_layer_arrays))
         else:
-            L.enqueue(surface_T=288.0)
+            L.enqueue(surface_T=288.0, fused=not args.unfused)
 
     for L in layers:
         prime(L)
@@ -277,7 +435,7 @@ def main():
             if comm is not None:
                 L.enqueue_allgather(comm, overlap_slot=slot)
         else:
-            L.enqueue(surface_T=288.0)
+            L.enqueue(surface_T=288.0, fused=not args.unfused)
             if comm is not None:
                 L.enqueue_allgather(comm, gather_bufs(L), overlap_slot=slot)
 
@@ -354,55 +512,62 @@ def main():
         n_prep, ms_prep = prof["line_prep"]
         n_ag, ms_ag = prof["allgather"]
         g = layer.layers[0].g if is_column else layer.g
-        pts = layer.count if world > 1 else g["n_work"]
-        # algorithmic bytes per launch of the dominant kernel: every line's 7 fp64
-        # HITRAN fields once + every grid point written once
-        balg_acc = 56.0 * layer.n_lines + 8.0 * pts
-        fused_sweep = (not is_column) and len(layer.jobs) == 1      # lbl_layer_step_dev: k, T, I_out leave K2 too
-        if fused_sweep:
-            balg_acc += 24.0 * pts
+        pts = layer.count if layer.plan is not None else g["n_work"]
+        n_arrays = len(layer.layers[0].jobs) if is_column else len(layer.jobs)     # cross-section arrays per layer
+        # Algorithmic bytes per launch of the dominant kernel: every line's 7 fp64 HITRAN
+        # fields read once (56 B/line) + 8 B per grid point for EVERY array the launch writes: one
+        # cross section per line list, and k, transmittance, outgoing radiance when the sweep is fused in.
+        fused_sweep = (not is_column) and not args.unfused and n_sw == 0
         t_acc = (ms_acc / max(n_acc, 1)) * 1e-3
         t_acc_step = (ms_acc / max(n_sampled, 1)) * 1e-3        # all K2 launches of one (sampled) step
+        launches_per_step = max(n_acc // max(n_sampled, 1), 1)   # a column launches K2 once per window group
+        n_xsec_written = (n_arrays * len(layer.layers)) if is_column else n_arrays
+        balg_acc = (56.0 * layer.n_lines + 8.0 * pts * n_xsec_written + (24.0 * pts if fused_sweep else 0.0)) / launches_per_step
         achieved = balg_acc / t_acc / 1e9 if t_acc > 0 else 0.0
-        n_mol_arrays = len(layer.layers[0].jobs) if is_column else len(layer.jobs)
         # per sweep launch: M xsec reads + k, T (, I_out) writes; I_in is computed in-kernel
-        balg_sw = 8.0 * pts * (n_mol_arrays + (2 if is_column else 3))
+        balg_sw = 8.0 * pts * (n_arrays + 3)
         sweep_kernel = "layer_sweep_kernel"
         if is_column:
             # one column_step_kernel launch per step: every layer's cross sections read once, the outgoing
             # spectrum written (+ two arrays per layer when --column-layer-arrays 1)
             n_sw, ms_sw = prof["column_sweep"]
             n_layers = len(layer.layers)
-            balg_sw = 8.0 * pts * (n_mol_arrays * n_layers + 1 + (2 * n_layers if args.column_layer_arrays else 0))
+            balg_sw = 8.0 * pts * (n_arrays * n_layers + 1 + (2 * n_layers if args.column_layer_arrays else 0))
             sweep_kernel = "column_step_kernel"
-        if is_column:
-            balg_acc = balg_acc / max(n_acc // max(n_sampled, 1), 1)      # K2 is launched once per window group
         t_sw = (ms_sw / max(n_sw, 1)) * 1e-3
-        pmc = load_pmc_traffic(args.workload if (args.scale == 1 and args.lines is None and world == 1) else None)
+        standard = args.scale == 1 and args.lines is None and world == 1 and not args.shard_of and not args.unfused
+        pmc = load_pmc(args.workload if standard else None, nat.source_hash())
+        traffic = pmc["hbm"].get("xsec_accumulate_kernel")
         result = {
             "metric": "line*gridpoint evals/sec (whole job)", "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "grid_points_per_gpu": int(pts), "lines_per_gpu": int(layer.n_lines),
                        "window_W": int(g["W"]), "evals_per_step": evals_total, "parallelism": "grid-range x%d" % world,
                        "gathered": args.gather, "device": info["name"], "preconditioning_s": args.precondition_seconds,
+                       "shard_bounds": (None if layer.plan is None else [list(b) for b in layer.plan.bounds]),
                        "allgather": ("none" if comm is None else "in-stream" if n_sets == 1 else
                                      "overlapped with the next step (2 buffer sets)")},
             "roofline": {"bound": "hbm", "kernel": "xsec_accumulate_lds_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc.get("xsec_accumulate_kernel"),
+                         "traffic": traffic, "traffic_stale": (pmc["stale"] if traffic is not None else None),
+                         "traffic_source": pmc["source"],
                          "algorithmic_bytes_per_launch": balg_acc, "avg_launch_ms": t_acc * 1e3, "launches": n_acc,
                          "launches_timed": "every launch of every %d-th timed step (%d of %d steps)" % (every, n_sampled, args.steps),
-                         "note": "compulsory traffic only (56 B/line + 8 B/grid point, + 24 B/grid point when the layer "
-                                 "sweep is fused in): this kernel is fp64-VALU bound by construction (SURVEY.md §8d), "
-                                 "see valu_f64"},
-            "valu_f64": valu_block(evals_local, t_acc_step, direct_ms, args.variant),
+                         "sweep_fused_in": bool(fused_sweep),
+                         "note": "compulsory traffic only (56 B/line + 8 B/grid point per array written: one cross section "
+                                 "per line list, + k, transmittance and radiance when the layer sweep is fused in). This "
+                                 "kernel is fp64-VALU bound by construction (SURVEY.md §8d): valu_f64.busy_frac is its "
+                                 "real utilisation figure"},
+            "valu_f64": valu_block(evals_local, t_acc_step, direct_ms, args.variant, pmc, launches_per_step),
             "roofline_sweep": {"fused_into": "xsec_accumulate_lds_kernel (lbl_layer_step_dev)"} if n_sw == 0 and not is_column else
                               {"bound": "hbm", "kernel": sweep_kernel,
                                "achieved": balg_sw / t_sw / 1e9 if t_sw > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": (balg_sw / t_sw / 1e9 / HBM_PEAK_GBS) if t_sw > 0 else 0.0,
-                               "traffic": pmc.get(sweep_kernel),
+                               "traffic": pmc["hbm"].get(sweep_kernel),
+                               "traffic_stale": (pmc["stale"] if pmc["hbm"].get(sweep_kernel) is not None else None),
                                "algorithmic_bytes_per_launch": balg_sw, "avg_launch_ms": t_sw * 1e3, "launches": n_sw},
             "kernel_ms_per_step": {"line_prep": ms_prep / args.steps, "xsec_accumulate": ms_acc / max(n_sampled, 1),
                                    ("column_step" if is_column else "layer_sweep"): ms_sw / args.steps,
@@ -413,6 +578,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(cfg["layers"][0] if is_column else cfg, args.cpu_seconds)
         if args.check:
             result["check"] = oracle_check(layer, cfg)
+    want_api = rank == 0 and world == 1 and not is_column and not args.no_api_path and not args.shard_of
     if rdzv is not None:
         rdzv.arrive("done")
         rdzv.cleanup()
@@ -422,52 +588,82 @@ def main():
         L.free()
     red.free()
     ctx.close()
+    if want_api:
+        result["api_path"] = api_path(cfg)
     if rank == 0:
         print(json.dumps(result))
 
 
-def valu_block(evals_local, t_acc_step, direct_ms, variant):
-    """fp64 vector-ALU accounting of K2.  The all-direct kernel (variant 3) spends at least 5 fp64
-    instructions per (line, grid point) pair; the default kernel (variant 5) replaces the pairs of
-    distant Lorentz lines by a 30-term series per (line, span), so its pair rate is not bounded by
-    5 instructions per pair and only the direct kernel's rate is priced against the VALU peak."""
+SIMDS = 256 * 4
+CLOCK_HZ = 2.4e9
+
+
+def valu_block(evals_local, t_acc_step, direct_ms, variant, pmc, launches_per_step):
+    """fp64 vector-ALU accounting of K2.
+    busy_frac: the kernel's measured VALU utilisation, SQ_INSTS_VALU (wave-instructions per launch,
+    from the committed rocprofv3 --pmc pass of this very command) x 4 issue cycles per fp64/VALU
+    wave-instruction / (1024 SIMDs x the launch duration measured live in this run x 2.4 GHz).
+    direct_*: the all-direct kernel (variant 3) spends at least 5 fp64 instructions per (line, grid
+    point) pair; the default kernel (variant 5) replaces the pairs of distant Lorentz lines by a
+    30-term series per (line, span), so its PAIR rate is not bounded by 5 instructions per pair and
+    only the direct kernel's rate is priced per pair against the VALU peak."""
     far_field = variant in (None, 5)
     out = {"kernel_evals_per_s": evals_local / t_acc_step if t_acc_step > 0 else 0.0,
            "far_field_series": far_field, "instr_per_eval_direct": FP64_INSTR_PER_EVAL,
            "peak_lane_instr_per_s": FP64_VALU_PEAK_INSTR}
+    insts = pmc["valu"].get("xsec_accumulate_kernel" if far_field else "xsec_accumulate_direct_kernel")
+    if insts and t_acc_step > 0:
+        t_launch = t_acc_step / launches_per_step
+        out.update({"busy_frac": insts * 4.0 / (SIMDS * t_launch * CLOCK_HZ),
+                    "valu_wave_insts_per_launch": insts, "busy_frac_stale": pmc["stale"],
+                    "busy_frac_source": "%s SQ_INSTS_VALU, live launch time %.1f us (rocprofv3 average of that pass: %s us)" % (
+                        pmc["source"], t_launch * 1e6,
+                        ("%.1f" % pmc["avg_us"]["xsec_accumulate_kernel"]) if "xsec_accumulate_kernel" in pmc["avg_us"] else "n/a")})
+    else:
+        out.update({"busy_frac": None, "busy_frac_stale": None})
     t_direct = direct_ms * 1e-3 if direct_ms else (None if far_field else t_acc_step)
     if t_direct:
         rate = evals_local / t_direct
         out.update({"direct_kernel_ms_per_step": t_direct * 1e3, "direct_kernel_evals_per_s": rate,
                     "direct_achieved_lane_instr_per_s": FP64_INSTR_PER_EVAL * rate,
                     "direct_frac": FP64_INSTR_PER_EVAL * rate / FP64_VALU_PEAK_INSTR})
-    out["note"] = ("5 fp64 instr per eval is the running-fraction Lorentz loop's minimum (measured ceiling of that loop "
-                   "alone on this chip: 4.9e12 evals/s, scripts/ubench_fp64.hip); direct_* = the all-direct kernel "
-                   "(accum_variant 3) on the same inputs, timed in an extra untimed pass")
+    out["note"] = ("busy_frac = measured VALU issue utilisation of the default kernel; 5 fp64 instr per eval is the "
+                   "running-fraction Lorentz loop's minimum (measured ceiling of that loop alone on this chip: 4.9e12 "
+                   "evals/s, scripts/ubench_fp64.hip); direct_* = the all-direct kernel (accum_variant 3) on the same "
+                   "inputs, timed in an extra untimed pass")
     return out
 
 
-def load_pmc_traffic(workload):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this workload
-    (profiles/pmc_traffic.json, produced by profiles/collect.sh + summarize.py on the GPU box in
-    separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for gfx950).  PMC counters cannot be read inside a timed run, so this is the value measured
-    for the same command; no entry for the workload -> traffic null."""
+def load_pmc(workload, source_hash):
+    """Committed rocprofv3 --pmc results of this workload (profiles/pmc_traffic.json, produced by
+    profiles/collect.sh + summarize.py on the GPU box in separate FETCH_SIZE / WRITE_SIZE / SQ passes;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read
+    inside a timed run, so these are the values measured for the same command; `stale` says whether
+    the kernel sources have changed since (hash of csrc/ + the header); no entry -> nulls."""
+    out = {"hbm": {}, "valu": {}, "avg_us": {}, "stale": None, "source": None}
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if workload is None or not os.path.isfile(path):
-        return {}
+        return out
     try:
         with open(path) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch", {})
+            e = json.load(f).get(workload, {})
     except (OSError, ValueError):
-        return {}
+        return out
+    if not e:
+        return out
+    out["hbm"] = e.get("hbm_bytes_per_launch", {})
+    out["valu"] = e.get("valu_wave_insts_per_launch", {})
+    out["avg_us"] = e.get("rocprofv3_avg_us", {})
+    out["stale"] = e.get("source_hash") != source_hash
+    out["source"] = "profiles/%s" % e.get("source")
+    return out
 
 
 def oracle_check(layer, cfg):
     from oracle import pyrad_oracle as orc
     ref = orc.layer_properties(cfg)
     got = layer.results()
-    first, count = (layer.first, layer.count) if layer.world > 1 else (0, layer.n)
+    first, count = (layer.first, layer.count) if layer.plan is not None else (0, layer.n)
     sl = slice(first, first + count)
     a, b = got["abs_coef"][sl], ref["abs_coef"][sl]
     return {"max_rel_err_abs_coef": float(np.max(np.abs(a - b) / np.abs(b)))}

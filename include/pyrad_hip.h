@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LBL_ABI_VERSION 1
+#define LBL_ABI_VERSION 2
 
 typedef enum lbl_status {
     LBL_OK = 0,
@@ -111,7 +111,12 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *                            1 plain | 0: positional order (waves then search their line ranges themselves)
  *   "accum_tile_order"       positional order only: 1 (default) natural | 0 one contiguous run of
  *                            tiles per XCD | 2 golden-ratio stride
- *   "accum_blocks_per_cu"    variant 4 only: resident workgroups per CU, 0 = ask the runtime */
+ *   "accum_blocks_per_cu"    variant 4 only: resident workgroups per CU, 0 = ask the runtime
+ *   "layer_step_fused"       1 (default) lbl_layer_step_dev folds the sweep into the accumulate kernel |
+ *                            0 accumulate launch + separate sweep launch (bit-identical; A/B and parity tests)
+ *   "debug_throw"            test hook: 1 / 2 / 3 raise std::bad_alloc / std::runtime_error /
+ *                            std::length_error inside the library; the call must come back as
+ *                            LBL_ERR_OOM / LBL_ERR_STATE / LBL_ERR_OOM (no exception crosses this boundary) */
 int lbl_set_option(lbl_ctx* ctx, const char* key, int value);
 
 /* Kernel timing with HIP events recorded on the context stream around every launch of a
@@ -157,6 +162,7 @@ int lbl_xsec_accumulate(lbl_ctx* ctx, const double* nu, const double* sw, const 
                         const double* delta_air, int64_t n_lines, const lbl_iso_params* iso,
                         const lbl_grid* grid, double* xsec_out, int64_t regime_counts[3]);
 
+#define LBL_MAX_JOBS 65536    /* jobs (isotopologue x layer) per batched call */
 /* Device-resident, asynchronous, batched form: job j accumulates lines[j] under iso[j] /
  * grid[j] into out[j] (n_base doubles).  All jobs run in one launch sequence so that
  * isotopologues, molecules and layers fill the chip together. */
@@ -191,15 +197,20 @@ int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* xsec, const 
                         lbl_buffer* I_in, double surface_T,
                         lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out);
 
-/* One step of a single-isotopologue layer (the gas cell of pyradClasses.py:648 with one
- * addMolecule, isotopeDepth 1): lbl_xsec_accumulate_dev for the one line list followed by
- * lbl_layer_sweep_dev with n_iso = n_mol = 1, in ONE launch sequence: when the work grid is
- * the base grid the sweep of a grid point runs in the accumulate kernel's output stage, right
- * after that point's cross section is final (same arithmetic, bit-identical results, no
- * separate sweep launch and no re-read of the cross section).  P and T come from `iso`, the
- * axis and the shard from `grid`; `xsec` receives the cross section as usual. */
-int lbl_layer_step_dev(lbl_ctx* ctx, lbl_lines* lines, const lbl_iso_params* iso, const lbl_grid* grid,
-                       lbl_buffer* xsec, double conc, double depth, lbl_buffer* I_in, double surface_T,
+/* One step of a layer (the gas cell of pyradClasses.py:648 after its addMolecule calls):
+ * lbl_xsec_accumulate_dev for the layer's n_iso line lists followed by lbl_layer_sweep_dev, in ONE
+ * launch sequence.  When the work grid is the base grid a workgroup owns its grid points for all
+ * line lists, one after the other: every cross section is stored as usual, folded into the
+ * molecule sum and the absorption coefficient while it is still in a register
+ * (pyradClasses.py:566-571, 583, 707-712), and transmittance and outgoing radiance follow in the
+ * output stage of the last line list (pyradClasses.py:716, 784-787) - same arithmetic and order
+ * as the two separate calls, bit-identical results, no sweep launch and no re-read of the cross
+ * sections.  All line lists share `grid` (axis, shard) and the layer's T and P (iso[i].T / .P must
+ * equal iso[0]'s); iso_mol / n_mol / conc as in lbl_layer_sweep_dev; xsec[i] receives the cross
+ * section of line list i.  lbl_set_option("layer_step_fused", 0) forces the two-call form. */
+int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lines, const lbl_iso_params* iso,
+                       const lbl_grid* grid, lbl_buffer* const* xsec, const int32_t* iso_mol, int n_mol,
+                       const double* conc, double depth, lbl_buffer* I_in, double surface_T,
                        lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out);
 
 /* Column fold of Layer.transmission over layers bottom to top (pyradClasses.py:784-787):
@@ -266,6 +277,12 @@ int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int
 int lbl_allgather_overlap_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count,
                               lbl_buffer* recv, int slot);
 int lbl_comm_fence_dev(lbl_comm* comm, int slot);
+/* Cost-balanced (unequal) shards: every rank sends `slot` doubles starting at its own first point,
+ * so the gathered buffer holds rank r's shard in the first count[r] entries of slot r.  This puts
+ * it back in grid order: out[first[r] + i] = gathered[r * slot + i], i < count[r], r < world_size
+ * (first / count: host arrays of world_size entries; out at least max(first[r] + count[r]) long). */
+int lbl_gather_compact_dev(lbl_ctx* ctx, lbl_buffer* gathered, int world_size, int64_t slot,
+                           const int64_t* first, const int64_t* count, lbl_buffer* out);
 
 #ifdef __cplusplus
 }

@@ -87,16 +87,36 @@ def main():
             allt = {}
     if "hbm_bytes_per_launch" in allt:          # old single-workload layout
         allt = {}
-    traffic = {}
+    traffic, valu_insts, avg_us, weights = {}, {}, {}, {}
     for k, v in pmc["kernels"].items():
-        # bench.py times the far-field kernel <R, LS, true>; its extra untimed pass runs the
-        # all-direct kernel <R, LS, false> (reported as valu_f64.direct_*)
+        # bench.py times the far-field kernel <R, LS, FF = true, CHAIN>; its extra untimed pass runs the
+        # all-direct kernel <R, LS, false, CHAIN> (reported as valu_f64.direct_*)
         if k.startswith("xsec_accumulate"):
-            base = "xsec_accumulate_kernel" if "true>" in k else "xsec_accumulate_direct_kernel"
+            targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
+            far = len(targs) >= 3 and targs[2] == "true"
+            base = "xsec_accumulate_kernel" if far else "xsec_accumulate_direct_kernel"
         else:
             base = k
-        traffic[base] = v["hbm_bytes_corrected"]
-    allt[wl] = {"source": "%s_%s_pmc.json" % (tag, wl), "hbm_bytes_per_launch": traffic}
+        # several instantiations can share a base name (a column launches one kernel per window
+        # group): launch-weighted means
+        w = max(v.get("launches_fetch_pass", 1), 1)
+        acc = weights.setdefault(base, [0.0, 0.0, 0.0, 0.0, 0.0])
+        acc[0] += w; acc[1] += w * v["hbm_bytes_corrected"]
+        if "valu" in v and "SQ_INSTS_VALU" in v["valu"]:
+            acc[2] += w * v["valu"]["SQ_INSTS_VALU"]
+        if k in kt:
+            acc[3] += kt[k][0]; acc[4] += kt[k][1]
+    for base, acc in weights.items():
+        traffic[base] = acc[1] / acc[0]
+        if acc[2]:
+            valu_insts[base] = acc[2] / acc[0]
+        if acc[3]:
+            avg_us[base] = acc[4] / acc[3]
+    sys.path.insert(0, os.path.dirname(here))
+    from pyrad_amd import _native
+    allt[wl] = {"source": "%s_%s_pmc.json" % (tag, wl), "source_hash": _native.source_hash(),
+                "hbm_bytes_per_launch": traffic, "valu_wave_insts_per_launch": valu_insts,
+                "rocprofv3_avg_us": avg_us}
     with open(tpath, "w") as f:
         json.dump(allt, f, indent=1, sort_keys=True)
     b = os.path.join(out, "bench_%s.json" % wl)

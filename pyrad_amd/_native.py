@@ -82,8 +82,8 @@ SIGNATURES = {
     "lbl_layer_sweep_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int, _D,
                                       C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                       C.c_int64, C.c_int64, _P, C.c_double, _P, _P, _P]),
-    "lbl_layer_step_dev": (C.c_int, [_P, _P, C.POINTER(IsoParams), C.POINTER(Grid), _P, C.c_double, C.c_double,
-                                     _P, C.c_double, _P, _P, _P]),
+    "lbl_layer_step_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(IsoParams), C.POINTER(Grid), C.POINTER(_P),
+                                     C.POINTER(C.c_int32), C.c_int, _D, C.c_double, _P, C.c_double, _P, _P, _P]),
     "lbl_column_sweep_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), _D, C.c_double, C.c_double, C.c_int64,
                                        C.c_int64, C.c_int64, _P, C.c_double, _P]),
     "lbl_column_step_dev": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.POINTER(_P), C.POINTER(C.c_int32),
@@ -100,6 +100,7 @@ SIGNATURES = {
     "lbl_allgather_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "lbl_allgather_overlap_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int]),
     "lbl_comm_fence_dev": (C.c_int, [_P, C.c_int]),
+    "lbl_gather_compact_dev": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P]),
 }
 
 _lib = None
@@ -111,6 +112,22 @@ def build(force: bool = False) -> str:
         subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=subprocess.DEVNULL)
     return LIB_PATH
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources and build flags (csrc/*.hip, *.h, Makefile, the public header):
+    profiles/pmc_traffic.json records it so that bench.py can tell when committed PMC numbers were
+    measured on other kernels than the ones it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile")
+    for f in files:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(os.path.dirname(_HERE), "include", "pyrad_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def load():
@@ -288,12 +305,33 @@ class Context:
             float(surface_T), abs_coef.h if abs_coef is not None else None, trans.h if trans is not None else None,
             I_out.h if I_out is not None else None))
 
-    def layer_step_dev(self, lines: "Lines", iso: IsoParams, grid: Grid, xsec, conc, depth, I_in=None, surface_T=0.0,
+    def layer_step_dev(self, lines, iso, grid: Grid, xsec, iso_mol, conc, depth, I_in=None, surface_T=0.0,
                        abs_coef=None, trans=None, I_out=None):
-        """Accumulate + sweep of a single-isotopologue layer in one launch sequence."""
+        """Accumulate + sweep of one layer in one launch sequence (lbl_layer_step_dev): ``lines`` /
+        ``iso`` / ``xsec`` are per line list (a single Lines / IsoParams / Buffer is taken as one),
+        ``iso_mol`` maps line list -> molecule, ``conc`` is per molecule."""
+        if isinstance(lines, Lines):
+            lines, iso, xsec = [lines], [iso], [xsec]
+        if np.isscalar(conc):
+            conc = [conc]
+        if iso_mol is None:
+            iso_mol = list(range(len(lines)))
+        n = len(lines)
+        L = (_P * n)(*[l.h for l in lines])
+        I = (IsoParams * n)(*iso)
+        X = (_P * n)(*[b.h for b in xsec])
+        M = (C.c_int32 * n)(*[int(m) for m in iso_mol])
+        cc = (C.c_double * max(len(conc), 1))(*[float(c) for c in conc])
         h = lambda b: b.h if b is not None else None
-        self.check(self.lib.lbl_layer_step_dev(self.h, lines.h, C.byref(iso), C.byref(grid), xsec.h, float(conc),
-                                               float(depth), h(I_in), float(surface_T), h(abs_coef), h(trans), h(I_out)))
+        self.check(self.lib.lbl_layer_step_dev(self.h, n, L, I, C.byref(grid), X, M, len(conc), cc, float(depth), h(I_in),
+                                               float(surface_T), h(abs_coef), h(trans), h(I_out)))
+
+    def gather_compact_dev(self, gathered, slot, bounds, out):
+        """padded all-gather result (slot r = rank r's shard) -> grid order (lbl_gather_compact_dev)."""
+        w = len(bounds)
+        F = (C.c_int64 * w)(*[int(f) for f, _ in bounds])
+        K = (C.c_int64 * w)(*[int(c) for _, c in bounds])
+        self.check(self.lib.lbl_gather_compact_dev(self.h, gathered.h, w, int(slot), F, K, out.h))
 
     def column_step_dev(self, layers, range_min, range_max, n, I_out, I_in=None, surface_T=0.0, first=0, count=0):
         """layers: bottom to top, each dict(xsec=[Buffer], iso_mol=[int], conc=[float], P, T, depth,

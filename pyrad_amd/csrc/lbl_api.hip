@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -69,6 +70,7 @@ struct lbl_ctx {
     int lpt = 3;             // longest-first worklist: 3 (default) bin-packed per CU when the launch is one round; 2 snake; 1 plain; 0 positional
     int tile_order = 1;      // 1: natural order (default; measured 8 % faster on the clustered C2 grid:
                              // all CUs work through one region together); 0: each XCD gets a contiguous run
+    bool no_fuse = false;    // lbl_layer_step_dev as accumulate + separate sweep launch (A/B, parity tests)
     int live_objects = 0;
     // event timing (lbl_profile_*)
     unsigned profiling = 0;        // bit k set: time kernel class k
@@ -93,15 +95,29 @@ struct lbl_lines {
 
 static thread_local std::string g_err;
 
-static int fail(lbl_ctx* ctx, int code, const char* fmt, ...) {
+static int fail(lbl_ctx* ctx, int code, const char* fmt, ...) noexcept {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf; else g_err = buf;
+    try {
+        if (ctx) ctx->err = buf; else g_err = buf;
+    } catch (...) {
+        // the message is lost, the status code is not
+    }
     return code;
 }
+
+// No C++ exception crosses the C boundary (include/pyrad_hip.h): every extern "C" entry point is a
+// function-try-block closed by this handler list.  Host containers sized by caller input
+// (std::vector in enqueue_accumulate / group_schedule / lbl_last_regime_counts ...) throw
+// bad_alloc or length_error on absurd sizes: both are reported as LBL_ERR_OOM.
+#define LBL_GUARD_END(ctx_expr)                                                                          \
+    catch (const std::bad_alloc&) { return fail((ctx_expr), LBL_ERR_OOM, "%s: host allocation failed", __func__); }      \
+    catch (const std::length_error&) { return fail((ctx_expr), LBL_ERR_OOM, "%s: host allocation too large", __func__); } \
+    catch (const std::exception& e) { return fail((ctx_expr), LBL_ERR_STATE, "%s: %s", __func__, e.what()); }             \
+    catch (...) { return fail((ctx_expr), LBL_ERR_STATE, "%s: unknown C++ exception", __func__); }
 
 #define HIP_TRY(ctx, expr)                                                                         \
     do {                                                                                           \
@@ -193,16 +209,16 @@ static bool needs_regrid(const lbl_grid& g) {
 // ----------------------------------------------------------------------------------------
 extern "C" int lbl_abi_version(void) { return LBL_ABI_VERSION; }
 
-extern "C" int lbl_device_count(int* count) {
+extern "C" int lbl_device_count(int* count) try {
     if (!count) return fail(nullptr, LBL_ERR_BAD_ARG, "count is NULL");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { *count = 0; return fail(nullptr, LBL_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
     *count = n;
     return LBL_OK;
-}
+} LBL_GUARD_END(nullptr)
 
-extern "C" int lbl_ctx_create(int device, lbl_ctx** out) {
+extern "C" int lbl_ctx_create(int device, lbl_ctx** out) try {
     if (!out) return fail(nullptr, LBL_ERR_BAD_ARG, "out is NULL");
     *out = nullptr;
     int n = 0;
@@ -220,9 +236,9 @@ extern "C" int lbl_ctx_create(int device, lbl_ctx** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
     *out = ctx;
     return LBL_OK;
-}
+} LBL_GUARD_END(nullptr)
 
-extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) {
+extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) try {
     if (!ctx) return LBL_OK;
     if (ctx->live_objects != 0) return fail(ctx, LBL_ERR_STATE, "%d device objects still alive", ctx->live_objects);
     (void)hipSetDevice(ctx->device);
@@ -237,23 +253,23 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) {
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
 extern "C" const char* lbl_last_error(const lbl_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
-extern "C" int lbl_sync(lbl_ctx* ctx) {
+extern "C" int lbl_sync(lbl_ctx* ctx) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_ctx_stream(lbl_ctx* ctx, void** stream) {
+extern "C" int lbl_ctx_stream(lbl_ctx* ctx, void** stream) try {
     if (!ctx || !stream) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     *stream = (void*)ctx->stream;
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes) {
+extern "C" int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     hipDeviceProp_t prop;
     HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
@@ -261,15 +277,15 @@ extern "C" int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu
     if (n_cu) *n_cu = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_profile_enable(lbl_ctx* ctx, int on) {
+extern "C" int lbl_profile_enable(lbl_ctx* ctx, int on) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     ctx->profiling = on > 0 ? (unsigned)on : 0u;
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_profile_reserve(lbl_ctx* ctx, int n_events) {
+extern "C" int lbl_profile_reserve(lbl_ctx* ctx, int n_events) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     while ((int)ctx->ev_pool.size() < n_events) {
@@ -278,9 +294,9 @@ extern "C" int lbl_profile_reserve(lbl_ctx* ctx, int n_events) {
         ctx->ev_pool.push_back(e);
     }
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_profile_reset(lbl_ctx* ctx) {
+extern "C" int lbl_profile_reset(lbl_ctx* ctx) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& v : ctx->ev_rec) {
@@ -288,9 +304,9 @@ extern "C" int lbl_profile_reset(lbl_ctx* ctx) {
         v.clear();
     }
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_profile_read(lbl_ctx* ctx, int kind, int64_t* launches, double* total_ms) {
+extern "C" int lbl_profile_read(lbl_ctx* ctx, int kind, int64_t* launches, double* total_ms) try {
     if (!ctx || !launches || !total_ms) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     if (kind < 0 || kind >= kProfileKinds) return fail(ctx, LBL_ERR_BAD_ARG, "kind out of range");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -303,7 +319,7 @@ extern "C" int lbl_profile_read(lbl_ctx* ctx, int kind, int64_t* launches, doubl
     *launches = (int64_t)ctx->ev_rec[kind].size();
     *total_ms = tot;
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
 // hook for lbl_comm.hip: time the all-gather like any other kernel class
 namespace lbl {
@@ -313,7 +329,7 @@ void comm_prof_end(lbl_ctx* ctx, void* start) { prof_end(ctx, PROF_GATHER, (hipE
 
 // Tuning knobs for benchmarking and A/B parity runs (not part of the reference surface):
 //   "accum_variant" 0 | 1 | 2,  "accum_points_per_lane" 0 (auto) | 1 | 2 | 4 | 8
-extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) {
+extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) try {
     if (!ctx || !key) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     if (!strcmp(key, "accum_variant")) {
         if (value < 0 || value > 5) return fail(ctx, LBL_ERR_BAD_ARG, "accum_variant must be 0..5");
@@ -335,16 +351,24 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) {
         if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_line_split must be 0, 1, 2, 4 or 8");
         ctx->accum_LS = value;
+    } else if (!strcmp(key, "layer_step_fused")) {
+        if (value < 0 || value > 1) return fail(ctx, LBL_ERR_BAD_ARG, "layer_step_fused must be 0 or 1");
+        ctx->no_fuse = value == 0;
+    } else if (!strcmp(key, "debug_throw")) {
+        // test hook: raise inside the library to prove that the boundary holds (tests/test_gpu_abi.py)
+        if (value == 1) throw std::bad_alloc();
+        if (value == 2) throw std::runtime_error("debug_throw");
+        if (value == 3) { std::vector<double> v; v.reserve(v.max_size() + 1); }     // length_error
     } else {
         return fail(ctx, LBL_ERR_BAD_ARG, "unknown option '%s'", key);
     }
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
 // ----------------------------------------------------------------------------------------
 // buffers
 // ----------------------------------------------------------------------------------------
-extern "C" int lbl_buffer_create(lbl_ctx* ctx, int64_t n, lbl_buffer** out) {
+extern "C" int lbl_buffer_create(lbl_ctx* ctx, int64_t n, lbl_buffer** out) try {
     if (!ctx || !out) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative length");
@@ -356,9 +380,9 @@ extern "C" int lbl_buffer_create(lbl_ctx* ctx, int64_t n, lbl_buffer** out) {
     ctx->live_objects++;
     *out = b;
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_buffer_destroy(lbl_buffer* buf) {
+extern "C" int lbl_buffer_destroy(lbl_buffer* buf) try {
     if (!buf) return LBL_OK;
     lbl_ctx* ctx = buf->ctx;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -366,15 +390,15 @@ extern "C" int lbl_buffer_destroy(lbl_buffer* buf) {
     ctx->live_objects--;
     delete buf;
     return LBL_OK;
-}
+} LBL_GUARD_END(buf ? buf->ctx : nullptr)
 
-extern "C" int lbl_buffer_size(const lbl_buffer* buf, int64_t* n) {
+extern "C" int lbl_buffer_size(const lbl_buffer* buf, int64_t* n) try {
     if (!buf || !n) return fail(nullptr, LBL_ERR_BAD_ARG, "NULL argument");
     *n = buf->n;
     return LBL_OK;
-}
+} LBL_GUARD_END(buf ? buf->ctx : nullptr)
 
-extern "C" int lbl_buffer_upload(lbl_buffer* buf, const double* host, int64_t n, int64_t dst_offset) {
+extern "C" int lbl_buffer_upload(lbl_buffer* buf, const double* host, int64_t n, int64_t dst_offset) try {
     if (!buf) return fail(nullptr, LBL_ERR_BAD_ARG, "buf is NULL");
     lbl_ctx* ctx = buf->ctx;
     if (n < 0 || dst_offset < 0 || dst_offset + n > buf->n) return fail(ctx, LBL_ERR_BAD_ARG, "upload range out of bounds");
@@ -383,9 +407,9 @@ extern "C" int lbl_buffer_upload(lbl_buffer* buf, const double* host, int64_t n,
     HIP_TRY(ctx, hipMemcpyAsync(buf->d + dst_offset, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // the host pointer is not kept past return
     return LBL_OK;
-}
+} LBL_GUARD_END(buf ? buf->ctx : nullptr)
 
-extern "C" int lbl_buffer_download(lbl_buffer* buf, double* host, int64_t n, int64_t src_offset) {
+extern "C" int lbl_buffer_download(lbl_buffer* buf, double* host, int64_t n, int64_t src_offset) try {
     if (!buf) return fail(nullptr, LBL_ERR_BAD_ARG, "buf is NULL");
     lbl_ctx* ctx = buf->ctx;
     if (n < 0 || src_offset < 0 || src_offset + n > buf->n) return fail(ctx, LBL_ERR_BAD_ARG, "download range out of bounds");
@@ -394,9 +418,9 @@ extern "C" int lbl_buffer_download(lbl_buffer* buf, double* host, int64_t n, int
     HIP_TRY(ctx, hipMemcpyAsync(host, buf->d + src_offset, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return LBL_OK;
-}
+} LBL_GUARD_END(buf ? buf->ctx : nullptr)
 
-extern "C" int lbl_buffer_fill(lbl_buffer* buf, double value) {
+extern "C" int lbl_buffer_fill(lbl_buffer* buf, double value) try {
     if (!buf) return fail(nullptr, LBL_ERR_BAD_ARG, "buf is NULL");
     lbl_ctx* ctx = buf->ctx;
     if (buf->n == 0) return LBL_OK;
@@ -411,20 +435,20 @@ extern "C" int lbl_buffer_fill(lbl_buffer* buf, double value) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return LBL_OK;
-}
+} LBL_GUARD_END(buf ? buf->ctx : nullptr)
 
-extern "C" int lbl_buffer_devptr(lbl_buffer* buf, void** devptr) {
+extern "C" int lbl_buffer_devptr(lbl_buffer* buf, void** devptr) try {
     if (!buf || !devptr) return fail(nullptr, LBL_ERR_BAD_ARG, "NULL argument");
     *devptr = (void*)buf->d;
     return LBL_OK;
-}
+} LBL_GUARD_END(buf ? buf->ctx : nullptr)
 
 // ----------------------------------------------------------------------------------------
 // line lists
 // ----------------------------------------------------------------------------------------
 extern "C" int lbl_lines_create(lbl_ctx* ctx, const double* nu, const double* sw, const double* elower,
                                 const double* gamma_air, const double* gamma_self, const double* n_air,
-                                const double* delta_air, int64_t n_lines, lbl_lines** out) {
+                                const double* delta_air, int64_t n_lines, lbl_lines** out) try {
     if (!ctx || !out) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
     if (n_lines < 0 || n_lines > 2000000000LL) return fail(ctx, LBL_ERR_BAD_ARG, "bad line count");
@@ -434,25 +458,31 @@ extern "C" int lbl_lines_create(lbl_ctx* ctx, const double* nu, const double* sw
     for (int64_t i = 1; i < n_lines; ++i)
         if (!(nu[i] >= nu[i - 1])) return fail(ctx, LBL_ERR_BAD_ARG, "nu must be non-decreasing (line %lld)", (long long)i);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // host-side allocations first: if they throw, nothing on the device has to be released
+    std::vector<double> host_nu(nu, nu + n_lines);
+    lbl_lines* L = new (std::nothrow) lbl_lines{ctx, nullptr, n_lines, {}, 0};
+    if (!L) return fail(ctx, LBL_ERR_OOM, "host allocation failed");
+    L->host_nu.swap(host_nu);
     double* d = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&d, (size_t)std::max<int64_t>(n_lines, 1) * 7 * sizeof(double)));
+    {
+        hipError_t em = hipMalloc((void**)&d, (size_t)std::max<int64_t>(n_lines, 1) * 7 * sizeof(double));
+        if (em != hipSuccess) { delete L; return fail(ctx, em == hipErrorOutOfMemory ? LBL_ERR_OOM : LBL_ERR_HIP, "line list allocation: %s", hipGetErrorString(em)); }
+    }
+    L->d = d;
     for (int k = 0; k < 7 && n_lines > 0; ++k) {
         hipError_t e = hipMemcpyAsync(d + (size_t)k * n_lines, src[k], (size_t)n_lines * sizeof(double),
                                       hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, LBL_ERR_HIP, "line upload: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipFree(d); delete L; return fail(ctx, LBL_ERR_HIP, "line upload: %s", hipGetErrorString(e)); }
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { (void)hipFree(d); return fail(ctx, LBL_ERR_HIP, "line upload: %s", hipGetErrorString(e)); }
-    lbl_lines* L = new (std::nothrow) lbl_lines{ctx, d, n_lines, {}, 0};
-    if (!L) { (void)hipFree(d); return fail(ctx, LBL_ERR_OOM, "host allocation failed"); }
-    L->host_nu.assign(nu, nu + n_lines);
+    if (e != hipSuccess) { (void)hipFree(d); delete L; return fail(ctx, LBL_ERR_HIP, "line upload: %s", hipGetErrorString(e)); }
     L->serial = ++ctx->lines_serial;
     ctx->live_objects++;
     *out = L;
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_lines_destroy(lbl_lines* lines) {
+extern "C" int lbl_lines_destroy(lbl_lines* lines) try {
     if (!lines) return LBL_OK;
     lbl_ctx* ctx = lines->ctx;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -460,13 +490,13 @@ extern "C" int lbl_lines_destroy(lbl_lines* lines) {
     ctx->live_objects--;
     delete lines;
     return LBL_OK;
-}
+} LBL_GUARD_END(lines ? lines->ctx : nullptr)
 
-extern "C" int lbl_lines_count(const lbl_lines* lines, int64_t* n) {
+extern "C" int lbl_lines_count(const lbl_lines* lines, int64_t* n) try {
     if (!lines || !n) return fail(nullptr, LBL_ERR_BAD_ARG, "NULL argument");
     *n = lines->n;
     return LBL_OK;
-}
+} LBL_GUARD_END(lines ? lines->ctx : nullptr)
 
 // ----------------------------------------------------------------------------------------
 // the hot path
@@ -547,13 +577,14 @@ static void choose_shape(const lbl_ctx* ctx, int variant, long long total_points
 // evaluates the same correctly rounded IEEE expression (nu - range_min) / resolution on the same
 // doubles (host and device code are built without fast-math), and truncation is shared.
 static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::vector<int>& jobs_in_group,
-                                               lbl_lines* const* lines, const lbl_grid* grid, int R, int LS, long long tile_pts) {
+                                               lbl_lines* const* lines, const lbl_grid* grid, int R, int LS, long long tile_pts,
+                                               bool chain) {
     std::vector<uint64_t> key;
     const bool far_field = variant == 5;
     int far_half_spans = 0;
     double far_cost = 1.0;
     if (far_field) accumulate_far_field_params(R, &far_half_spans, &far_cost);
-    key.push_back((uint64_t)R << 32 | (uint64_t)LS << 8 | (uint64_t)ctx->lpt << 1 | (uint64_t)far_field);
+    key.push_back((uint64_t)R << 32 | (uint64_t)LS << 8 | (uint64_t)chain << 4 | (uint64_t)ctx->lpt << 1 | (uint64_t)far_field);
     for (int j : jobs_in_group) {
         long long sf, sc;
         shard_range(grid[j], &sf, &sc);
@@ -616,7 +647,8 @@ static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const 
                 const double n_near = (double)(e[5] - e[4]);
                 cost += n_near * (5.0 * R + 29.0) + n_edge * 8.0 * R + n_far * far_cost * 5.0 * R + 600.0;
             }
-            items.push_back({(int)(cost + 0.5), (int)k, (int)t});
+            if (chain && k > 0) items[(size_t)t].count += (int)(cost + 0.5);      // one workgroup walks every line list of the chain
+            else items.push_back({(int)(cost + 0.5), (int)k, (int)t});
         }
     }
     std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.count > y.count; });
@@ -673,7 +705,10 @@ struct DbgOut { long long* index; double* lhw; double* ghw; double* inten; int32
 
 static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines, const lbl_iso_params* iso,
                               const lbl_grid* grid, double* const* out_dev, const DbgOut* dbg, bool prep_only,
-                              const FusedSweep* fuse = nullptr) {
+                              const FusedSweep* fuse = nullptr, const int32_t* chain_flags = nullptr,
+                              const double* chain_conc = nullptr) {
+    // fuse != NULL: the n_jobs jobs are the line lists of ONE layer (same grid) and form a chain:
+    // one workgroup accumulates all of them on its points and folds the layer sweep in
     if (n_jobs <= 0) return LBL_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // layout of the scratch arenas
@@ -749,6 +784,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             ++e;
         }
         Group g{k, e - k, 0, 0, 0, ctx->accum_variant, nullptr, 0, nullptr, {}};
+        if (fuse) pts /= (e - k);            // a chain: one grid, its line lists one after the other
         choose_shape(ctx, g.variant, pts, lns, mh, &g.R, &g.LS);
         // with the R actually chosen (a small grid may have shrunk it): does any job of the group have far lines?
         if (ctx->accum_variant == 5 && mxh < 32LL * g.R * (far_half_spans + 1)) g.variant = 3;
@@ -756,7 +792,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             // cached host schedule of this group: dispatch order + the line ranges of every span
             std::vector<int> members(order.begin() + k, order.begin() + e);
             const lbl_ctx::Schedule* sc = group_schedule(ctx, g.variant, members, lines, grid, g.R, g.LS,
-                                                         accumulate_tile_points(g.R, g.LS, g.variant));
+                                                         accumulate_tile_points(g.R, g.LS, g.variant), fuse != nullptr);
             if (!sc) return fail(ctx, LBL_ERR_OOM, "schedule allocation failed");
             g.worklist = sc->d_list; g.total_tiles = sc->total; g.tabs = sc->d_tabs; g.tab_off = sc->tab_off;
         }
@@ -810,7 +846,14 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             a.flush_every = (a.H + 64 * g.R + 1 <= 40000) ? 32 : 16;
             a.pad = ctx->tile_order;
             a.span_tab = g.tabs ? g.tabs + g.tab_off[(size_t)(k - g.first)] : nullptr;
-            if (fuse && n_jobs == 1) a.fuse = *fuse;
+            a.chain_len = 1;
+            if (fuse) {
+                // (a chain is one group: same grid, so same window class; its jobs keep their order)
+                a.chain_len = (k == g.first) ? g.count : 1;
+                a.chain_flags = chain_flags ? chain_flags[j] : (CHAIN_MOL_FIRST | CHAIN_MOL_LAST);
+                a.conc = chain_conc ? chain_conc[j] : 0.0;
+                if (k == g.first) a.fuse = *fuse;
+            }
             g.max_tiles = std::max(g.max_tiles, a.n_tiles);
             if (balanced) {
                 const size_t gi = (size_t)(&g - &groups[0]);
@@ -879,8 +922,9 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             launch_accumulate_balanced(da + g.first, g.count, (int)S, g.R, group_workers[gi], spans, cnts, prefix, slab,
                                        ctx->stream);
         } else {
-            launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, g.variant, g.worklist, g.total_tiles,
-                              ctx->stream);
+            // a chain of one line list is an ordinary job with the fused output stage
+            launch_accumulate(da + g.first, fuse ? 1 : g.count, g.max_tiles, g.R, g.LS, g.variant, g.worklist, g.total_tiles,
+                              fuse != nullptr && g.count > 1, ctx->stream);
         }
         prof_end(ctx, PROF_ACCUM, ev);
         HIP_TRY(ctx, hipGetLastError());
@@ -897,9 +941,10 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
 }
 
 extern "C" int lbl_xsec_accumulate_dev(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines, const lbl_iso_params* iso,
-                                       const lbl_grid* grid, lbl_buffer* const* out) {
+                                       const lbl_grid* grid, lbl_buffer* const* out) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (n_jobs < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative job count");
+    if (n_jobs > LBL_MAX_JOBS) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d jobs per batch", LBL_MAX_JOBS);
     if (n_jobs == 0) return LBL_OK;
     if (!lines || !iso || !grid || !out) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     std::vector<double*> outs(n_jobs);
@@ -909,9 +954,9 @@ extern "C" int lbl_xsec_accumulate_dev(lbl_ctx* ctx, int n_jobs, lbl_lines* cons
         outs[j] = out[j]->d;
     }
     return enqueue_accumulate(ctx, n_jobs, lines, iso, grid, outs.data(), nullptr, false);
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_last_regime_counts(lbl_ctx* ctx, int n_jobs, int64_t* counts) {
+extern "C" int lbl_last_regime_counts(lbl_ctx* ctx, int n_jobs, int64_t* counts) try {
     if (!ctx || !counts) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     if (n_jobs < 0 || n_jobs > ctx->last_jobs) return fail(ctx, LBL_ERR_BAD_ARG, "n_jobs exceeds the last batch (%d)", ctx->last_jobs);
     if (n_jobs == 0) return LBL_OK;
@@ -929,12 +974,12 @@ extern "C" int lbl_last_regime_counts(lbl_ctx* ctx, int n_jobs, int64_t* counts)
         counts[3 * j] = c[0]; counts[3 * j + 1] = c[1]; counts[3 * j + 2] = c[2];
     }
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
 extern "C" int lbl_xsec_accumulate(lbl_ctx* ctx, const double* nu, const double* sw, const double* elower,
                                    const double* gamma_air, const double* gamma_self, const double* n_air,
                                    const double* delta_air, int64_t n_lines, const lbl_iso_params* iso,
-                                   const lbl_grid* grid, double* xsec_out, int64_t regime_counts[3]) {
+                                   const lbl_grid* grid, double* xsec_out, int64_t regime_counts[3]) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (!iso || !grid || !xsec_out) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     int rc = check_grid(ctx, grid);
@@ -955,11 +1000,11 @@ extern "C" int lbl_xsec_accumulate(lbl_ctx* ctx, const double* nu, const double*
     lbl_lines_destroy(L);
     if (rc) ctx->err = keep;
     return rc;
-}
+} LBL_GUARD_END(ctx)
 
 extern "C" int lbl_line_quantities(lbl_ctx* ctx, lbl_lines* lines, const lbl_iso_params* iso, const lbl_grid* grid,
                                    int64_t* index, double* lorentz_hw, double* gauss_hw, double* intensity,
-                                   int32_t* regime) {
+                                   int32_t* regime) try {
     if (!ctx || !lines || !iso || !grid) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     const size_t n = (size_t)lines->n;
     if (n == 0) return LBL_OK;
@@ -990,7 +1035,7 @@ extern "C" int lbl_line_quantities(lbl_ctx* ctx, lbl_lines* lines, const lbl_iso
     if (rc) return rc;
     if (e != hipSuccess) return fail(ctx, LBL_ERR_HIP, "line_quantities: %s", hipGetErrorString(e));
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
 // ----------------------------------------------------------------------------------------
 // sweeps
@@ -1012,7 +1057,7 @@ static int check_buf(lbl_ctx* ctx, const lbl_buffer* b, int64_t n, const char* w
 extern "C" int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* xsec, const int32_t* iso_mol, int n_mol,
                                    const double* conc, double P, double T, double depth, double range_min,
                                    double range_max, int64_t n, int64_t first, int64_t count, lbl_buffer* I_in,
-                                   double surface_T, lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out) {
+                                   double surface_T, lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (n_iso < 0 || n_iso > kMaxIso || n_mol < 0 || n_mol > kMaxIso) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d isotopologues per sweep", kMaxIso);
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
@@ -1052,27 +1097,43 @@ extern "C" int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* x
     prof_end(ctx, PROF_SWEEP, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, lbl_lines* lines, const lbl_iso_params* iso, const lbl_grid* grid,
-                                  lbl_buffer* xsec, double conc, double depth, lbl_buffer* I_in, double surface_T,
-                                  lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out) {
+extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lines, const lbl_iso_params* iso,
+                                  const lbl_grid* grid, lbl_buffer* const* xsec, const int32_t* iso_mol, int n_mol,
+                                  const double* conc, double depth, lbl_buffer* I_in, double surface_T,
+                                  lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
-    if (!lines || !iso || !grid || !xsec) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    if (n_iso < 1 || n_iso > kMaxIso || n_mol < 1 || n_mol > kMaxIso) return fail(ctx, LBL_ERR_BAD_ARG, "1..%d line lists and molecules per layer step", kMaxIso);
+    if (!lines || !iso || !grid || !xsec || !iso_mol || !conc) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     int rc;
+    if ((rc = check_grid(ctx, grid))) return rc;
     const int64_t n = grid->n_base;
-    if ((rc = check_buf(ctx, xsec, n, "xsec", true))) return rc;
+    std::vector<double*> outs((size_t)n_iso);
+    std::vector<lbl_grid> grids((size_t)n_iso, *grid);
+    std::vector<int32_t> flags((size_t)n_iso, 0);
+    std::vector<double> link_conc((size_t)n_iso, 0.0);
+    for (int i = 0; i < n_iso; ++i) {
+        if ((rc = check_buf(ctx, xsec[i], n, "xsec", true))) return rc;
+        if (iso_mol[i] < 0 || iso_mol[i] >= n_mol || (i > 0 && iso_mol[i] < iso_mol[i - 1]))
+            return fail(ctx, LBL_ERR_BAD_ARG, "iso_mol must be non-decreasing and < n_mol");
+        if (iso[i].T != iso[0].T || iso[i].P != iso[0].P)
+            return fail(ctx, LBL_ERR_BAD_ARG, "line list %d: T and P must be the layer's (those of line list 0)", i);
+        outs[i] = xsec[i]->d;
+        if (i == 0 || iso_mol[i] != iso_mol[i - 1]) flags[i] |= CHAIN_MOL_FIRST;
+        if (i == n_iso - 1 || iso_mol[i] != iso_mol[i + 1]) flags[i] |= CHAIN_MOL_LAST;
+        link_conc[i] = conc[iso_mol[i]];
+    }
     if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
     if ((rc = check_buf(ctx, abs_coef, n, "abs_coef", false))) return rc;
     if ((rc = check_buf(ctx, trans, n, "trans", false))) return rc;
     if ((rc = check_buf(ctx, I_out, n, "I_out", false))) return rc;
     if (I_out && !I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "I_out needs I_in or surface_T > 0");
-    double* out = xsec->d;
-    const bool fusable = (ctx->accum_variant == 3 || ctx->accum_variant == 5) && !needs_regrid(*grid);
+    const bool fusable = (ctx->accum_variant == 3 || ctx->accum_variant == 5) && !needs_regrid(*grid) && !ctx->no_fuse;
     if (fusable) {
         FusedSweep f;
         memset(&f, 0, sizeof f);
-        f.conc = conc; f.P = iso->P; f.T = iso->T; f.depth = depth;
+        f.P = iso[0].P; f.T = iso[0].T; f.depth = depth;
         f.start = grid->range_min; f.stop = grid->range_max; f.step = axis_step(grid->range_min, grid->range_max, n);
         planck_constants(&f.pa, &f.pb);
         f.surface_T = surface_T;
@@ -1081,21 +1142,21 @@ extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, lbl_lines* lines, const lbl_iso_
         f.trans = trans ? trans->d : nullptr;
         f.I_out = I_out ? I_out->d : nullptr;
         f.n = n; f.on = 1;
-        return enqueue_accumulate(ctx, 1, &lines, iso, grid, &out, nullptr, false, &f);
+        return enqueue_accumulate(ctx, n_iso, lines, iso, grids.data(), outs.data(), nullptr, false, &f, flags.data(),
+                                  link_conc.data());
     }
     // a work grid that needs the regrid kernel, or a kernel variant without the fused stage: two steps
-    if ((rc = enqueue_accumulate(ctx, 1, &lines, iso, grid, &out, nullptr, false))) return rc;
-    const int32_t mol0 = 0;
+    if ((rc = enqueue_accumulate(ctx, n_iso, lines, iso, grids.data(), outs.data(), nullptr, false))) return rc;
     long long sf, sc;
     shard_range(*grid, &sf, &sc);
     const bool whole = sc == grid->n_work;
-    return lbl_layer_sweep_dev(ctx, 1, &xsec, &mol0, 1, &conc, iso->P, iso->T, depth, grid->range_min, grid->range_max, n,
-                               whole ? 0 : sf, whole ? 0 : sc, I_in, surface_T, abs_coef, trans, I_out);
-}
+    return lbl_layer_sweep_dev(ctx, n_iso, xsec, iso_mol, n_mol, conc, iso[0].P, iso[0].T, depth, grid->range_min,
+                               grid->range_max, n, whole ? 0 : sf, whole ? 0 : sc, I_in, surface_T, abs_coef, trans, I_out);
+} LBL_GUARD_END(ctx)
 
 extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const* trans, const double* layer_T,
                                     double range_min, double range_max, int64_t n, int64_t first, int64_t count,
-                                    lbl_buffer* I_in, double surface_T, lbl_buffer* I_out) {
+                                    lbl_buffer* I_in, double surface_T, lbl_buffer* I_out) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (n_layers < 0 || n_layers > kMaxLayers) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d layers", kMaxLayers);
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
@@ -1131,13 +1192,13 @@ extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* cons
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
 extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_iso, lbl_buffer* const* xsec,
                                    const int32_t* iso_mol, const int32_t* n_mol, const double* conc, const double* P,
                                    const double* T, const double* depth, double range_min, double range_max, int64_t n,
                                    int64_t first, int64_t count, lbl_buffer* I_in, double surface_T,
-                                   lbl_buffer* const* abs_coef, lbl_buffer* const* trans, lbl_buffer* I_out) {
+                                   lbl_buffer* const* abs_coef, lbl_buffer* const* trans, lbl_buffer* I_out) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (n_layers < 0 || n_layers > kMaxLayers) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d layers", kMaxLayers);
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
@@ -1189,9 +1250,9 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_sum_dev(lbl_ctx* ctx, int n_in, lbl_buffer* const* in, int64_t n, lbl_buffer* out) {
+extern "C" int lbl_sum_dev(lbl_ctx* ctx, int n_in, lbl_buffer* const* in, int64_t n, lbl_buffer* out) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (n_in < 0 || n_in > kMaxIso) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d inputs", kMaxIso);
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
@@ -1209,9 +1270,9 @@ extern "C" int lbl_sum_dev(lbl_ctx* ctx, int n_in, lbl_buffer* const* in, int64_
     launch_sum(a, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_optical_dev(lbl_ctx* ctx, lbl_buffer* trans, int64_t n, int kind, lbl_buffer* out) {
+extern "C" int lbl_optical_dev(lbl_ctx* ctx, lbl_buffer* trans, int64_t n, int kind, lbl_buffer* out) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
     if (kind < 0 || kind > 2) return fail(ctx, LBL_ERR_BAD_ARG, "kind must be 0 (emissivity), 1 (absorbance) or 2 (optical depth)");
@@ -1222,9 +1283,9 @@ extern "C" int lbl_optical_dev(lbl_ctx* ctx, lbl_buffer* trans, int64_t n, int k
     launch_optical(trans->d, n, kind, out->d, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_planck_dev(lbl_ctx* ctx, double range_min, double range_max, int64_t n, double T, lbl_buffer* out) {
+extern "C" int lbl_planck_dev(lbl_ctx* ctx, double range_min, double range_max, int64_t n, double T, lbl_buffer* out) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     int rc;
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
@@ -1235,10 +1296,10 @@ extern "C" int lbl_planck_dev(lbl_ctx* ctx, double range_min, double range_max, 
     launch_planck(out->d, n, range_min, range_max, T, pa, pb, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
 extern "C" int lbl_band_integral(lbl_ctx* ctx, lbl_buffer* spectrum, int64_t n, double unit_angle, double res,
-                                 double* result) {
+                                 double* result) try {
     if (!ctx || !result) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     int rc;
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
@@ -1256,9 +1317,9 @@ extern "C" int lbl_band_integral(lbl_ctx* ctx, lbl_buffer* spectrum, int64_t n, 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *result = s * unit_angle * res;              // value * unitAngle * res (pyradClasses.py:28)
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_line_survey_dev(lbl_ctx* ctx, lbl_lines* lines, const lbl_grid* grid, lbl_buffer* out) {
+extern "C" int lbl_line_survey_dev(lbl_ctx* ctx, lbl_lines* lines, const lbl_grid* grid, lbl_buffer* out) try {
     if (!ctx || !lines || !grid) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     if (lines->ctx != ctx) return fail(ctx, LBL_ERR_STATE, "line list belongs to another context");
     int rc;
@@ -1270,7 +1331,31 @@ extern "C" int lbl_line_survey_dev(lbl_ctx* ctx, lbl_lines* lines, const lbl_gri
                        grid->n_base, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
+
+extern "C" int lbl_gather_compact_dev(lbl_ctx* ctx, lbl_buffer* gathered, int world_size, int64_t slot,
+                                      const int64_t* first, const int64_t* count, lbl_buffer* out) try {
+    if (!ctx || !first || !count) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    if (world_size < 1 || world_size > kMaxRanks) return fail(ctx, LBL_ERR_BAD_ARG, "world_size must be 1..%d", kMaxRanks);
+    if (slot < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative slot");
+    int rc;
+    if ((rc = check_buf(ctx, gathered, (int64_t)world_size * slot, "gathered", true))) return rc;
+    CompactArgs a;
+    memset(&a, 0, sizeof a);
+    long long need = 0, max_count = 0;
+    for (int r = 0; r < world_size; ++r) {
+        if (first[r] < 0 || count[r] < 0 || count[r] > slot) return fail(ctx, LBL_ERR_BAD_ARG, "rank %d: shard outside its slot", r);
+        a.first[r] = first[r]; a.count[r] = count[r];
+        need = std::max<long long>(need, first[r] + count[r]);
+        max_count = std::max<long long>(max_count, count[r]);
+    }
+    if ((rc = check_buf(ctx, out, need, "out", true))) return rc;
+    a.gathered = gathered->d; a.out = out->d; a.slot = slot; a.world = world_size;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    launch_gather_compact(a, max_count, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBL_OK;
+} LBL_GUARD_END(ctx)
 
 // hooks for lbl_comm.hip (kept out of the public header)
 namespace lbl {

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <stdexcept>
 #include <string>
 
 // private views of the objects defined in lbl_api.hip
@@ -22,6 +23,12 @@ int ctx_device(lbl_ctx* ctx);
 void* comm_prof_begin(lbl_ctx* ctx);
 void comm_prof_end(lbl_ctx* ctx, void* start);
 }
+
+// no C++ exception crosses the C boundary (see lbl_api.hip)
+#define LBL_GUARD_END(ctx_expr)                                                                                   \
+    catch (const std::bad_alloc&) { return lbl::comm_fail((ctx_expr), LBL_ERR_OOM, "host allocation failed"); }   \
+    catch (const std::exception& e) { return lbl::comm_fail((ctx_expr), LBL_ERR_STATE, e.what()); }               \
+    catch (...) { return lbl::comm_fail((ctx_expr), LBL_ERR_STATE, "unknown C++ exception"); }
 
 // Every collective of a communicator is issued on ONE stream of its own (cstream), in the same
 // order on every rank.  The context stream and cstream are ordered with events only, so the
@@ -39,7 +46,7 @@ struct lbl_comm {
 
 static_assert(sizeof(ncclUniqueId) <= LBL_UNIQUE_ID_BYTES, "unique id does not fit");
 
-extern "C" int lbl_comm_unique_id(char id[LBL_UNIQUE_ID_BYTES]) {
+extern "C" int lbl_comm_unique_id(char id[LBL_UNIQUE_ID_BYTES]) try {
     if (!id) return lbl::comm_fail(nullptr, LBL_ERR_BAD_ARG, "id is NULL");
     ncclUniqueId u;
     ncclResult_t r = ncclGetUniqueId(&u);
@@ -47,10 +54,10 @@ extern "C" int lbl_comm_unique_id(char id[LBL_UNIQUE_ID_BYTES]) {
     memset(id, 0, LBL_UNIQUE_ID_BYTES);
     memcpy(id, &u, sizeof u);
     return LBL_OK;
-}
+} LBL_GUARD_END(nullptr)
 
 extern "C" int lbl_comm_create(lbl_ctx* ctx, const char id[LBL_UNIQUE_ID_BYTES], int world_size, int rank,
-                               lbl_comm** out) {
+                               lbl_comm** out) try {
     if (!ctx || !id || !out) return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     *out = nullptr;
     if (world_size < 1 || rank < 0 || rank >= world_size) return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "bad world_size / rank");
@@ -77,9 +84,9 @@ extern "C" int lbl_comm_create(lbl_ctx* ctx, const char id[LBL_UNIQUE_ID_BYTES],
     }
     *out = cm;
     return LBL_OK;
-}
+} LBL_GUARD_END(ctx)
 
-extern "C" int lbl_comm_destroy(lbl_comm* comm) {
+extern "C" int lbl_comm_destroy(lbl_comm* comm) try {
     if (!comm) return LBL_OK;
     void* s = nullptr;
     lbl_ctx_stream(comm->ctx, &s);
@@ -91,7 +98,7 @@ extern "C" int lbl_comm_destroy(lbl_comm* comm) {
     (void)hipStreamDestroy(comm->cstream);
     delete comm;
     return LBL_OK;
-}
+} LBL_GUARD_END(comm ? comm->ctx : nullptr)
 
 static int allgather_impl(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count, lbl_buffer* recv,
                           int slot, bool fence_now) {
@@ -122,7 +129,7 @@ static int allgather_impl(lbl_comm* comm, lbl_buffer* send, int64_t send_offset,
     return LBL_OK;
 }
 
-extern "C" int lbl_comm_fence_dev(lbl_comm* comm, int slot) {
+extern "C" int lbl_comm_fence_dev(lbl_comm* comm, int slot) try {
     if (!comm) return lbl::comm_fail(nullptr, LBL_ERR_BAD_ARG, "comm is NULL");
     if (slot < -1 || slot > 3) return lbl::comm_fail(comm->ctx, LBL_ERR_BAD_ARG, "slot must be -1 (all) or 0..3");
     void* s = nullptr;
@@ -134,16 +141,16 @@ extern "C" int lbl_comm_fence_dev(lbl_comm* comm, int slot) {
         comm->pending[i] = false;
     }
     return LBL_OK;
-}
+} LBL_GUARD_END(comm ? comm->ctx : nullptr)
 
-extern "C" int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count, lbl_buffer* recv) {
+extern "C" int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count, lbl_buffer* recv) try {
     void* ev = comm ? lbl::comm_prof_begin(comm->ctx) : nullptr;
     int rc = allgather_impl(comm, send, send_offset, count, recv, 3, true);
     if (comm) lbl::comm_prof_end(comm->ctx, ev);
     return rc;
-}
+} LBL_GUARD_END(comm ? comm->ctx : nullptr)
 
 extern "C" int lbl_allgather_overlap_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count,
-                                         lbl_buffer* recv, int slot) {
+                                         lbl_buffer* recv, int slot) try {
     return allgather_impl(comm, send, send_offset, count, recv, slot, false);
-}
+} LBL_GUARD_END(comm ? comm->ctx : nullptr)

@@ -46,10 +46,10 @@ enum : int32_t {
 };
 
 // One accumulate job = one isotopologue of one layer (Isotope.createCrossSection).
-// Sweep of a single-isotopologue layer fused into the accumulate kernel's output stage
-// (lbl_layer_step_dev): the arithmetic of layer_sweep_kernel for n_iso = n_mol = 1.
+// Sweep of a layer fused into the accumulate kernel's output stage (lbl_layer_step_dev): the
+// arithmetic of layer_sweep_kernel; per-molecule volume fractions travel with the chain's jobs.
 struct FusedSweep {
-    double conc, P, T, depth;
+    double P, T, depth;
     double start, stop, step;       // xAxis = linspace(start, stop, n)
     double pa, pb, surface_T;
     const double* I_in;
@@ -77,8 +77,16 @@ struct AccumJob {
     // shard, 8 ints per span {iA, iB, iC, iD, iF1, iF2, 0, 0} (see wave_line_ranges[_far]); NULL:
     // the wave searches the centre indices itself
     const int32_t* span_tab;
-    FusedSweep fuse;       // fuse.on: sweep every point right after its cross section is final
+    // Chain (fused layer step, lbl_layer_step_dev): the head job carries chain_len >= 1 = number of
+    // consecutive jobs (line lists of ONE layer, same grid) a workgroup accumulates one after the
+    // other on its points; every link says whether it opens / closes a molecule and that molecule's
+    // volume fraction.  Ordinary jobs: chain_len = 1, fuse.on = 0.
+    int32_t chain_len;
+    int32_t chain_flags;
+    double conc;
+    FusedSweep fuse;       // head only; fuse.on: fold every point right after its cross section is final
 };
+enum : int32_t { CHAIN_MOL_FIRST = 1, CHAIN_MOL_LAST = 2 };
 
 // Balanced variant: spans (64*R consecutive grid points) of all jobs of a launch group are
 // numbered job-major; job j owns spans [span_first, span_first + n_spans).
@@ -152,7 +160,7 @@ struct ColumnArgs {
 // ---- launchers (lbl_kernels.hip) ---------------------------------------------------------
 void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStream_t s);
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
-                       const int2* worklist, int total_tiles, hipStream_t s);
+                       const int2* worklist, int total_tiles, bool chain, hipStream_t s);
 int accumulate_tile_points(int R, int LS, int variant);
 void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost);
 // balanced variant (4): span ranges -> prefix sum -> equal shares of (span, line) pairs per wave -> slab reduce
@@ -170,6 +178,9 @@ int band_partial_count(long long n);
 void launch_band_integral(const double* y, long long n, double* partial, double* result, hipStream_t s);
 struct SumArgs { const double* in[kMaxIso]; int32_t n_in; double* out; long long n; };
 void launch_sum(const SumArgs& a, hipStream_t s);
+constexpr int kMaxRanks = 64;
+struct CompactArgs { const double* gathered; double* out; long long slot; long long first[kMaxRanks]; long long count[kMaxRanks]; int32_t world; };
+void launch_gather_compact(const CompactArgs& a, long long max_count, hipStream_t s);
 void launch_optical(const double* trans, long long n, int kind, double* out, hipStream_t s);
 void launch_line_survey(const double* nu, const double* sw, int n_lines, double range_min, double resolution,
                         double* out, long long n_base, hipStream_t s);

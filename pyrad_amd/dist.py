@@ -30,6 +30,8 @@ class FileRendezvous:
     def __init__(self, rank: int, world: int, key: str | None = None, root: str | None = None, timeout: float = 120.0):
         self.rank, self.world, self.timeout = rank, world, timeout
         if key is None:
+            key = os.environ.get("PYRAD_RENDEZVOUS_KEY")
+        if key is None:
             key = "%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
                                 os.getppid())
         root = root or os.environ.get("PYRAD_RENDEZVOUS_DIR", "/tmp")
@@ -93,6 +95,98 @@ def shard_bounds(n: int, world_size: int, rank: int):
     first = min(rank * S, n)
     count = max(min((rank + 1) * S, n) - first, 0)
     return S, first, count
+
+
+class ShardPlan:
+    """Contiguous grid-range shards of one work grid: ``bounds[r] = (first, count)`` for every
+    rank, ``S`` = the per-rank slot of the all-gather (max count; every rank sends S doubles).
+    ``in_place``: all shards are S long and start at r*S (the last may be short), so the
+    all-gather can run in place on a buffer of world*S doubles; otherwise every rank sends S
+    doubles starting at its ``first`` (its buffer is S longer than the grid) into a separate
+    gathered buffer of world*S doubles whose slot r holds rank r's shard in its first count_r
+    entries (``assemble`` / lbl_gather_compact_dev bring it back to grid order)."""
+
+    def __init__(self, n: int, bounds, rank: int):
+        self.n = int(n)
+        self.bounds = [(int(f), int(c)) for f, c in bounds]
+        self.world = len(self.bounds)
+        self.rank = int(rank)
+        self.S = max(max(c for _, c in self.bounds), 1)
+        self.in_place = all(f == min(r * self.S, self.n) for r, (f, _) in enumerate(self.bounds))
+        pos = 0
+        for f, c in self.bounds:
+            if f != pos or c < 0:
+                raise ValueError("shards must tile the grid contiguously: %r" % (self.bounds,))
+            pos += c
+        if pos != self.n:
+            raise ValueError("shards cover %d of %d grid points" % (pos, self.n))
+
+    @property
+    def first(self):
+        return self.bounds[self.rank][0]
+
+    @property
+    def count(self):
+        return self.bounds[self.rank][1]
+
+    def assemble(self, gathered):
+        """padded gathered buffer (world*S) -> the n-point spectrum in grid order"""
+        g = np.asarray(gathered)
+        return np.concatenate([g[r * self.S: r * self.S + c] for r, (_, c) in enumerate(self.bounds)])[:self.n]
+
+
+def equal_plan(n: int, world_size: int, rank: int) -> ShardPlan:
+    """Equal-width shards (the in-place all-gather layout)."""
+    return ShardPlan(n, [shard_bounds(n, world_size, r)[1:] for r in range(world_size)], rank)
+
+
+SPAN = 256          # grid points a wavefront owns at R = 4 (cost model granularity)
+ALIGN = 1024        # shard boundaries are multiples of one workgroup's points (4 spans)
+
+
+def span_costs(centre_index, H: int, n: int) -> np.ndarray:
+    """Estimated K2 wave-instructions per span of 256 grid points for one line list, the host
+    model of lbl_api.hip's group_schedule: near lines (within 4 half-spans of the span, evaluated
+    point by point, ~60 % with a Gaussian pass) 5R + 29, lines reached through the far-field
+    series ~1.6, a fixed part per span.  ``centre_index`` = sorted int centre indices (cls:390)."""
+    c = np.asarray(centre_index, dtype=np.int64)
+    n_spans = -(-int(n) // SPAN)
+    lo = np.arange(n_spans, dtype=np.int64) * SPAN
+    hi = np.minimum(lo + SPAN, n) - 1
+    H = int(H)
+    reach = np.searchsorted(c, hi + H, "right") - np.searchsorted(c, lo - H, "left")
+    near_half = min(H, 4 * (SPAN // 2))
+    near = np.searchsorted(c, hi + near_half, "right") - np.searchsorted(c, lo - near_half, "left")
+    near = np.minimum(near, reach)
+    return near * (5.0 * 4 + 29.0) + (reach - near) * 1.6 + 600.0
+
+
+def balanced_plan(n: int, world_size: int, rank: int, cost_per_span: np.ndarray) -> ShardPlan:
+    """Contiguous shards with (nearly) equal summed cost; boundaries at multiples of ALIGN grid
+    points.  ``cost_per_span``: summed over every job (isotopologue x layer) that runs on the grid."""
+    n = int(n)
+    per_block = ALIGN // SPAN
+    cost = np.asarray(cost_per_span, dtype=np.float64)
+    n_blocks = -(-n // ALIGN)
+    pad = n_blocks * per_block - cost.size
+    block = np.concatenate([cost, np.zeros(max(pad, 0))])[:n_blocks * per_block].reshape(n_blocks, per_block).sum(axis=1)
+    prefix = np.concatenate([[0.0], np.cumsum(block)])
+    total = prefix[-1]
+    cuts = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        b = int(np.searchsorted(prefix, target, "left"))
+        # the boundary nearer to the target of the two that bracket it
+        if b > 0 and abs(prefix[b - 1] - target) <= abs(prefix[min(b, n_blocks)] - target):
+            b -= 1
+        cuts.append(min(max(b, cuts[-1]), n_blocks))
+    cuts.append(n_blocks)
+    bounds = []
+    for r in range(world_size):
+        f = min(cuts[r] * ALIGN, n)
+        e = min(cuts[r + 1] * ALIGN, n)
+        bounds.append((f, e - f))
+    return ShardPlan(n, bounds, rank)
 
 
 def halo_select(lines: dict, range_min, resolution, W, first, count):

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _native as nat
 from . import settings
-from .dist import shard_bounds, halo_select
+from .dist import ShardPlan, equal_plan, halo_select, shard_bounds  # noqa: F401 (re-exported)
 
 K_BOLTZMANN = 1.38064852E-23     # pyradClasses.py:16
 PI = 3.141592653589793           # pyradClasses.py:19
@@ -106,6 +106,41 @@ def shutdown():
 # ----------------------------------------------------------------------------------------
 # device-resident gas cell / column (what bench.py and the sharded path drive)
 # ----------------------------------------------------------------------------------------
+def balanced_shards(layer_cfgs, world: int, rank: int):
+    """Cost-balanced contiguous shards for a layer or a column: ``layer_cfgs`` = list of dicts with
+    P, range_min, range_max, base_resolution, dynamic_resolution and molecules (each with
+    isotopologues = [dict(lines=...)]); all layers must share one work grid.  The cost of a span is
+    the host model of K2 summed over every line list of every layer (dist.span_costs)."""
+    from .dist import span_costs, balanced_plan
+    cost, n_work = None, None
+    for c in layer_cfgs:
+        g = layer_grid(c["P"], c["range_min"], c["range_max"], c.get("base_resolution"), c.get("dynamic_resolution", True))
+        if n_work is None:
+            n_work = g["n_work"]
+        elif n_work != g["n_work"]:
+            raise ValueError("all layers of a column must share one work grid to be sharded together")
+        H = max(int(g["W"]) - 2, 0)
+        for mol in c["molecules"]:
+            for iso in mol["isotopologues"]:
+                lines = select_window(iso["lines"], g["eff_min"], g["eff_max"])
+                idx = np.sort(((np.asarray(lines["nu"], dtype=np.float64) - g["range_min"]) / g["resolution"]).astype(np.int64))
+                sc = span_costs(idx, H, n_work)
+                cost = sc if cost is None else cost + sc
+    if cost is None:
+        return equal_plan(n_work or 0, world, rank)
+    return balanced_plan(n_work, world, rank, cost)
+
+
+def as_plan(shard, n_work):
+    """None | ShardPlan | (world, rank) [equal-width shards] -> ShardPlan or None (one rank)."""
+    if shard is None:
+        return None
+    if isinstance(shard, ShardPlan):
+        return shard if shard.world > 1 else None
+    world, rank = shard
+    return equal_plan(n_work, world, rank) if world > 1 else None
+
+
 class ResidentLayer:
     """One layer (gas cell) whose line lists, cross sections and spectra live in HBM.
 
@@ -124,25 +159,36 @@ class ResidentLayer:
         g = self.g
         n = g["n_base"]
         self.n = n
-        if shard is not None and shard[0] > 1:
-            self.world, self.rank = shard
-            self.S, self.first, self.count = shard_bounds(g["n_work"], self.world, self.rank)
+        plan = as_plan(shard, g["n_work"])
+        self.plan = plan
+        if plan is not None:
+            self.world, self.rank = plan.world, plan.rank
+            self.S, self.first, self.count = plan.S, plan.first, plan.count
         else:
             self.world, self.rank = 1, 0
-            self.S, self.first, self.count = n, 0, 0          # count 0 == whole grid
-        self.padded_n = self.S * self.world if self.world > 1 else n
+            self.S, self.first, self.count = n, 0, n
+        # a sharded layer's spectra are S longer than the grid when the all-gather is out of place
+        # (every rank sends S doubles starting at its own first point); in place they are world*S long
+        if plan is None:
+            self.padded_n = n
+        elif plan.in_place:
+            self.padded_n = self.S * self.world
+        else:
+            self.padded_n = n + self.S
+        self.empty = plan is not None and self.count == 0      # more ranks than tiles: nothing to do here
         self.jobs = []
         self.iso_mol, self.conc = [], []
         self.evals = 0
         self.n_lines = 0
         self._keep = []
-        sh = None if self.world == 1 else (self.first, self.count)
+        sh = None if plan is None else (self.first, self.count)
         self.grid_native = native_grid(g, sh)
+        self.gathered = {}
         for m, mol in enumerate(molecules):
             self.conc.append(float(mol["conc"]))
             for iso in mol["isotopologues"]:
                 lines = select_window(iso["lines"], g["eff_min"], g["eff_max"])
-                if self.world > 1:
+                if plan is not None:
                     lines = self._halo_select(lines)
                 dev_lines = ctx.lines(lines)
                 out = ctx.buffer(max(self.padded_n, 1))
@@ -152,7 +198,8 @@ class ResidentLayer:
                 self.jobs.append((dev_lines, ip, self.grid_native, out))
                 self.iso_mol.append(m)
                 self.n_lines += dev_lines.n
-                self.evals += eval_count(lines["nu"], g["range_min"], g["resolution"], g["W"], g["n_work"], sh)
+                if not self.empty:
+                    self.evals += eval_count(lines["nu"], g["range_min"], g["resolution"], g["W"], g["n_work"], sh)
                 if keep_host_lines:
                     self._keep.append(lines)
         self.abs_coef = ctx.buffer(max(self.padded_n, 1))
@@ -166,48 +213,76 @@ class ResidentLayer:
         return halo_select(lines, g["range_min"], g["resolution"], g["W"], self.first, self.count)
 
     # -- enqueue ------------------------------------------------------------------------
+    def _range(self):
+        return (0, 0) if self.plan is None else (self.first, self.count)
+
     def enqueue_xsec(self):
-        self.ctx.xsec_accumulate_dev(self.jobs)
+        if not self.empty:
+            self.ctx.xsec_accumulate_dev(self.jobs)
 
     def enqueue_sweep(self, I_in=None, surface_T=0.0, want_I=True):
-        first, count = (0, 0) if self.world == 1 else (self.first, self.count)
-        if self.world > 1 and self.count == 0:
+        if self.empty:
             return
+        first, count = self._range()
         self.ctx.layer_sweep_dev([j[3] for j in self.jobs], self.iso_mol, self.conc, self.P, self.T, self.depth,
                                  self.range_min, self.range_max, self.n, I_in=I_in, surface_T=surface_T,
                                  abs_coef=self.abs_coef, trans=self.trans,
                                  I_out=self.I_out if want_I else None, first=first, count=count)
 
     def enqueue(self, surface_T=288.0, I_in=None, fused=True):
-        if fused and len(self.jobs) == 1 and not (self.world > 1 and self.count == 0):
-            # one line list: the sweep rides in the accumulate kernel's output stage
-            lines, iso, grid, xsec = self.jobs[0]
-            self.ctx.layer_step_dev(lines, iso, grid, xsec, self.conc[0], self.depth, I_in=I_in, surface_T=surface_T,
-                                    abs_coef=self.abs_coef, trans=self.trans, I_out=self.I_out)
+        """One layer step: line prep, accumulate, sweep.  ``fused`` (default): the sweep rides in the
+        accumulate kernel's output stage (lbl_layer_step_dev, any number of line lists); False: the
+        accumulate launch followed by the separate sweep launch (bit-identical, kept for A/B tests)."""
+        if self.empty:
+            return
+        if fused and self.jobs:
+            self.ctx.layer_step_dev([j[0] for j in self.jobs], [j[1] for j in self.jobs], self.grid_native,
+                                    [j[3] for j in self.jobs], self.iso_mol, self.conc, self.depth, I_in=I_in,
+                                    surface_T=surface_T, abs_coef=self.abs_coef, trans=self.trans, I_out=self.I_out)
             return
         self.enqueue_xsec()
         self.enqueue_sweep(I_in=I_in, surface_T=surface_T)
 
     def enqueue_allgather(self, comm: nat.Comm, buffers=None, overlap_slot=None):
-        """The single RCCL all-gather of the path, in place on the padded buffers.  With
-        ``overlap_slot`` the context stream does not wait for it: call
+        """The single RCCL all-gather of the path.  Equal shards: in place on the padded buffers.
+        Cost-balanced (unequal) shards: every rank sends S doubles from its own first point into a
+        gathered buffer of world*S doubles (slot r = rank r's shard; ``results`` puts it back in
+        grid order).  With ``overlap_slot`` the context stream does not wait for it: call
         ``comm.fence_dev(overlap_slot)`` before this layer's buffers are touched again."""
         for b in (buffers if buffers is not None else (self.abs_coef,)):
-            comm.allgather_dev(b, self.rank * self.S, self.S, b, overlap_slot=overlap_slot)
+            if self.plan is None or self.plan.in_place:
+                comm.allgather_dev(b, self.rank * self.S, self.S, b, overlap_slot=overlap_slot)
+            else:
+                comm.allgather_dev(b, self.first, self.S, self._gathered(b), overlap_slot=overlap_slot)
+
+    def _gathered(self, b):
+        key = id(b)
+        if key not in self.gathered:
+            self.gathered[key] = self.ctx.buffer(self.S * self.world).fill(0.0)
+        return self.gathered[key]
 
     # -- results ------------------------------------------------------------------------
     def xsec_host(self, i=0):
         return self.jobs[i][3].download(self.n)
 
+    def spectrum_host(self, b):
+        """Host copy of a spectrum buffer in grid order (after the all-gather when sharded)."""
+        if self.plan is not None and not self.plan.in_place and id(b) in self.gathered:
+            return self.plan.assemble(self.gathered[id(b)].download(self.S * self.world))
+        return b.download(self.n)
+
     def results(self):
-        return dict(abs_coef=self.abs_coef.download(self.n), transmittance=self.trans.download(self.n),
-                    transmission=self.I_out.download(self.n))
+        return dict(abs_coef=self.spectrum_host(self.abs_coef), transmittance=self.spectrum_host(self.trans),
+                    transmission=self.spectrum_host(self.I_out))
 
     def free(self):
         for j in self.jobs:
             j[0].free(); j[3].free()
         for b in (self.abs_coef, self.trans, self.I_out):
             b.free()
+        for b in self.gathered.values():
+            b.free()
+        self.gathered = {}
         self.jobs = []
 
 
@@ -231,9 +306,12 @@ class ResidentColumn:
             if (L.range_min, L.range_max, L.n) != (first.range_min, first.range_max, first.n):
                 raise ValueError("all layers of a column must share one wavenumber range and base grid")
         self.n = first.n
+        self.plan = first.plan
         self.world, self.rank, self.S = first.world, first.rank, first.S
         self.first, self.count = first.first, first.count
+        self.empty = first.empty
         self.I_toa = ctx.buffer(max(first.padded_n, 1)).fill(0.0)
+        self.I_gathered = None
         self.jobs = [j for L in self.layers for j in L.jobs]
         self.evals = sum(L.evals for L in self.layers)
         self.n_lines = sum(L.n_lines for L in self.layers)
@@ -242,11 +320,11 @@ class ResidentColumn:
         """One column step.  ``fused``: a single pass over all cross sections (lbl_column_step_dev)
         instead of one sweep per layer plus the fold; ``layer_arrays`` False skips writing the
         per-layer absorption coefficient / transmittance arrays (only the outgoing spectrum)."""
+        if self.empty:
+            return
         self.ctx.xsec_accumulate_dev(self.jobs)
-        first, count = (0, 0) if self.world == 1 else (self.first, self.count)
+        first, count = (0, 0) if self.plan is None else (self.first, self.count)
         if fused:
-            if self.world > 1 and self.count == 0:
-                return
             desc = [dict(xsec=[j[3] for j in L.jobs], iso_mol=L.iso_mol, conc=L.conc, P=L.P, T=L.T, depth=L.depth,
                          trans=L.trans if layer_arrays else None, abs_coef=L.abs_coef if layer_arrays else None)
                     for L in self.layers]
@@ -255,20 +333,29 @@ class ResidentColumn:
             return
         for L in self.layers:
             L.enqueue_sweep(want_I=False)
-        if self.world > 1 and self.count == 0:
-            return
         self.ctx.column_sweep_dev([L.trans for L in self.layers], [L.T for L in self.layers],
                                   self.layers[0].range_min, self.layers[0].range_max, self.n, self.I_toa,
                                   surface_T=self.surface_T, first=first, count=count)
 
     def enqueue_allgather(self, comm: nat.Comm, overlap_slot=None):
-        comm.allgather_dev(self.I_toa, self.rank * self.S, self.S, self.I_toa, overlap_slot=overlap_slot)
+        if self.plan is None or self.plan.in_place:
+            comm.allgather_dev(self.I_toa, self.rank * self.S, self.S, self.I_toa, overlap_slot=overlap_slot)
+            return
+        if self.I_gathered is None:
+            self.I_gathered = self.ctx.buffer(self.S * self.world).fill(0.0)
+        comm.allgather_dev(self.I_toa, self.first, self.S, self.I_gathered, overlap_slot=overlap_slot)
 
     def results(self):
-        return dict(toa=self.I_toa.download(self.n),
-                    transmittance=[L.trans.download(self.n) for L in self.layers])
+        if self.plan is not None and not self.plan.in_place and self.I_gathered is not None:
+            toa = self.plan.assemble(self.I_gathered.download(self.S * self.world))
+        else:
+            toa = self.I_toa.download(self.n)
+        return dict(toa=toa, transmittance=[L.trans.download(self.n) for L in self.layers])
 
     def free(self):
         for L in self.layers:
             L.free()
         self.I_toa.free()
+        if self.I_gathered is not None:
+            self.I_gathered.free()
+            self.I_gathered = None

@@ -128,7 +128,7 @@ def getTransmittance(obj):
 def getOpticalDepth(obj):
     if not obj.progressCrossSection:
         obj.createCrossSection()
-    return _optical(obj.transmittance, 2)          # -log(transmittance), cls:76
+    return obj.opticalDepth                         # -log(transmittance), cls:76
 
 
 def getAbsorbance(obj):
@@ -257,96 +257,191 @@ def concentration_from_kwargs(**abundance):
 
 
 # ----------------------------------------------------------------------------------------
-# device helpers
+# device residency: cross sections and swept spectra stay in HBM between getters
 # ----------------------------------------------------------------------------------------
-def _optical(trans, kind):
-    """emissivity (0) / absorbance (1) / optical depth (2) of a host transmittance array, on the device."""
-    trans = np.ascontiguousarray(trans, dtype=np.float64)
-    ctx = _ctx()
-    a = ctx.buffer(max(trans.size, 1)); b = ctx.buffer(max(trans.size, 1))
-    try:
-        a.upload(trans)
-        ctx.optical_dev(a, trans.size, kind, b)
-        return b.download(trans.size)
-    finally:
-        a.free(); b.free()
+class _LazyArray:
+    """Attribute whose host copy is fetched from the device on first read.  The reference keeps
+    plain NumPy arrays in ``crossSection`` / ``lineSurvey``; here the device owns the data and a
+    host array is made only when somebody looks at it (a getter chain that ends in absCoef never
+    does).  Assigning a host array drops the loader."""
+
+    def __init__(self, name):
+        self.host, self.loader = "_%s_host" % name, "_%s_loader" % name
+
+    def __get__(self, obj, owner=None):
+        if obj is None:
+            return self
+        load = obj.__dict__.get(self.loader)
+        if load is not None:
+            obj.__dict__[self.host] = load()
+            obj.__dict__[self.loader] = None
+        return obj.__dict__.get(self.host)
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.host] = value
+        obj.__dict__[self.loader] = None
+        hook = getattr(obj, "_host_array_assigned", None)
+        if hook is not None:
+            hook(self.host)
+
+    def defer(self, obj, loader):
+        obj.__dict__[self.host] = None
+        obj.__dict__[self.loader] = loader
+
+
+def _free_buffers(bufs):
+    for b in bufs.values():
+        try:
+            if b.ctx.h:
+                b.free()
+        except Exception:
+            pass
+    bufs.clear()
+
+
+class _SweepState:
+    """Device buffers of one object's property chain (absorption coefficient, transmittance and
+    scratch) and the key of what they were computed from; a getter re-sweeps only when the key
+    (member cross-section versions, concentrations, P, T, depth, grid) has changed."""
+
+    def __init__(self, owner):
+        self.bufs = {}
+        self.n = -1
+        self.key = None
+        import weakref
+        weakref.finalize(owner, _free_buffers, self.bufs)
+
+    def reserve(self, ctx, n):
+        if self.n != n or any(b.h is None or b.ctx is not ctx for b in self.bufs.values()):
+            _free_buffers(self.bufs)
+            self.n, self.key = n, None
+        return self
+
+    def buf(self, ctx, name):
+        b = self.bufs.get(name)
+        if b is None:
+            b = self.bufs[name] = ctx.buffer(max(self.n, 1))
+        return b
+
+
+def _iso_params(iso):
+    layer = iso.layer
+    q_T = iso.q[layer.T]                       # KeyError for a non-integer temperature, as cls:389
+    return nat.IsoParams(float(layer.T), float(layer.P), float(iso.molecule.concentration), float(iso.molmass),
+                         float(q_T), float(iso.q296))
+
+
+def _check_window(g):
+    if g["W"] < 1:
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0")     # rightCurve[0], cls:393
+
+
+def _mark_computed(ctx, isotopes, n):
+    for iso in isotopes:
+        iso._xs_version += 1
+        iso._dev_xsec_valid = True
+        Isotope.crossSection.defer(iso, (lambda b=iso._dev_xsec, n=n: b.download(n)))
+        iso._regime_counts = None
+        iso.progressCrossSection = True
+    if VERBOSE:
+        for iso in isotopes:
+            _say('\ngaussian only: %s\t lorentz only: %s\t voigt: %s\n' % iso.regimeCounts, end='\r')
 
 
 def _compute_cross_sections(isotopes):
     """Batched Isotope.createCrossSection (cls:361-407) for every dirty isotopologue in the
-    list: one prep launch + one accumulate launch for all of them."""
+    list: one prep launch + one accumulate launch for all of them.  The cross sections stay on
+    the device; ``iso.crossSection`` downloads on first read."""
     dirty = [i for i in isotopes if not i.progressCrossSection and not i.exotic]
     if not dirty:
         return
     ctx = _ctx()
     jobs = []
     for iso in dirty:
-        layer = iso.layer
-        g = layer._grid()
-        if g["W"] < 1:
-            raise IndexError("index 0 is out of bounds for axis 0 with size 0")     # rightCurve[0], cls:393
-        q_T = iso.q[layer.T]                       # KeyError for a non-integer temperature, as cls:389
-        ip = nat.IsoParams(float(layer.T), float(layer.P), float(iso.molecule.concentration), float(iso.molmass),
-                           float(q_T), float(iso.q296))
-        jobs.append((iso._device_lines(ctx), ip, _engine.native_grid(g), iso._device_xsec(ctx, g["n_base"])))
+        g = iso.layer._grid()
+        _check_window(g)
+        jobs.append((iso._device_lines(ctx), _iso_params(iso), _engine.native_grid(g), iso._device_xsec(ctx, g["n_base"])))
     ctx.xsec_accumulate_dev(jobs)
-    counts = ctx.last_regime_counts(len(jobs))
-    for iso, job, cnt in zip(dirty, jobs, counts):
-        iso.crossSection = job[3].download(iso.layer._grid()["n_base"])
-        iso.regimeCounts = tuple(int(x) for x in cnt)
-        _say('\ngaussian only: %s\t lorentz only: %s\t voigt: %s\n' % iso.regimeCounts, end='\r')
-        iso.progressCrossSection = True
-
-
-def _sweep(layer, isotopes_by_molecule, concentrations, I_in=None, want=("abs_coef",)):
-    """Fused sweep (K4) over the given isotopologues; returns the requested host arrays."""
-    ctx = _ctx()
-    g = layer._grid()
-    n = g["n_base"]
-    xs, iso_mol = [], []
-    for m, isos in enumerate(isotopes_by_molecule):
-        for iso in isos:
-            xs.append(iso._device_xsec_current(ctx, n))
-            iso_mol.append(m)
-    bufs = {name: ctx.buffer(max(n, 1)) for name in want}
-    tmp_in = None
-    try:
-        if I_in is not None:
-            I_in = np.ascontiguousarray(I_in, dtype=np.float64)
-            if I_in.shape != (n,):
-                raise ValueError("operands could not be broadcast together with shapes (%d,) %s" % (n, I_in.shape))
-            tmp_in = ctx.buffer(max(n, 1)).upload(I_in)
-        ctx.layer_sweep_dev(xs, iso_mol, concentrations, layer.P, layer.T, layer.depth, layer.rangeMin,
-                            layer.rangeMax, n, I_in=tmp_in, surface_T=0.0,
-                            abs_coef=bufs.get("abs_coef"), trans=bufs.get("trans"), I_out=bufs.get("I_out"))
-        return {name: b.download(n) for name, b in bufs.items()}
-    finally:
-        for b in bufs.values():
-            b.free()
-        if tmp_in is not None:
-            tmp_in.free()
+    _mark_computed(ctx, dirty, dirty[0].layer._grid()["n_base"])
 
 
 class _OpticalMixin:
     """The property chain shared by Isotope, Molecule and Layer (cls:322-340, 581-606, 707-732,
-    784-787).  ``_sweep_members`` says which isotopologues and concentrations take part."""
+    784-787).  ``_sweep_members`` says which isotopologues and concentrations take part; the
+    swept arrays live in a per-object _SweepState on the device and a getter downloads only the
+    array it returns."""
 
     def _sweep_members(self):
         raise NotImplementedError
 
+    def _ensure_swept(self):
+        """(state, n) with absorption coefficient and transmittance of the CURRENT members resident.
+        When every line-by-line member is dirty (first use, or after a temperature / pressure / range
+        change) the whole layer step runs as one fused launch sequence (lbl_layer_step_dev: line
+        prep, accumulate, sweep in the accumulate kernel's output stage); otherwise only the dirty
+        isotopologues are accumulated and the sweep kernel runs if anything it reads has changed."""
+        ctx = _ctx()
+        layer = self._layer()
+        g = layer._grid()
+        n = g["n_base"]
+        members, conc = self._sweep_members()
+        flat = [iso for isos in members for iso in isos]
+        st = self.__dict__.get("_sweep_state")
+        if st is None:
+            st = self.__dict__["_sweep_state"] = _SweepState(self)
+        st.reserve(ctx, n)
+        lbl = [i for i in flat if not i.exotic]
+        dirty = [i for i in lbl if not i.progressCrossSection]
+        fusable = (dirty and len(dirty) == len(flat) and g["resolution"] == g["base_resolution"]
+                   and g["n_work"] == n and len(flat) <= 48)
+        if fusable:
+            _check_window(g)
+            iso_mol = [m for m, isos in enumerate(members) for _ in isos]
+            ctx.layer_step_dev([i._device_lines(ctx) for i in flat], [_iso_params(i) for i in flat],
+                               _engine.native_grid(g), [i._device_xsec(ctx, n) for i in flat], iso_mol, conc,
+                               layer.depth, abs_coef=st.buf(ctx, "abs_coef"), trans=st.buf(ctx, "trans"))
+            _mark_computed(ctx, flat, n)
+            st.key = self._sweep_key(flat, conc, layer, g)
+        else:
+            _compute_cross_sections(dirty)
+            key = self._sweep_key(flat, conc, layer, g)
+            if st.key != key:
+                xs = [iso._device_xsec_current(ctx, n) for iso in flat]
+                iso_mol = [m for m, isos in enumerate(members) for _ in isos]
+                ctx.layer_sweep_dev(xs, iso_mol, conc, layer.P, layer.T, layer.depth, layer.rangeMin, layer.rangeMax, n,
+                                    abs_coef=st.buf(ctx, "abs_coef"), trans=st.buf(ctx, "trans"))
+                st.key = self._sweep_key(flat, conc, layer, g)
+        self._members_ready()
+        return st, n
+
+    @staticmethod
+    def _sweep_key(flat, conc, layer, g):
+        return (tuple((id(i), i._xs_version) for i in flat), tuple(float(c) for c in conc), layer.P, layer.T, layer.depth,
+                layer.rangeMin, layer.rangeMax, g["n_base"])
+
+    def _members_ready(self):
+        """hook: a Layer / Molecule marks the molecule sums it stands for as computed (cls:566-571)"""
+
     @property
     def absCoef(self):
-        isos, conc = self._sweep_members()
-        return _sweep(self._layer(), isos, conc, want=("abs_coef",))["abs_coef"]
+        st, n = self._ensure_swept()
+        return st.bufs["abs_coef"].download(n)
 
     @property
     def transmittance(self):
-        isos, conc = self._sweep_members()
-        return _sweep(self._layer(), isos, conc, want=("trans",))["trans"]
+        st, n = self._ensure_swept()
+        return st.bufs["trans"].download(n)
+
+    def _optical(self, kind):
+        st, n = self._ensure_swept()
+        ctx = _ctx()
+        out = st.buf(ctx, "tmp")
+        ctx.optical_dev(st.bufs["trans"], n, kind, out)
+        return out.download(n)
 
     @property
     def emissivity(self):
-        return _optical(self.transmittance, 0)
+        return self._optical(0)                 # 1 - transmittance (cls:330-332)
 
     @property
     def emittance(self):
@@ -354,15 +449,28 @@ class _OpticalMixin:
 
     @property
     def absorbance(self):
-        return _optical(self.transmittance, 1)
+        return self._optical(1)                 # log10(1 / transmittance) (cls:338-340)
+
+    @property
+    def opticalDepth(self):
+        return self._optical(2)                 # -log(transmittance) (cls:73-76)
 
     def planck(self, temperature):
         return self._layer().planck(temperature)
 
     def transmission(self, surfaceSpectrum):
-        """transmittance * surfaceSpectrum + emittance * planck(T)  (cls:784-787)."""
-        isos, conc = self._sweep_members()
-        return _sweep(self._layer(), isos, conc, I_in=surfaceSpectrum, want=("I_out",))["I_out"]
+        """transmittance * surfaceSpectrum + emittance * planck(T)  (cls:784-787): the resident
+        transmittance folded with the uploaded spectrum by the column kernel (one layer)."""
+        st, n = self._ensure_swept()
+        ctx = _ctx()
+        layer = self._layer()
+        I_in = np.ascontiguousarray(surfaceSpectrum, dtype=np.float64)
+        if I_in.shape != (n,):
+            raise ValueError("operands could not be broadcast together with shapes (%d,) %s" % (n, I_in.shape))
+        src = st.buf(ctx, "I_in").upload(I_in)
+        out = st.buf(ctx, "tmp")
+        ctx.column_sweep_dev([st.bufs["trans"]], [layer.T], layer.rangeMin, layer.rangeMax, n, out, I_in=src)
+        return out.download(n)
 
 
 # ----------------------------------------------------------------------------------------
@@ -403,18 +511,21 @@ class Line:
 # ----------------------------------------------------------------------------------------
 class Isotope(_OpticalMixin, list):
     _FIELDS = ("nu", "sw", "a", "gamma_air", "gamma_self", "elower", "n_air", "delta_air")
+    crossSection = _LazyArray("crossSection")      # device-resident after createCrossSection; downloaded on read
+    lineSurvey = _LazyArray("lineSurvey")          # computed (K7) and downloaded on first read
 
     def __init__(self, number, molecule):
         super().__init__()
         self.molecule = molecule
         self.layer = self.molecule.layer
-        self.crossSection = np.copy(self.layer.crossSection)
-        self.exotic = molecule.exotic
-        self._lines = {f: np.zeros(0) for f in self._FIELDS}
         self._dev_lines = None
         self._dev_xsec = None
         self._dev_xsec_valid = False
-        self.regimeCounts = (0, 0, 0)
+        self._xs_version = 0
+        self._regime_counts = (0, 0, 0)
+        self.crossSection = np.copy(self.layer.crossSection)
+        self.exotic = molecule.exotic
+        self._lines = {f: np.zeros(0) for f in self._FIELDS}
         if number not in EXOTIC_IDS:
             params = _data.get_source().readMolParams(number)
             self.globalIsoNumber = params[0]
@@ -489,6 +600,23 @@ class Isotope(_OpticalMixin, list):
             self._dev_lines = None
         self.progressCrossSection = False
 
+    def _host_array_assigned(self, which):
+        if which == "_crossSection_host":           # somebody installed a host array: the device copy is stale
+            self._dev_xsec_valid = False
+            self._xs_version += 1
+
+    @property
+    def regimeCounts(self):
+        """(gaussian, lorentz, voigt) line counts as printed at cls:406, from the device's regime
+        select (lbl_line_quantities) - fetched when asked for, not on every createCrossSection."""
+        if self._regime_counts is None:
+            ctx = _ctx()
+            g = self.layer._grid()
+            q = ctx.line_quantities(self._device_lines(ctx), _iso_params(self), _engine.native_grid(dict(g, W=max(g["W"], 1))))
+            c = np.bincount(q["regime"], minlength=3)
+            self._regime_counts = (int(c[0]), int(c[1]), int(c[2]))
+        return self._regime_counts
+
     # -- device residency ----------------------------------------------------------------
     def _device_lines(self, ctx):
         if self._dev_lines is None or self._dev_lines.h is None:
@@ -496,24 +624,26 @@ class Isotope(_OpticalMixin, list):
         return self._dev_lines
 
     def _device_xsec(self, ctx, n):
-        if self._dev_xsec is None or self._dev_xsec.h is None or self._dev_xsec.n < n:
-            if self._dev_xsec is not None and self._dev_xsec.h is not None:
+        if self._dev_xsec is None or self._dev_xsec.h is None or self._dev_xsec.n < n or self._dev_xsec.ctx is not ctx:
+            if self._dev_xsec is not None and self._dev_xsec.h is not None and self._dev_xsec.ctx.h:
                 self._dev_xsec.free()
             self._dev_xsec = ctx.buffer(max(n, 1))
-        self._dev_xsec_valid = True
+            import weakref
+            weakref.finalize(self, _free_buffers, {"xsec": self._dev_xsec})
         return self._dev_xsec
 
     def _device_xsec_current(self, ctx, n):
-        """Device copy of self.crossSection (re-uploaded if the host array was replaced)."""
+        """Device copy of self.crossSection (uploaded if a host array was installed since)."""
+        if (self._dev_xsec_valid and self._dev_xsec is not None and self._dev_xsec.h is not None
+                and self._dev_xsec.ctx is ctx):
+            return self._dev_xsec
         xs = np.ascontiguousarray(self.crossSection, dtype=np.float64)
         if xs.shape != (n,):
             raise ValueError("cross section has %s points, layer grid has %d" % (xs.shape, n))
-        if not (self.progressCrossSection and self._dev_xsec_valid and self._dev_xsec is not None
-                and self._dev_xsec.h is not None):
-            buf = self._device_xsec(ctx, n)
-            buf.upload(xs)
-            self._dev_xsec_valid = self.progressCrossSection
-        return self._dev_xsec
+        buf = self._device_xsec(ctx, n)
+        buf.upload(xs)
+        self._dev_xsec_valid = True
+        return buf
 
     # -- reference surface ---------------------------------------------------------------
     def _layer(self):
@@ -542,7 +672,8 @@ class Isotope(_OpticalMixin, list):
         lines = src.gatherData(self.globalIsoNumber, self.layer.effectiveRangeMin, self.layer.effectiveRangeMax)
         self.q = src.getQData(self.globalIsoNumber)
         self.set_lines(lines)
-        self.createLineSurvey()
+        _ctx()                                            # the reference computes the survey here (cls:359): fail now without a GPU
+        Isotope.lineSurvey.defer(self, self.createLineSurvey)      # ... the histogram itself on first read
 
     def createCrossSection(self):
         """cls:361-407 on the device: K1 line prep, K2 owner-computes accumulate, K3 regrid."""
@@ -558,10 +689,11 @@ class Isotope(_OpticalMixin, list):
         try:
             grid = _engine.native_grid(dict(g, n_base=n, W=max(g["W"], 1)))
             ctx.line_survey_dev(self._device_lines(ctx), grid, out)
-            self.lineSurvey = out.download(n)
+            survey = out.download(n)
         finally:
             out.free()
-        return self.lineSurvey
+        self.lineSurvey = survey
+        return survey
 
     def linelist(self):
         return list(self)
@@ -571,6 +703,8 @@ class Isotope(_OpticalMixin, list):
 # Molecule (cls:445-642)
 # ----------------------------------------------------------------------------------------
 class Molecule(_OpticalMixin, list):
+    crossSection = _LazyArray("crossSection")      # sum of the isotopologue cross sections, summed and downloaded on read
+
     def __init__(self, shortNameOrMolNum, layer, isotopeDepth=1, **abundance):
         super().__init__()
         self.layer = layer
@@ -702,15 +836,30 @@ class Molecule(_OpticalMixin, list):
             isotope.getData()
 
     def createCrossSection(self):
-        """cls:566-571: sum of the isotopologue cross sections (no abundance weighting)."""
+        """cls:566-571: sum of the isotopologue cross sections (no abundance weighting).  The
+        isotopologues are accumulated (with this molecule's sweep folded in when all of them are
+        due); the sum itself is formed on the device when ``crossSection`` is read."""
         if self.exotic:
             return
-        _compute_cross_sections(list(self))
-        ctx = _ctx()
+        self._ensure_swept()
+
+    def _mark_sum_ready(self):
+        if self.exotic or self.progressCrossSection:
+            return
         n = int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION)
-        bufs = [iso._device_xsec_current(ctx, n) for iso in self]
-        self.crossSection = _sum_on_device(ctx, bufs, n)
+        isos = list(self)
+        versions = [i._xs_version for i in isos]
+
+        def load():
+            ctx = _ctx()
+            if [i._xs_version for i in isos] != versions:
+                raise RuntimeError("isotopologue cross sections changed before the molecule sum was read")
+            return _sum_on_device(ctx, [i._device_xsec_current(ctx, n) for i in isos], n)
+        Molecule.crossSection.defer(self, load)
         self.progressCrossSection = True
+
+    def _members_ready(self):
+        self._mark_sum_ready()
 
     @property
     def lineSurvey(self):
@@ -757,6 +906,7 @@ def _sum_on_device(ctx, bufs, n):
 # ----------------------------------------------------------------------------------------
 class Layer(_OpticalMixin, list):
     hasAtmosphere = False
+    crossSection = _LazyArray("crossSection")      # sum of the molecule cross sections, formed on read
 
     def __init__(self, depth, T, P, rangeMin, rangeMax, atmosphere=None, name='', dynamicResolution=True):
         super().__init__()
@@ -812,29 +962,35 @@ class Layer(_OpticalMixin, list):
         return self
 
     def _sweep_members(self):
-        # Layer.absCoef (cls:707-712) recomputes dirty molecules through getAbsCoef
-        _compute_cross_sections([iso for m in self for iso in m])
-        for m in self:
-            if not m.progressCrossSection:
-                m.createCrossSection()
+        # Layer.absCoef (cls:707-712) walks the molecules through getAbsCoef; dirty ones are recomputed
         return [m._members() for m in self], [m.concentration for m in self]
 
+    def _members_ready(self):
+        for m in self:
+            m._mark_sum_ready()
+
     def createCrossSection(self):
-        """cls:684-689: sum of the molecule cross sections."""
-        _compute_cross_sections([iso for m in self for iso in m])
-        ctx = _ctx()
+        """cls:684-689: sum of the molecule cross sections.  One fused layer step brings every dirty
+        line list up to date (and leaves absorption coefficient and transmittance resident for the
+        getters that follow); the sum is formed on the device when ``crossSection`` is read."""
+        self._ensure_swept()
         n = int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION)
-        tmp = []
-        try:
-            for molecule in self:
-                xs = np.ascontiguousarray(getCrossSection(molecule), dtype=np.float64)
-                if xs.shape != (n,):        # e.g. a partially overlapping xsc table (mergeArray, cls:216-219)
-                    raise ValueError("operands could not be broadcast together with shapes (%d,) %s" % (n, xs.shape))
-                tmp.append(ctx.buffer(max(n, 1)).upload(xs))
-            self.crossSection = _sum_on_device(ctx, tmp, n)
-        finally:
-            for b in tmp:
-                b.free()
+        molecules = list(self)
+
+        def load():
+            ctx = _ctx()
+            tmp = []
+            try:
+                for molecule in molecules:
+                    xs = np.ascontiguousarray(getCrossSection(molecule), dtype=np.float64)
+                    if xs.shape != (n,):        # e.g. a partially overlapping xsc table (mergeArray, cls:216-219)
+                        raise ValueError("operands could not be broadcast together with shapes (%d,) %s" % (n, xs.shape))
+                    tmp.append(ctx.buffer(max(n, 1)).upload(xs))
+                return _sum_on_device(ctx, tmp, n)
+            finally:
+                for b in tmp:
+                    b.free()
+        Layer.crossSection.defer(self, load)
         self.progressCrossSection = True
 
     @property
@@ -954,9 +1110,7 @@ class Atmosphere(list):
         n = int((first.rangeMax - first.rangeMin) / utils.BASE_RESOLUTION)
         _compute_cross_sections([iso for L in layers for m in L for iso in m])
         for L in layers:
-            for m in L:
-                if not m.progressCrossSection:
-                    m.createCrossSection()
+            L._members_ready()
         # one pass over every layer's device-resident cross sections (lbl_column_step_dev)
         desc = []
         for L in layers:

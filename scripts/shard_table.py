@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""What G-way sharding of a workload costs, measured on ONE GPU: every shard
+(G, r) of C3 / C5 is built and stepped alone, exactly what rank r of G computes per step (no
+communicator), with equal-width and with cost-balanced bounds.
+
+    python scripts/shard_table.py [C3] [C5] > gpurun_out/shard_table.json
+
+Per (workload, G, mode): t(r) for every r, max_r t(r) (the step of the slowest rank), sum_r t(r),
+t_full (G = 1), predicted speed-up t_full / max_r t(r) and the fixed cost per step
+(sum_r t(r) - t_full) / (G - 1)."""
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+from pyrad_amd import _native as nat, engine  # noqa: E402
+
+
+def time_steps(ctx, obj, is_column, steps, budget_s=1.5):
+    step = (lambda: obj.enqueue(layer_arrays=False)) if is_column else (lambda: obj.enqueue(surface_T=288.0))
+    step(); ctx.sync()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.2:                 # clocks
+        step()
+    ctx.sync()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ctx.sync()
+        best = min(best, (time.perf_counter() - t0) / steps)
+    return best * 1e3
+
+
+def main():
+    workloads = [w for w in sys.argv[1:] if w in ("C2", "C3", "C5")] or ["C3", "C5"]
+    ctx = nat.Context(0)
+    out = {"device": ctx.device_info()["name"], "unit": "ms per step (K1 + K2 with the sweep folded in; C5: + column step)", "rows": []}
+    for wl in workloads:
+        cfg, desc = bench.build_workload(wl, 1)
+        is_column = wl == "C5"
+        if is_column:
+            layer_cfgs = [dict(c, molecules=bench.molecules_of(c)) for c in cfg["layers"]]
+        else:
+            layer_cfgs = [dict(cfg, molecules=bench.molecules_of(cfg))]
+        steps = 20 if is_column else 100
+
+        def build(shard):
+            if is_column:
+                return engine.ResidentColumn(ctx, layer_cfgs, cfg["surface_T"], shard=shard)
+            c = layer_cfgs[0]
+            return engine.ResidentLayer(ctx, c["depth"], c["T"], c["P"], c["range_min"], c["range_max"], c["molecules"],
+                                        c["base_resolution"], c.get("dynamic_resolution", True), shard=shard)
+        full = build(None)
+        t_full = time_steps(ctx, full, is_column, steps)
+        evals_full = full.evals
+        full.free()
+        print("%s full: %.4f ms" % (wl, t_full), file=sys.stderr)
+        for G in (2, 4, 8):
+            for mode in ("equal", "balanced"):
+                ts, ev, bounds = [], 0, None
+                for r in range(G):
+                    plan = engine.balanced_shards(layer_cfgs, G, r) if mode == "balanced" else engine.as_plan((G, r), full.n)
+                    bounds = plan.bounds
+                    part = build(plan)
+                    ts.append(time_steps(ctx, part, is_column, steps))
+                    ev += part.evals
+                    part.free()
+                row = dict(workload=wl, G=G, bounds=mode, t_full_ms=t_full, t_r_ms=ts, max_ms=max(ts), sum_ms=sum(ts),
+                           predicted_speedup=t_full / max(ts), fixed_ms_per_step=(sum(ts) - t_full) / (G - 1),
+                           imbalance=max(ts) / (sum(ts) / G), evals_match=bool(ev == evals_full),
+                           shard_points=[c for _, c in bounds])
+                out["rows"].append(row)
+                print("%s G=%d %-8s max %.4f sum %.4f speed-up %.2f imbalance %.3f fixed %.4f" % (
+                    wl, G, mode, row["max_ms"], row["sum_ms"], row["predicted_speedup"], row["imbalance"],
+                    row["fixed_ms_per_step"]), file=sys.stderr)
+    ctx.close()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""CPU: `python bench.py --gpus N` without a launcher starts its own N ranks (before anything
+touches the GPU) with the torchrun environment contract, relays rank 0's single line and
+propagates a failing rank's status; shard plans (equal and cost-balanced) tile the grid."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+
+def test_spawn_plan_env_and_argv_for_two_ranks():
+    argv = ["--gpus", "2", "--steps", "7", "--warmup", "2"]
+    plan = bench.spawn_plan(2, argv, {"PATH": "/usr/bin", "WORLD_SIZE_UNRELATED": "x"}, port=29517)
+    assert len(plan) == 2
+    keys = set()
+    for r, (cmd, env) in enumerate(plan):
+        assert cmd[0] == sys.executable and cmd[1] == os.path.join(REPO, "bench.py") and cmd[2:] == argv
+        assert env["RANK"] == str(r) and env["LOCAL_RANK"] == str(r) and env["WORLD_SIZE"] == "2"
+        assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29517"
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"          # dmabuf IPC: RCCL needs it on this driver
+        assert env["PATH"] == "/usr/bin"
+        keys.add(env["PYRAD_RENDEZVOUS_KEY"])
+    assert len(keys) == 1                                        # one rendezvous for the whole launch
+    # an explicit setting of the caller is kept
+    plan = bench.spawn_plan(2, argv, {"HSA_ENABLE_IPC_MODE_LEGACY": "1"}, port=1)
+    assert plan[0][1]["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+
+
+def test_the_parent_spawns_before_importing_the_gpu_library():
+    """The self-launch branch sits before the first import of pyrad_amd in main()."""
+    src = open(os.path.join(REPO, "bench.py")).read()
+    body = src[src.index("def main():"):]
+    assert body.index("run_ranks(spawn_plan(") < body.index("from pyrad_amd import _native")
+    head = src[:src.index("def main():")]
+    assert "import pyrad_amd" not in head and "from pyrad_amd" not in head.replace("    from pyrad_amd", "")
+
+
+def test_run_ranks_relays_rank0_and_propagates_failure(capfd):
+    ok = [([sys.executable, "-c", "import os; print('{\"rank\": %s}' % os.environ['RANK'])"], dict(os.environ, RANK="0")),
+          ([sys.executable, "-c", "print('noise from rank 1')"], dict(os.environ, RANK="1"))]
+    assert bench.run_ranks(ok, timeout_s=60) == 0
+    out, err = capfd.readouterr()
+    assert out.strip() == '{"rank": 0}'                           # exactly rank 0's line on stdout
+    assert "noise from rank 1" in err                             # other ranks' stdout goes to stderr
+    bad = [([sys.executable, "-c", "import time; time.sleep(30)"], dict(os.environ)),
+           ([sys.executable, "-c", "raise SystemExit(3)"], dict(os.environ))]
+    assert bench.run_ranks(bad, timeout_s=60) == 3                # and the sleeping rank was ended, not waited for
+
+
+def test_gpus_mismatch_and_missing_device_are_errors(monkeypatch):
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=4" in str(e.value)
+
+
+def test_shard_plans_tile_the_grid():
+    from pyrad_amd import dist
+    rng = np.random.default_rng(5)
+    # banded line density: most lines in one eighth of the grid
+    c = np.sort(np.concatenate([rng.integers(0, 2_400_000, 40_000), rng.integers(900_000, 1_200_000, 260_000)]))
+    cost = dist.span_costs(c, 4998, 2_400_000)
+    for world in (2, 3, 4, 8):
+        eq = dist.equal_plan(2_400_000, world, 0)
+        assert eq.in_place and sum(k for _, k in eq.bounds) == 2_400_000
+        bal = [dist.balanced_plan(2_400_000, world, r, cost) for r in range(world)]
+        assert all(b.bounds == bal[0].bounds for b in bal)        # every rank derives the same plan
+        b = bal[0]
+        assert b.bounds[0][0] == 0 and sum(k for _, k in b.bounds) == 2_400_000
+        assert all(f % dist.ALIGN == 0 for f, _ in b.bounds)
+        # summed cost per shard: balanced is much flatter than equal-width on this density
+        prefix = np.concatenate([[0.0], np.cumsum(cost)])
+        load = lambda bounds: [prefix[-(-(f + k) // dist.SPAN)] - prefix[f // dist.SPAN] for f, k in bounds]
+        lb, le = load(b.bounds), load(eq.bounds)
+        assert max(lb) / (sum(lb) / world) < 1.1 < max(le) / (sum(le) / world)
+        # the padded all-gather layout round-trips
+        spec = rng.random(2_400_000)
+        gathered = np.zeros(world * b.S)
+        for r, (f, k) in enumerate(b.bounds):
+            gathered[r * b.S:r * b.S + k] = spec[f:f + k]
+        assert np.array_equal(b.assemble(gathered), spec)
+    # more ranks than aligned blocks: trailing shards are empty, nothing is lost
+    tiny = dist.balanced_plan(3000, 8, 7, dist.span_costs(np.array([10, 20, 2999]), 48, 3000))
+    assert sum(k for _, k in tiny.bounds) == 3000 and tiny.count == 0

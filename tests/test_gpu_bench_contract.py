@@ -32,16 +32,22 @@ def test_default_contract():
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2
-    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["unit"] == "evals/s"
     assert "workload" in d["config"] and "model" not in d["config"]
-    assert d["value"] > 1e11 and d["ms_per_step"] > 0
+    assert "CO2+H2O+CH4 100-2500" in d["config"]["workload"] and d["config"]["grid_points_per_gpu"] == 2400000
+    assert d["value"] > 1e12 and d["ms_per_step"] > 0
     assert abs(d["value"] - d["config"]["evals_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["launches"] == 2      # steps 0 and 4 of 5 carry events
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e5 and "sample" in c
+    assert c["vectorised_value"] > c["value"]
+    assert r["sweep_fused_in"] is True and "traffic_stale" in r and "busy_frac" in d["valu_f64"]
+    # 3 cross sections + k, T, I written once each, 56 B per line read
+    assert r["algorithmic_bytes_per_launch"] == 56.0 * d["config"]["lines_per_gpu"] + 8.0 * 2400000 * 6
+    assert "api_path" in d and d["api_path"]["ms_per_call"] > 0
 
 
 def test_forced_single_rank_communicator_pipeline():

@@ -168,3 +168,71 @@ def test_c5_full_size_column_sampled_parity(ctx):
     column.enqueue()
     assert np.array_equal(column.results()["toa"], got["toa"])
     column.free()
+
+
+def c3_molecules(cfg):
+    from pyrad_amd.model import concentration_from_kwargs
+    mols = []
+    for mol in cfg["molecules"]:
+        sp = synthetic.SPECIES[mol["species"]]
+        mols.append(dict(conc=concentration_from_kwargs(**mol["conc"]),
+                         isotopologues=[dict(lines=mol["lines"], molmass=sp["molmass"],
+                                             q_T=synthetic.q_value(mol["species"], cfg["T"]), q296=sp["q296"])]))
+    return mols
+
+
+@pytest.mark.parametrize("mode", ["balanced", "equal"])
+def test_config4_workload_eight_shards_equal_unsharded(ctx, mode):
+    """BASELINE config 4's workload on one GPU: the full-size C3 cell cut into 8 contiguous shards
+    (cost-balanced bounds, and equal widths), every shard computed alone with its halo of lines exactly
+    as rank r of 8 would, laid into the all-gather's padded layout and compacted back to grid order
+    (lbl_gather_compact_dev): the assembled spectra equal the unsharded ones (same lines per point,
+    same order: bit for bit), the shards' eval counts add up to the whole job's, and a shard's fused
+    and unfused steps agree."""
+    from pyrad_amd import engine
+    cfg = synthetic.config_c3()
+    mols = c3_molecules(cfg)
+    args = (cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"], mols, cfg["base_resolution"],
+            cfg["dynamic_resolution"])
+    whole = engine.ResidentLayer(ctx, *args)
+    whole.enqueue(surface_T=288)
+    ref = whole.results()
+    ref_xs = [whole.xsec_host(i) for i in range(3)]
+    evals_whole, n = whole.evals, whole.n
+    whole.free()
+    G = 8
+    plans = [engine.balanced_shards([dict(cfg, molecules=mols)], G, r) if mode == "balanced"
+             else engine.as_plan((G, r), n) for r in range(G)]
+    S = plans[0].S
+    assert all(p.bounds == plans[0].bounds for p in plans) and sum(c for _, c in plans[0].bounds) == n
+    if mode == "balanced":
+        assert all(f % 1024 == 0 for f, _ in plans[0].bounds)
+    gathered = {k: ctx.buffer(G * S).fill(0.0) for k in ("abs_coef", "trans", "I_out")}
+    evals, lines_kept = 0, 0
+    for r in range(G):
+        part = engine.ResidentLayer(ctx, *args, shard=plans[r])
+        assert (part.first, part.count) == plans[r].bounds[r]
+        part.enqueue(surface_T=288)
+        sl = slice(part.first, part.first + part.count)
+        for i in range(3):
+            assert np.array_equal(part.xsec_host(i)[sl], ref_xs[i][sl]), (r, i)
+        # what the all-gather moves: S doubles from this rank's first point into slot r
+        for k, b in (("abs_coef", part.abs_coef), ("trans", part.trans), ("I_out", part.I_out)):
+            gathered[k].upload(b.download(part.count, part.first), offset=r * S)
+        if r in (0, 5):
+            fused = {k: v[sl].copy() for k, v in part.results().items()}
+            part.enqueue(surface_T=288, fused=False)
+            assert all(np.array_equal(part.results()[k][sl], fused[k]) for k in fused)
+        evals += part.evals
+        lines_kept += part.n_lines
+        part.free()
+    assert evals == evals_whole
+    assert lines_kept < 1.1 * 3 * 131072          # halo replication stays below 10 % at 8 shards
+    out = ctx.buffer(n)
+    for k, name in (("abs_coef", "abs_coef"), ("trans", "transmittance"), ("I_out", "transmission")):
+        ctx.gather_compact_dev(gathered[k], S, plans[0].bounds, out)
+        got = out.download(n)
+        assert np.array_equal(got, ref[name]), name
+        assert np.array_equal(plans[0].assemble(gathered[k].download(G * S)), ref[name])
+        gathered[k].free()
+    out.free()

@@ -320,9 +320,9 @@ def test_error_paths(ctx):
     xb, out = ctx.buffer(n), ctx.buffer(n)
     L = ctx.lines(lines)
     with pytest.raises(nat.LblError):               # I_out without I_in or a surface temperature
-        ctx.layer_step_dev(L, iso, engine.native_grid(g), xb, 4e-4, 10.0, I_out=out)
+        ctx.layer_step_dev(L, iso, engine.native_grid(g), xb, None, 4e-4, 10.0, I_out=out)
     with pytest.raises(nat.LblError):               # output buffer shorter than the base grid
-        ctx.layer_step_dev(L, iso, engine.native_grid(g), ctx.buffer(n - 1), 4e-4, 10.0)
+        ctx.layer_step_dev(L, iso, engine.native_grid(g), ctx.buffer(n - 1), None, 4e-4, 10.0)
     layer = dict(xsec=[xb, xb], iso_mol=[1, 0], conc=[1e-3, 2e-3], P=1000.0, T=280.0, depth=5.0)
     with pytest.raises(nat.LblError):               # iso_mol must be non-decreasing
         ctx.column_step_dev([layer], 600, 700, n, out, surface_T=288.0)
@@ -535,6 +535,73 @@ def test_fused_layer_step_is_bit_identical(ctx, orc):
             check(r["abs_coef"][sl], ref["abs_coef"][sl])
             check(r["transmission"][sl], ref_I[sl])
             I0.free(); L.free()
+
+
+@pytest.mark.parametrize("variant", [5, 3])
+def test_fused_layer_step_many_line_lists_is_bit_identical(ctx, orc, variant):
+    """A layer with several line lists (3 molecules, one with two isotopologues): the chain form of
+    lbl_layer_step_dev - one workgroup owns its grid points for all line lists and folds molecule
+    sums, absorption coefficient, transmittance and radiance in the output stage - against the
+    accumulate launch + separate sweep launch, whole grid and shards, every launch shape the
+    library picks for these sizes and forced ones; then against the oracle."""
+    from pyrad_amd import engine
+    ctx.set_option("accum_variant", variant)
+    try:
+        for rmin, rmax, n_lines, P in ((640, 672, 2500, 1013.25), (100, 130, 300, 1013.25), (2000, 2004, 60, 300.0)):
+            g = orc.layer_grid(P, rmin, rmax, .001, False)
+            T = 255
+            species = [("co2", dict(ppm=400), 71), ("co2_636", None, 72), ("h2o", dict(percentage=1), 73), ("ch4", dict(ppm=1.8), 74)]
+            sets = {s: synthetic.make_lines(seed, n_lines, g["eff_min"], g["eff_max"]) for s, _, seed in species}
+            iso_of = lambda s: dict(lines=sets[s], molmass=synthetic.SPECIES[s]["molmass"], q_T=synthetic.q_value(s, T),
+                                    q296=synthetic.SPECIES[s]["q296"])
+            mols = [dict(conc=orc.concentration(ppm=400), isotopologues=[iso_of("co2"), iso_of("co2_636")]),
+                    dict(conc=orc.concentration(percentage=1), isotopologues=[iso_of("h2o")]),
+                    dict(conc=orc.concentration(ppm=1.8), isotopologues=[iso_of("ch4")])]
+            for shard, R, LS in ((None, 0, 0), ((3, 1), 0, 0), (None, 4, 1), (None, 4, 4), (None, 2, 2), ((2, 0), 1, 8)):
+                ctx.set_option("accum_points_per_lane", R)
+                ctx.set_option("accum_line_split", LS)
+                L = engine.ResidentLayer(ctx, 8.0, T, P, rmin, rmax, mols, .001, False, shard=shard)
+                assert len(L.jobs) == 4 and L.iso_mol == [0, 0, 1, 2]
+                sl = slice(L.first, L.first + L.count)
+                L.enqueue(surface_T=288.0, fused=False)
+                two = {k: v[sl].copy() for k, v in L.results().items()}
+                xs_two = [L.xsec_host(i)[sl].copy() for i in range(4)]
+                for b in [L.abs_coef, L.trans, L.I_out] + [j[3] for j in L.jobs]:
+                    b.fill(0.0)
+                L.enqueue(surface_T=288.0, fused=True)
+                one = L.results()
+                for i in range(4):
+                    assert np.array_equal(L.xsec_host(i)[sl], xs_two[i]), (i, rmin, shard, R, LS)
+                for k in two:
+                    assert np.array_equal(one[k][sl], two[k]), (k, rmin, shard, R, LS)
+                # forcing the two-call form inside the entry point gives the same bits too
+                ctx.set_option("layer_step_fused", 0)
+                L.enqueue(surface_T=288.0, fused=True)
+                ctx.set_option("layer_step_fused", 1)
+                for k in two:
+                    assert np.array_equal(L.results()[k][sl], two[k])
+                if shard is None and R == 0:
+                    cfg = dict(depth=8.0, T=T, P=P, range_min=rmin, range_max=rmax, base_resolution=.001,
+                               dynamic_resolution=False,
+                               molecules=[dict(species="co2", conc=dict(ppm=400), lines=sets["co2"])])
+                    # oracle: molecule by molecule (layer_properties takes one isotopologue per molecule)
+                    k_ref = np.zeros(L.n)
+                    for m, names in ((mols[0], ("co2", "co2_636")), (mols[1], ("h2o",)), (mols[2], ("ch4",))):
+                        xs_m = np.zeros(L.n)
+                        for nm in names:
+                            lines = orc.select_window(sets[nm], g["eff_min"], g["eff_max"])
+                            xs, _ = orc.create_cross_section(lines, T, P, m["conc"], synthetic.SPECIES[nm]["molmass"],
+                                                             synthetic.q_value(nm, T), synthetic.SPECIES[nm]["q296"], g)
+                            xs_m = xs_m + xs
+                        k_ref = k_ref + orc.abs_coef(xs_m, m["conc"], P, T)
+                    check(one["abs_coef"], k_ref)
+                    check(one["transmittance"], orc.transmittance(k_ref, 8.0))
+                L.free()
+    finally:
+        ctx.set_option("accum_variant", 5)
+        ctx.set_option("accum_points_per_lane", 0)
+        ctx.set_option("accum_line_split", 0)
+        ctx.set_option("layer_step_fused", 1)
 
 
 @pytest.mark.parametrize("seed", range(16))
