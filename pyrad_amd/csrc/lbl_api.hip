@@ -784,7 +784,9 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             ++e;
         }
         Group g{k, e - k, 0, 0, 0, ctx->accum_variant, nullptr, 0, nullptr, {}};
-        if (fuse) pts /= (e - k);            // a chain: one grid, its line lists one after the other
+        // (a chain gets the shape its line lists would get as ordinary jobs of one batch - points and
+        // lines summed over the jobs - so that the fused and the two-call form of a layer step sum every
+        // grid point in the same order and agree bit for bit)
         choose_shape(ctx, g.variant, pts, lns, mh, &g.R, &g.LS);
         // with the R actually chosen (a small grid may have shrunk it): does any job of the group have far lines?
         if (ctx->accum_variant == 5 && mxh < 32LL * g.R * (far_half_spans + 1)) g.variant = 3;

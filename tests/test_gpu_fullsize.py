@@ -186,9 +186,12 @@ def test_config4_workload_eight_shards_equal_unsharded(ctx, mode):
     """BASELINE config 4's workload on one GPU: the full-size C3 cell cut into 8 contiguous shards
     (cost-balanced bounds, and equal widths), every shard computed alone with its halo of lines exactly
     as rank r of 8 would, laid into the all-gather's padded layout and compacted back to grid order
-    (lbl_gather_compact_dev): the assembled spectra equal the unsharded ones (same lines per point,
-    same order: bit for bit), the shards' eval counts add up to the whole job's, and a shard's fused
-    and unfused steps agree."""
+    (lbl_gather_compact_dev).  Cost-balanced bounds are multiples of a workgroup's 1024 points, so every
+    span sees the same lines in the same classes as in the unsharded run and the assembled spectra are
+    bit-identical to it; equal-width bounds (300,000 points) shift the spans, which changes which
+    lines go through the far-field series: agreement to 1e-13.  The shards' eval counts add up to the
+    whole job's, and a shard's fused and unfused steps agree bit for bit."""
+    same = (lambda a, b: np.array_equal(a, b)) if mode == "balanced" else (lambda a, b: rel_err(a, b) <= 1e-13)
     from pyrad_amd import engine
     cfg = synthetic.config_c3()
     mols = c3_molecules(cfg)
@@ -215,7 +218,7 @@ def test_config4_workload_eight_shards_equal_unsharded(ctx, mode):
         part.enqueue(surface_T=288)
         sl = slice(part.first, part.first + part.count)
         for i in range(3):
-            assert np.array_equal(part.xsec_host(i)[sl], ref_xs[i][sl]), (r, i)
+            assert same(part.xsec_host(i)[sl], ref_xs[i][sl]), (r, i)
         # what the all-gather moves: S doubles from this rank's first point into slot r
         for k, b in (("abs_coef", part.abs_coef), ("trans", part.trans), ("I_out", part.I_out)):
             gathered[k].upload(b.download(part.count, part.first), offset=r * S)
@@ -232,7 +235,7 @@ def test_config4_workload_eight_shards_equal_unsharded(ctx, mode):
     for k, name in (("abs_coef", "abs_coef"), ("trans", "transmittance"), ("I_out", "transmission")):
         ctx.gather_compact_dev(gathered[k], S, plans[0].bounds, out)
         got = out.download(n)
-        assert np.array_equal(got, ref[name]), name
-        assert np.array_equal(plans[0].assemble(gathered[k].download(G * S)), ref[name])
+        assert same(got, ref[name]), name
+        assert np.array_equal(plans[0].assemble(gathered[k].download(G * S)), got)
         gathered[k].free()
     out.free()
