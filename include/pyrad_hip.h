@@ -112,8 +112,8 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "accum_tile_order"       positional order only: 1 (default) natural | 0 one contiguous run of
  *                            tiles per XCD | 2 golden-ratio stride
  *   "accum_blocks_per_cu"    variant 4 only: resident workgroups per CU, 0 = ask the runtime
- *   "layer_step_fused"       1 (default) lbl_layer_step_dev folds the sweep into the accumulate kernel |
- *                            0 accumulate launch + separate sweep launch (bit-identical; A/B and parity tests)
+ *   "layer_step_fused"       1 (default) lbl_layer_step_dev folds the sweep of a single-line-list layer into the
+ *                            accumulate kernel | 0 always accumulate launch + sweep launch (bit-identical; A/B)
  *   "debug_throw"            test hook: 1 / 2 / 3 raise std::bad_alloc / std::runtime_error /
  *                            std::length_error inside the library; the call must come back as
  *                            LBL_ERR_OOM / LBL_ERR_STATE / LBL_ERR_OOM (no exception crosses this boundary) */
@@ -199,12 +199,12 @@ int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* xsec, const 
 
 /* One step of a layer (the gas cell of pyradClasses.py:648 after its addMolecule calls):
  * lbl_xsec_accumulate_dev for the layer's n_iso line lists followed by lbl_layer_sweep_dev, in ONE
- * launch sequence.  When the work grid is the base grid a workgroup owns its grid points for all
- * line lists, one after the other: every cross section is stored as usual, folded into the
- * molecule sum and the absorption coefficient while it is still in a register
- * (pyradClasses.py:566-571, 583, 707-712), and transmittance and outgoing radiance follow in the
- * output stage of the last line list (pyradClasses.py:716, 784-787) - same arithmetic and order
- * as the two separate calls, bit-identical results, no sweep launch and no re-read of the cross
+ * launch sequence.  A layer with one line list on the base grid has the sweep of a point in the
+ * accumulate kernel's output stage, right after that point's cross section is final (same arithmetic,
+ * bit-identical results, no sweep launch, no re-read of the cross section).  With several line lists
+ * the sweep kernel follows the accumulate launch: both ways of folding it in were measured slower on
+ * MI355X.  Molecule sums, absorption coefficient, transmittance, outgoing radiance:
+ * pyradClasses.py:566-571, 583, 707-716, 784-787; xsec[i] always receives line list i's cross
  * sections.  All line lists share `grid` (axis, shard) and the layer's T and P (iso[i].T / .P must
  * equal iso[0]'s); iso_mol / n_mol / conc as in lbl_layer_sweep_dev; xsec[i] receives the cross
  * section of line list i.  lbl_set_option("layer_step_fused", 0) forces the two-call form. */

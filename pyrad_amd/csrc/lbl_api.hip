@@ -577,14 +577,13 @@ static void choose_shape(const lbl_ctx* ctx, int variant, long long total_points
 // evaluates the same correctly rounded IEEE expression (nu - range_min) / resolution on the same
 // doubles (host and device code are built without fast-math), and truncation is shared.
 static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::vector<int>& jobs_in_group,
-                                               lbl_lines* const* lines, const lbl_grid* grid, int R, int LS, long long tile_pts,
-                                               bool chain) {
+                                               lbl_lines* const* lines, const lbl_grid* grid, int R, int LS, long long tile_pts) {
     std::vector<uint64_t> key;
     const bool far_field = variant == 5;
     int far_half_spans = 0;
     double far_cost = 1.0;
     if (far_field) accumulate_far_field_params(R, &far_half_spans, &far_cost);
-    key.push_back((uint64_t)R << 32 | (uint64_t)LS << 8 | (uint64_t)chain << 4 | (uint64_t)ctx->lpt << 1 | (uint64_t)far_field);
+    key.push_back((uint64_t)R << 32 | (uint64_t)LS << 8 | (uint64_t)ctx->lpt << 1 | (uint64_t)far_field);
     for (int j : jobs_in_group) {
         long long sf, sc;
         shard_range(grid[j], &sf, &sc);
@@ -647,8 +646,7 @@ static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const 
                 const double n_near = (double)(e[5] - e[4]);
                 cost += n_near * (5.0 * R + 29.0) + n_edge * 8.0 * R + n_far * far_cost * 5.0 * R + 600.0;
             }
-            if (chain && k > 0) items[(size_t)t].count += (int)(cost + 0.5);      // one workgroup walks every line list of the chain
-            else items.push_back({(int)(cost + 0.5), (int)k, (int)t});
+            items.push_back({(int)(cost + 0.5), (int)k, (int)t});
         }
     }
     std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.count > y.count; });
@@ -705,10 +703,8 @@ struct DbgOut { long long* index; double* lhw; double* ghw; double* inten; int32
 
 static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines, const lbl_iso_params* iso,
                               const lbl_grid* grid, double* const* out_dev, const DbgOut* dbg, bool prep_only,
-                              const FusedSweep* fuse = nullptr, const int32_t* chain_flags = nullptr,
-                              const double* chain_conc = nullptr) {
-    // fuse != NULL: the n_jobs jobs are the line lists of ONE layer (same grid) and form a chain:
-    // one workgroup accumulates all of them on its points and folds the layer sweep in
+                              const FusedSweep* fuse = nullptr, double fuse_conc = 0.0) {
+    // fuse != NULL (n_jobs == 1): the layer sweep runs in the output stage of the one job
     if (n_jobs <= 0) return LBL_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // layout of the scratch arenas
@@ -784,9 +780,6 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             ++e;
         }
         Group g{k, e - k, 0, 0, 0, ctx->accum_variant, nullptr, 0, nullptr, {}};
-        // (a chain gets the shape its line lists would get as ordinary jobs of one batch - points and
-        // lines summed over the jobs - so that the fused and the two-call form of a layer step sum every
-        // grid point in the same order and agree bit for bit)
         choose_shape(ctx, g.variant, pts, lns, mh, &g.R, &g.LS);
         // with the R actually chosen (a small grid may have shrunk it): does any job of the group have far lines?
         if (ctx->accum_variant == 5 && mxh < 32LL * g.R * (far_half_spans + 1)) g.variant = 3;
@@ -794,7 +787,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             // cached host schedule of this group: dispatch order + the line ranges of every span
             std::vector<int> members(order.begin() + k, order.begin() + e);
             const lbl_ctx::Schedule* sc = group_schedule(ctx, g.variant, members, lines, grid, g.R, g.LS,
-                                                         accumulate_tile_points(g.R, g.LS, g.variant), fuse != nullptr);
+                                                         accumulate_tile_points(g.R, g.LS, g.variant));
             if (!sc) return fail(ctx, LBL_ERR_OOM, "schedule allocation failed");
             g.worklist = sc->d_list; g.total_tiles = sc->total; g.tabs = sc->d_tabs; g.tab_off = sc->tab_off;
         }
@@ -848,13 +841,10 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             a.flush_every = (a.H + 64 * g.R + 1 <= 40000) ? 32 : 16;
             a.pad = ctx->tile_order;
             a.span_tab = g.tabs ? g.tabs + g.tab_off[(size_t)(k - g.first)] : nullptr;
-            a.chain_len = 1;
-            if (fuse) {
-                // (a chain is one group: same grid, so same window class; its jobs keep their order)
-                a.chain_len = (k == g.first) ? g.count : 1;
-                a.chain_flags = chain_flags ? chain_flags[j] : (CHAIN_MOL_FIRST | CHAIN_MOL_LAST);
-                a.conc = chain_conc ? chain_conc[j] : 0.0;
-                if (k == g.first) a.fuse = *fuse;
+            if (fuse && n_jobs == 1) {
+                a.chain_flags = CHAIN_MOL_FIRST | CHAIN_MOL_LAST;
+                a.conc = fuse_conc;
+                a.fuse = *fuse;
             }
             g.max_tiles = std::max(g.max_tiles, a.n_tiles);
             if (balanced) {
@@ -924,9 +914,8 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             launch_accumulate_balanced(da + g.first, g.count, (int)S, g.R, group_workers[gi], spans, cnts, prefix, slab,
                                        ctx->stream);
         } else {
-            // a chain of one line list is an ordinary job with the fused output stage
-            launch_accumulate(da + g.first, fuse ? 1 : g.count, g.max_tiles, g.R, g.LS, g.variant, g.worklist, g.total_tiles,
-                              fuse != nullptr && g.count > 1, ctx->stream);
+            launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, g.variant, g.worklist, g.total_tiles,
+                              ctx->stream);
         }
         prof_end(ctx, PROF_ACCUM, ev);
         HIP_TRY(ctx, hipGetLastError());
@@ -1113,8 +1102,6 @@ extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lin
     const int64_t n = grid->n_base;
     std::vector<double*> outs((size_t)n_iso);
     std::vector<lbl_grid> grids((size_t)n_iso, *grid);
-    std::vector<int32_t> flags((size_t)n_iso, 0);
-    std::vector<double> link_conc((size_t)n_iso, 0.0);
     for (int i = 0; i < n_iso; ++i) {
         if ((rc = check_buf(ctx, xsec[i], n, "xsec", true))) return rc;
         if (iso_mol[i] < 0 || iso_mol[i] >= n_mol || (i > 0 && iso_mol[i] < iso_mol[i - 1]))
@@ -1122,16 +1109,16 @@ extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lin
         if (iso[i].T != iso[0].T || iso[i].P != iso[0].P)
             return fail(ctx, LBL_ERR_BAD_ARG, "line list %d: T and P must be the layer's (those of line list 0)", i);
         outs[i] = xsec[i]->d;
-        if (i == 0 || iso_mol[i] != iso_mol[i - 1]) flags[i] |= CHAIN_MOL_FIRST;
-        if (i == n_iso - 1 || iso_mol[i] != iso_mol[i + 1]) flags[i] |= CHAIN_MOL_LAST;
-        link_conc[i] = conc[iso_mol[i]];
     }
     if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
     if ((rc = check_buf(ctx, abs_coef, n, "abs_coef", false))) return rc;
     if ((rc = check_buf(ctx, trans, n, "trans", false))) return rc;
     if ((rc = check_buf(ctx, I_out, n, "I_out", false))) return rc;
     if (I_out && !I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "I_out needs I_in or surface_T > 0");
-    const bool fusable = (ctx->accum_variant == 3 || ctx->accum_variant == 5) && !needs_regrid(*grid) && !ctx->no_fuse;
+    // One line list on the base grid: the sweep of a point runs in the accumulate kernel's output stage.
+    // (A molecule without line lists before it adds 0 * conc to k in the sweep kernel: same bits.)
+    const bool fusable = n_iso == 1 && (ctx->accum_variant == 3 || ctx->accum_variant == 5) && !needs_regrid(*grid) &&
+                         !ctx->no_fuse;
     if (fusable) {
         FusedSweep f;
         memset(&f, 0, sizeof f);
@@ -1144,10 +1131,10 @@ extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lin
         f.trans = trans ? trans->d : nullptr;
         f.I_out = I_out ? I_out->d : nullptr;
         f.n = n; f.on = 1;
-        return enqueue_accumulate(ctx, n_iso, lines, iso, grids.data(), outs.data(), nullptr, false, &f, flags.data(),
-                                  link_conc.data());
+        return enqueue_accumulate(ctx, 1, lines, iso, grids.data(), outs.data(), nullptr, false, &f, conc[iso_mol[0]]);
     }
-    // a work grid that needs the regrid kernel, or a kernel variant without the fused stage: two steps
+    // several line lists, a work grid that needs the regrid kernel, or a kernel variant without the fused
+    // stage: the accumulate launch and the sweep launch
     if ((rc = enqueue_accumulate(ctx, n_iso, lines, iso, grids.data(), outs.data(), nullptr, false))) return rc;
     long long sf, sc;
     shard_range(*grid, &sf, &sc);

@@ -77,14 +77,11 @@ struct AccumJob {
     // shard, 8 ints per span {iA, iB, iC, iD, iF1, iF2, 0, 0} (see wave_line_ranges[_far]); NULL:
     // the wave searches the centre indices itself
     const int32_t* span_tab;
-    // Chain (fused layer step, lbl_layer_step_dev): the head job carries chain_len >= 1 = number of
-    // consecutive jobs (line lists of ONE layer, same grid) a workgroup accumulates one after the
-    // other on its points; every link says whether it opens / closes a molecule and that molecule's
-    // volume fraction.  Ordinary jobs: chain_len = 1, fuse.on = 0.
-    int32_t chain_len;
-    int32_t chain_flags;
+    // Fused layer step of a single-line-list layer (lbl_layer_step_dev): the sweep of a point runs in
+    // this job's output stage with the molecule's volume fraction `conc`.
+    int32_t chain_flags, pad2;
     double conc;
-    FusedSweep fuse;       // head only; fuse.on: fold every point right after its cross section is final
+    FusedSweep fuse;       // fuse.on: sweep every point right after its cross section is final
 };
 enum : int32_t { CHAIN_MOL_FIRST = 1, CHAIN_MOL_LAST = 2 };
 
@@ -160,7 +157,7 @@ struct ColumnArgs {
 // ---- launchers (lbl_kernels.hip) ---------------------------------------------------------
 void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStream_t s);
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
-                       const int2* worklist, int total_tiles, bool chain, hipStream_t s);
+                       const int2* worklist, int total_tiles, hipStream_t s);
 int accumulate_tile_points(int R, int LS, int variant);
 void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost);
 // balanced variant (4): span ranges -> prefix sum -> equal shares of (span, line) pairs per wave -> slab reduce

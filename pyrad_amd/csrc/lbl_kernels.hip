@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
     int regime = -1;
     if (i < J.n_lines) {
         const double nu = J.nu[i];
-        const double T = J.T, q = J.q_frac;
+        const double q = J.q_frac;
         const double Pp0 = J.P_over_p0;                                   // P / p0, evaluated on the host
         // Line.broadenedLine (pyradClasses.py:252-254)
         const double broadened = nu + J.delta_air[i] * J.P / p0;
@@ -829,12 +829,12 @@ __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec
     }
 }
 
-// Fused layer sweep (lbl_layer_step_dev): a workgroup owns its grid points for ALL line lists of the
-// layer, one after the other, so the cross section of a point is in a register when it is final and
-// the absorption coefficient can be folded on the spot - exactly the arithmetic and operation order
-// of layer_sweep_kernel:  xs_m = 0 + sum of the molecule's isotopologue cross sections
-// (pyradClasses.py:566-571), k = 0 + sum_m xs_m * conc_m * P / 1E4 / kB / T (pyradClasses.py:583,
-// 707-712).  fold: one isotopologue's finished cross section into (xs_m, k).
+// Fused sweep of a layer with ONE line list (lbl_layer_step_dev): the arithmetic and operation order of
+// layer_sweep_kernel applied in the accumulate kernel's output stage, where the cross section of a point
+// is in a register:  xs_m = 0 + cross section (pyradClasses.py:566-571), k = 0 + xs_m * conc * P / 1E4 /
+// kB / T (pyradClasses.py:583, 707-712).  Layers with several line lists keep the separate sweep launch:
+// both ways of folding them into this kernel were built and measured slower (DESIGN.md "what did not help":
+// one workgroup walking all line lists of its points, -6 %; the last workgroup of a tile folding it, -3 %).
 __device__ __forceinline__ void fused_fold(const FusedSweep& A, const AccumJob& J, double xsec, double& xs_m, double& kk) {
 #pragma clang fp contract(off)
     if (J.chain_flags & CHAIN_MOL_FIRST) xs_m = 0.0;
@@ -863,14 +863,8 @@ __device__ __forceinline__ void fused_finish(const FusedSweep& A, long long j, d
 // consecutive points and a lane reading every 64th point are both nearly conflict-free)
 __device__ __forceinline__ int span_slot(int o) { return o + (o >> 4); }
 
-// CHAIN: the workgroup walks chain_len line lists (fused layer step with several line lists).  The
-// chain loop costs registers (loop-invariant constants of the body - the exp polynomial, masks - are
-// hoisted across it: 150-168 instead of 123 VGPRs), so ordinary jobs keep the loop-free instantiation.
-#ifndef LBL_CHAIN_MIN_BLOCKS
-#define LBL_CHAIN_MIN_BLOCKS 1
-#endif
-template <int R, int LS, bool FF = false, bool CHAIN = false>
-__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), (CHAIN ? LBL_CHAIN_MIN_BLOCKS : ((R >= 8 && LS <= 4) ? 4 : 1)))
+template <int R, int LS, bool FF = false>
+__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), ((R >= 8 && LS <= 4) ? 4 : 1))
 void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* __restrict__ worklist) {
     constexpr int NW = LS > 4 ? LS : 4;              // wavefronts per workgroup (LS = 8: 512 threads)
     constexpr int PG = NW / LS;                      // point groups (64*R points each) per workgroup
@@ -879,9 +873,6 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
     constexpr int STAGE_MIN = FF ? 576 : 512;        // FF: 8 x 72 doubles for wave_sum_rows
     constexpr int STAGE = (68 * R > STAGE_MIN) ? 68 * R : STAGE_MIN;
     __shared__ double s_stage[NW][STAGE];
-    // chains (fused layer step with several line lists): the running molecule cross section and
-    // absorption coefficient of every point of the workgroup between two line lists
-    __shared__ double s_fold[PG][2][64 * R];
 
     // worklist: (job, tile) pairs of the whole launch sorted by decreasing line count (longest
     // first), built once per (line lists, grid) on the host; without it blockIdx.y is the job
@@ -892,40 +883,24 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
     } else {
         tile = xcd_tile(blockIdx.x, jobs[job].n_tiles, jobs[job].pad);
     }
-    // a chain = chain_len consecutive jobs on ONE grid (the line lists of a layer): this workgroup
-    // accumulates them one after the other on the same points; grid, shard and window are the head's
-    const AccumJob& J0 = jobs[job];
-    const int chain = CHAIN ? uniform_i32(J0.chain_len) : 1;
-    const int lane_id = threadIdx.x & 63;
-    const int wave_id = uniform_i32(threadIdx.x >> 6);
-    const int n_end_id = J0.p_end;
-    const long long wave_lo_ll = (long long)J0.p_begin + (long long)(tile < 0 ? 0 : tile) * (64LL * R * PG) + (long long)(wave_id / LS) * (64LL * R);
-    const bool active = tile >= 0 && wave_lo_ll < n_end_id;
-    if (LS == 1 && !active) return;                  // no workgroup barrier below when waves do not share points
-    const int wlo_id = active ? (int)wave_lo_ll : 0;
-    const int H_id = J0.H;
-
-#pragma clang loop unroll(disable)
-    for (int link = 0; link < chain; ++link) {
-    // The body below is the whole kernel of an ordinary job.  Everything per-lane in it derives from
-    // the lane id and the span origin; both are made opaque per iteration so that the compiler does
-    // not hoist the body's (many) loop-invariant per-lane values out of the chain loop and keep them
-    // alive across it (that cost 60-80 VGPRs and half the occupancy).
-    int lane = lane_id, wlo = wlo_id, wave = wave_id, H = H_id, n_end = n_end_id;
-    if (CHAIN) {
-        asm volatile("" : "+v"(lane));
-        asm volatile("" : "+s"(wlo), "+s"(wave), "+s"(H), "+s"(n_end));
-    }
+    const AccumJob& J = jobs[job];
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform_i32(threadIdx.x >> 6);
     const int grp = wave / LS, part = wave % LS;
-    double* lh = s_stage[wave];
-    double* lc = s_stage[wave] + 256;
+    const int n_end = J.p_end;
+    const long long wave_lo_ll = (long long)J.p_begin + (long long)(tile < 0 ? 0 : tile) * (64LL * R * PG) + (long long)grp * (64LL * R);
+    const bool active = tile >= 0 && wave_lo_ll < n_end;
+    if (LS == 1 && !active) return;                  // no workgroup barrier below when waves do not share points
+    const int wlo = active ? (int)wave_lo_ll : 0;
     const int whi = active ? min(wlo + 64 * R - 1, n_end - 1) : 0;
+    const int H = J.H;
     const int p0 = wlo + lane * R;
     const double x0 = (double)p0;
     const double Hf = (double)H;
-    const AccumJob& J = jobs[job + link];
     WaveAcc<R> S;
     S.init(J.flush_every);
+    double* lh = s_stage[wave];
+    double* lc = s_stage[wave] + 256;
 
     // line ranges of this span: tabulated by the host with the schedule, else searched here
     const int32_t* tab = nullptr;
@@ -993,7 +968,6 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         // point is summed over the waves in the same order whichever wave stores it
         double* __restrict__ out = J.out;
         const int w0 = wave - part;                      // first wave of this span
-        const bool last = link + 1 == chain;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             if (LS > 1 && (i % LS) != part) continue;        // row i belongs to wave i % LS of the span
@@ -1002,24 +976,15 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
             for (int q = 1; q < LS; ++q) t += s_stage[w0 + q][span_slot(o)];
             if (wlo + o < n_end) {
                 out[wlo + o] = t;
-                if (J0.fuse.on) {
-                    // (xs_m, k) of this point: kept by the lane that owns row i of the span, in LDS
-                    // between two line lists of the chain
+                if (J.fuse.on) {
+                    // a layer with ONE line list: the sweep of a point right here, its cross section is in a register
                     double xs_m = 0.0, kk = 0.0;
-                    if (link > 0) { xs_m = s_fold[grp][0][o]; kk = s_fold[grp][1][o]; }
-                    fused_fold(J0.fuse, J, t, xs_m, kk);
-                    if (last) fused_finish(J0.fuse, wlo + o, kk);
-                    else { s_fold[grp][0][o] = xs_m; s_fold[grp][1][o] = kk; }
+                    fused_fold(J.fuse, J, t, xs_m, kk);
+                    fused_finish(J.fuse, wlo + o, kk);
                 }
             }
         }
     }
-    // the next line list stages its records in the words other waves of the span have just read
-    if (link + 1 < chain) {
-        if (LS > 1) __syncthreads();
-        else __builtin_amdgcn_wave_barrier();
-    }
-    }   // chain
 }
 
 // ---- variant 4: balanced single-round partition -----------------------------------------------
@@ -1490,7 +1455,7 @@ static void launch_accum_scalar(const AccumJob* d_jobs, int n_jobs, int max_tile
     }
 }
 
-template <int R, bool FF, bool CHAIN>
+template <int R, bool FF>
 static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, int LS, const int2* worklist,
                              int total_tiles, hipStream_t s) {
     dim3 grid(((max_tiles + 7) / 8) * 8, n_jobs);
@@ -1501,10 +1466,10 @@ static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, 
     // diagnostics only (scripts/cost_fit.py): unused dynamic LDS to limit the workgroups resident per CU
     static const int pad = getenv("LBL_DIAG_LDS_PAD") ? atoi(getenv("LBL_DIAG_LDS_PAD")) : 0;
     switch (LS) {
-        case 8: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 8, FF, CHAIN>), grid, dim3(512), pad, s, d_jobs, worklist); break;
-        case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4, FF, CHAIN>), grid, dim3(256), pad, s, d_jobs, worklist); break;
-        case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2, FF, CHAIN>), grid, dim3(256), pad, s, d_jobs, worklist); break;
-        default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1, FF, CHAIN>), grid, dim3(256), pad, s, d_jobs, worklist); break;
+        case 8: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 8, FF>), grid, dim3(512), pad, s, d_jobs, worklist); break;
+        case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
+        case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
+        default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
     }
 }
 
@@ -1520,28 +1485,25 @@ int accumulate_tile_points(int R, int LS, int variant) {
     return variant >= 3 ? 64 * R * ((LS > 4 ? LS : 4) / LS) : 256 * R;
 }
 
-template <bool FF, bool CHAIN>
-static void launch_accum_lds_r(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, const int2* worklist,
-                               int total_tiles, hipStream_t s) {
-    switch (R) {
-        case 1: launch_accum_lds<1, FF, CHAIN>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-        case 2: launch_accum_lds<2, FF, CHAIN>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-        case 4: launch_accum_lds<4, FF, CHAIN>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-        default: launch_accum_lds<8, FF, CHAIN>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-    }
-}
-
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
-                       const int2* worklist, int total_tiles, bool chain, hipStream_t s) {
+                       const int2* worklist, int total_tiles, hipStream_t s) {
     if (n_jobs <= 0 || max_tiles <= 0) return;
     if (variant >= 5) {
-        if (chain) launch_accum_lds_r<true, true>(d_jobs, n_jobs, max_tiles, R, LS, worklist, total_tiles, s);
-        else launch_accum_lds_r<true, false>(d_jobs, n_jobs, max_tiles, R, LS, worklist, total_tiles, s);
+        switch (R) {
+            case 1: launch_accum_lds<1, true>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 2: launch_accum_lds<2, true>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 4: launch_accum_lds<4, true>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            default: launch_accum_lds<8, true>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+        }
         return;
     }
     if (variant >= 3) {
-        if (chain) launch_accum_lds_r<false, true>(d_jobs, n_jobs, max_tiles, R, LS, worklist, total_tiles, s);
-        else launch_accum_lds_r<false, false>(d_jobs, n_jobs, max_tiles, R, LS, worklist, total_tiles, s);
+        switch (R) {
+            case 1: launch_accum_lds<1, false>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 2: launch_accum_lds<2, false>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 4: launch_accum_lds<4, false>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            default: launch_accum_lds<8, false>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+        }
         return;
     }
     switch (R) {

@@ -44,9 +44,11 @@ def test_default_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e5 and "sample" in c
     assert c["vectorised_value"] > c["value"]
-    assert r["sweep_fused_in"] is True and "traffic_stale" in r and "busy_frac" in d["valu_f64"]
-    # 3 cross sections + k, T, I written once each, 56 B per line read
-    assert r["algorithmic_bytes_per_launch"] == 56.0 * d["config"]["lines_per_gpu"] + 8.0 * 2400000 * 6
+    assert r["sweep_fused_in"] is False and "traffic_stale" in r and "busy_frac" in d["valu_f64"]
+    # K2 of the three-molecule cell: 56 B per line read, one cross section per line list written
+    assert r["algorithmic_bytes_per_launch"] == 56.0 * d["config"]["lines_per_gpu"] + 8.0 * 2400000 * 3
+    sw = d["roofline_sweep"]
+    assert sw["kernel"] == "layer_sweep_kernel" and sw["algorithmic_bytes_per_launch"] == 8.0 * 2400000 * 6 and sw["frac"] > 0.2
     assert "api_path" in d and d["api_path"]["ms_per_call"] > 0
 
 
