@@ -266,6 +266,20 @@ def eval_count(index, W, n_work):
     return int(cnt.sum())
 
 
+def line_survey(nu_in_reader_order, sw, range_min, range_max, resolution, base_resolution):
+    """cls:409-428 createLineSurvey: S added into the bin int((nu - rangeMin) / layer.resolution) of an
+    array of int((max - min) / BASE) bins, in the order the lines were appended (cls:352-357: the
+    reader's dict order); bins outside [0, len-1] are dropped (isBetween, cls:842-846).  With
+    resolution != BASE the index and the array length use different steps - kept as is."""
+    survey = np.zeros(int((range_max - range_min) / base_resolution))       # cls:416
+    last = len(survey) - 1
+    for v, s in zip(nu_in_reader_order, sw):
+        idx = int((v - range_min) / resolution)                             # cls:423
+        if 0 <= idx <= last:
+            survey[idx] = survey[idx] + s
+    return survey
+
+
 # ----------------------------------------------------------------------------
 # Concentration setters (cls:543-560)
 # ----------------------------------------------------------------------------

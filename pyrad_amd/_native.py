@@ -70,6 +70,8 @@ SIGNATURES = {
     "lbl_buffer_download": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "lbl_buffer_fill": (C.c_int, [_P, C.c_double]),
     "lbl_buffer_devptr": (C.c_int, [_P, C.POINTER(_P)]),
+    "lbl_host_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
+    "lbl_host_free": (C.c_int, [_P, _P]),
     "lbl_lines_create": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(_P)]),
     "lbl_lines_destroy": (C.c_int, [_P]),
     "lbl_lines_count": (C.c_int, [_P, C.POINTER(C.c_int64)]),
@@ -180,6 +182,9 @@ class Context:
         if getattr(self, "h", None):
             for child in list(self._children):
                 child.free()
+            for blocks in self.__dict__.pop("_pinned_pool", {}).values():      # idle blocks; a block a caller still
+                for ptr in blocks:                                              # holds an array in is freed with that array
+                    self.lib.lbl_host_free(self.h, ptr)
             self.check(self.lib.lbl_ctx_destroy(self.h))
             self.h = None
 
@@ -243,6 +248,36 @@ class Context:
             self.check(self.lib.lbl_profile_read(self.h, kind, C.byref(n), C.byref(ms)))
             out[name] = (n.value, ms.value)
         return out
+
+    # -- page-locked host arrays ---------------------------------------------------------
+    def host_array(self, n: int) -> np.ndarray:
+        """float64 array of n elements in page-locked host memory (lbl_host_alloc): downloads into it
+        and uploads from it run at the link's DMA rate.  The block returns to a per-context pool when
+        the array (and every view of it) is gone, and is released with the context."""
+        import weakref
+        nbytes = max(int(n), 1) * 8
+        cls = 1 << max(nbytes - 1, 1).bit_length()             # pool by power-of-two size class
+        pool = self.__dict__.setdefault("_pinned_pool", {})
+        free = pool.setdefault(cls, [])
+        if free:
+            ptr = free.pop()
+        else:
+            p = _P()
+            self.check(self.lib.lbl_host_alloc(self.h, cls, C.byref(p)))
+            ptr = p.value
+        raw = (C.c_char * nbytes).from_address(ptr)
+        arr = np.frombuffer(raw, dtype=np.float64, count=int(n))
+        weakref.finalize(raw, Context._recycle, weakref.ref(self), self.lib, cls, ptr)
+        return arr
+
+    @staticmethod
+    def _recycle(ctx_ref, lib, cls, ptr):
+        """the last array over a block is gone: back to the pool, or freed if its context has closed"""
+        ctx = ctx_ref()
+        if ctx is not None and getattr(ctx, "h", None):
+            ctx.__dict__.setdefault("_pinned_pool", {}).setdefault(cls, []).append(ptr)
+        else:
+            lib.lbl_host_free(None, ptr)
 
     # -- objects -------------------------------------------------------------------------
     def buffer(self, n: int, data=None) -> "Buffer":
@@ -396,9 +431,11 @@ class Buffer:
         self.ctx.check(self.ctx.lib.lbl_buffer_upload(self.h, _ptr(a), a.size, int(offset)))
         return self
 
-    def download(self, n: int | None = None, offset: int = 0) -> np.ndarray:
+    def download(self, n: int | None = None, offset: int = 0, pinned: bool = False) -> np.ndarray:
+        """Host copy of n elements.  ``pinned``: into page-locked memory of the context's pool (DMA
+        rate; the array must not outlive the context)."""
         n = self.n - offset if n is None else int(n)
-        out = np.empty(n, dtype=np.float64)
+        out = self.ctx.host_array(n) if pinned else np.empty(n, dtype=np.float64)
         self.ctx.check(self.ctx.lib.lbl_buffer_download(self.h, _ptr(out), n, int(offset)))
         return out
 

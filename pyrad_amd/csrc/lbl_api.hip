@@ -437,6 +437,23 @@ extern "C" int lbl_buffer_fill(lbl_buffer* buf, double value) try {
     return LBL_OK;
 } LBL_GUARD_END(buf ? buf->ctx : nullptr)
 
+extern "C" int lbl_host_alloc(lbl_ctx* ctx, int64_t bytes, void** out) try {
+    if (!ctx || !out) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    if (bytes < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostMalloc(out, (size_t)std::max<int64_t>(bytes, 1), hipHostMallocDefault));
+    return LBL_OK;
+} LBL_GUARD_END(ctx)
+
+// ctx may be NULL: the block outlived its context (a caller still held an array in it)
+extern "C" int lbl_host_free(lbl_ctx* ctx, void* ptr) try {
+    if (!ptr) return LBL_OK;
+    if (ctx) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipHostFree(ptr));
+    return LBL_OK;
+} LBL_GUARD_END(ctx)
+
 extern "C" int lbl_buffer_devptr(lbl_buffer* buf, void** devptr) try {
     if (!buf || !devptr) return fail(nullptr, LBL_ERR_BAD_ARG, "NULL argument");
     *devptr = (void*)buf->d;

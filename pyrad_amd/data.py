@@ -107,12 +107,12 @@ class PyradDataDir:
         return [int(c[0]), c[1], int(c[2]), int(c[3]), float(c[4]), float(c[5]), int(c[6]), float(c[7])]
 
     def getQData(self, global_iso):
+        """readQFile (ut:451-461): every row must hold ``T Q``; a blank row raises IndexError there too."""
         q = {}
         with open('%s/%s/q%s.txt' % (self.root, global_iso, global_iso)) as f:
-            for row in f:
+            for row in f.readlines():
                 cell = row.split()
-                if cell:
-                    q[int(cell[0])] = float(cell[1])
+                q[int(cell[0])] = float(cell[1])
         return q
 
     @staticmethod
@@ -133,11 +133,10 @@ class PyradDataDir:
             if rows is None:
                 raise FileNotFoundError("%s (PyRad would download it; this build has no network code)" % path)
             for row in rows:
-                cell = row.split(',')
-                if len(cell) < 10:
-                    continue
+                cell = row.split(',')                          # a malformed row raises IndexError / ValueError, as ut:434-446
                 nu = float(cell[2])
                 if range_min < nu and nu < range_max:          # ut:437-438
+                    int(cell[1])                               # the reference parses the isotopologue column too (ut:439)
                     info[nu] = (float(cell[3]), float(cell[4]), float(cell[5]), float(cell[6]), float(cell[7]),
                                 float(cell[8]), float(cell[9]))
         if not info:

@@ -95,8 +95,13 @@ def resetCrossSection(obj):
     """cls:38-45: marks every Isotope/Molecule below ``obj`` dirty (a Layer itself is skipped)."""
     if not isinstance(obj, Layer):
         if not obj.exotic:
-            obj.crossSection = np.zeros(int((obj.rangeMax - obj.rangeMin) / utils.BASE_RESOLUTION))
+            n = int((obj.rangeMax - obj.rangeMin) / utils.BASE_RESOLUTION)
+            type(obj).crossSection.defer(obj, lambda n=n: np.zeros(n))      # the zeros of cls:41, made when read
+            if isinstance(obj, Isotope):
+                obj._host_array_assigned("_crossSection_host")
             obj.progressCrossSection = False
+    if isinstance(obj, Isotope):
+        return                      # its children are Lines (the reference walks them and skips each one)
     for child in obj:
         if not isinstance(child, Line):
             resetCrossSection(child)
@@ -340,7 +345,7 @@ def _mark_computed(ctx, isotopes, n):
     for iso in isotopes:
         iso._xs_version += 1
         iso._dev_xsec_valid = True
-        Isotope.crossSection.defer(iso, (lambda b=iso._dev_xsec, n=n: b.download(n)))
+        Isotope.crossSection.defer(iso, (lambda b=iso._dev_xsec, n=n: b.download(n, pinned=True)))
         iso._regime_counts = None
         iso.progressCrossSection = True
     if VERBOSE:
@@ -425,19 +430,19 @@ class _OpticalMixin:
     @property
     def absCoef(self):
         st, n = self._ensure_swept()
-        return st.bufs["abs_coef"].download(n)
+        return st.bufs["abs_coef"].download(n, pinned=True)
 
     @property
     def transmittance(self):
         st, n = self._ensure_swept()
-        return st.bufs["trans"].download(n)
+        return st.bufs["trans"].download(n, pinned=True)
 
     def _optical(self, kind):
         st, n = self._ensure_swept()
         ctx = _ctx()
         out = st.buf(ctx, "tmp")
         ctx.optical_dev(st.bufs["trans"], n, kind, out)
-        return out.download(n)
+        return out.download(n, pinned=True)
 
     @property
     def emissivity(self):
@@ -470,7 +475,7 @@ class _OpticalMixin:
         src = st.buf(ctx, "I_in").upload(I_in)
         out = st.buf(ctx, "tmp")
         ctx.column_sweep_dev([st.bufs["trans"]], [layer.T], layer.rangeMin, layer.rangeMax, n, out, I_in=src)
-        return out.download(n)
+        return out.download(n, pinned=True)
 
 
 # ----------------------------------------------------------------------------------------
@@ -1055,12 +1060,12 @@ class Layer(_OpticalMixin, list):
         """pyradPlanck.planckWavenumber(self.xAxis, temperature) (cls:781-782, pl:38-44), on the device."""
         ctx = _ctx()
         n = int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION)
-        out = ctx.buffer(max(n, 1))
-        try:
-            ctx.planck_dev(self.rangeMin, self.rangeMax, n, float(temperature), out)
-            return out.download(n)
-        finally:
-            out.free()
+        st = self.__dict__.get("_planck_state")
+        if st is None:
+            st = self.__dict__["_planck_state"] = _SweepState(self)
+        out = st.reserve(ctx, n).buf(ctx, "planck")
+        ctx.planck_dev(self.rangeMin, self.rangeMax, n, float(temperature), out)
+        return out.download(n, pinned=True)
 
 
 # ----------------------------------------------------------------------------------------

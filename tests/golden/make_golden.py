@@ -623,9 +623,202 @@ def g8():
     save("G8_xsc", **arrays)
 
 
+# ----------------------------------------------------------------------------
+# G9: the data/ tree readers — ut:90-101 openReturnLines, ut:173-189 gatherData (segment loop),
+#     ut:421-448 readHitranOnlineFile, ut:451-461 readQFile, ut:464-477 readMolParams
+# ----------------------------------------------------------------------------
+def _reference_data_dir_functions(root):
+    """The reference's OWN cache-file readers, cut out of pyradUtilities.py with ``ast`` and executed
+    unmodified (the module cannot be imported: bs4, network at import).  The namespace supplies the
+    module globals they read; the download functions they would fall back to raise, so a test tree
+    that made the reference reach for the network fails loudly instead."""
+    import ast
+    path = os.path.join(REFERENCE, "pyradUtilities.py")
+    with open(path) as f:
+        tree = ast.parse(f.read(), path)
+    wanted = {"openReturnLines", "readHitranOnlineFile", "readQFile", "readMolParams", "gatherData", "getQData"}
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in wanted]
+    assert {n.name for n in body} == wanted
+
+    def no_network(*a, **k):
+        raise AssertionError("the reference reached for a download: %r" % (a,))
+    ns = {"os": os, "np": np, "cwd": root, "dataDir": root + "/data", "NULL_TAG": '#/null/#',
+          "logToFile": lambda *a, **k: None, "downloadHitran": no_network, "downloadQData": no_network}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def _pyr_row(mol_id, local_iso, nu, sw, a, elower, g_air, g_self, d_air, n_air):
+    # request_params order of ut:369-374: molec_id,local_iso_id,nu,sw,a,elower,gamma_air,gamma_self,delta_air,n_air
+    return "%d,%d,%.6f,%.3E,%.3E,%.4f,%.4f,%.3f,%.6f,%.2f\n" % (mol_id, local_iso, nu, sw, a, elower, g_air, g_self, d_air, n_air)
+
+
+def g9():
+    import json, shutil, tempfile
+    arrays = {}
+    root = tempfile.mkdtemp(prefix="pyrad_data_")
+    try:
+        rng = np.random.default_rng(900)
+        ns = _reference_data_dir_functions(root)
+        files = {}
+
+        def rows_for(lo, hi, n, mol_id, extra=()):
+            nu = np.round(np.sort(rng.uniform(lo, hi, n)), 6)
+            rows = [_pyr_row(mol_id, 1, v, 10.0 ** rng.uniform(-24, -19), rng.uniform(.01, 9), rng.uniform(0, 3000),
+                             rng.uniform(.05, .1), rng.uniform(.06, .12), rng.uniform(-.01, 0), rng.uniform(.5, .8)) for v in nu]
+            return rows + list(extra)
+
+        def row_at(nu, sw, mol_id=2):
+            return _pyr_row(mol_id, 1, nu, sw, 1.0, 100.0, .07, .09, -.002, .7)
+
+        # isotopologue 7 (CO2 626): three 100 cm^-1 segments around a 600-700 layer at 1 atm (595-705)
+        seg500 = rows_for(500.0, 600.0, 40, 2, [row_at(595.0, 1e-20), row_at(594.999999, 2e-20), row_at(595.000001, 3e-20),
+                                                  row_at(600.0, 4e-20)])          # nu == window edge; 600.0 also in the next file
+        seg600 = rows_for(600.0, 700.0, 160, 2, [row_at(600.0, 5e-20),              # duplicate nu ACROSS segments: last wins
+                                                  row_at(650.123456, 6e-20), row_at(650.123456, 7e-20),   # ... and WITHIN one
+                                                  row_at(700.0, 8e-20)])
+        rng.shuffle(seg600)                                                         # unsorted rows
+        seg700 = ["# a header line the cache writer might leave\n", "# and another\n"] + \
+            rows_for(700.0, 800.0, 30, 2, [row_at(700.0, 9e-20), row_at(705.0, 1e-21), row_at(704.999999, 1.1e-21)])
+        files["7/500.pyr"], files["7/600.pyr"], files["7/700.pyr"] = seg500, seg600, seg700
+        # isotopologue 1 (H2O 161): a NULL_TAG segment (HITRAN had no lines there, ut:96-98), a regular one
+        files["1/500.pyr"] = ["#/null/#\n"]
+        files["1/600.pyr"] = rows_for(600.0, 700.0, 90, 1)
+        files["1/700.pyr"] = rows_for(700.0, 800.0, 12, 1)
+        for iso, species in ((7, "co2"), (1, "h2o")):
+            q = synthetic.q_table(species, 400)
+            files["%d/q%d.txt" % (iso, iso)] = ["%d %s\n" % (T, repr(float(Q))) for T, Q in sorted(q.items())]
+            files["%d/params.pyr" % iso] = ["#\t#\t#\n", "# Molecule params for pyrad\n", "#\t#\t#\n",
+                                            ",".join(str(x) for x in synthetic.mol_params(species)) + "\n"]
+        tree = {}
+        for rel, rows in files.items():
+            full = os.path.join(root, "data", rel)
+            os.makedirs(os.path.dirname(full), exist_ok=True)
+            with open(full, "w") as f:
+                f.writelines(rows)
+            with open(full, "rb") as f:
+                tree[rel] = f.read()
+        arrays["tree_json"] = np.array(json.dumps(sorted(tree)))
+        for i, key in enumerate(sorted(tree)):
+            arrays["tree.%d" % i] = np.frombuffer(tree[key], dtype=np.uint8)
+
+        # -- the readers, query by query -------------------------------------------------------
+        queries = [(7, 595.0, 705.0), (7, 650.5, 660.25), (7, 599.0, 601.0), (7, 0.0, 1000.0),
+                   (1, 595.0, 705.0), (1, 510.0, 590.0), (1, 699.5, 700.5)]
+        fields = ("isotope", "intensity", "einsteinA", "airHalfWidth", "selfHalfWidth", "lowerEnergy",
+                  "tempExponent", "pressureShift")
+        kept = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for qi, (iso, lo, hi) in enumerate(queries):
+                if (iso, lo, hi) == (7, 0.0, 1000.0):
+                    # segments 0..400 and 800, 900 do not exist: the reference would download them
+                    try:
+                        ns["gatherData"](iso, lo, hi)
+                    except AssertionError:
+                        arrays["q%d.raises" % qi] = np.array("download")
+                    kept.append([iso, lo, hi])
+                    continue
+                got = ns["gatherData"](iso, lo, hi)
+                arrays["q%d.nu" % qi] = np.array(list(got.keys()), dtype=np.float64)       # insertion order (cls:352 iterates it)
+                for f in fields:
+                    arrays["q%d.%s" % (qi, f)] = np.array([got[k][f] for k in got], dtype=np.float64)
+                kept.append([iso, lo, hi])
+            arrays["queries_json"] = np.array(json.dumps(kept))
+            for iso in (7, 1):
+                qd = ns["readQFile"](iso)
+                arrays["qfile.%d.T" % iso] = np.array(list(qd.keys()), dtype=np.int64)
+                arrays["qfile.%d.Q" % iso] = np.array(list(qd.values()), dtype=np.float64)
+                arrays["params.%d_json" % iso] = np.array(json.dumps(ns["readMolParams"](iso)))
+
+        # -- a layer fed by the reference's own readers, through the reference's own classes ---
+        keep = (UT.gatherData, UT.getQData, UT.readMolParams)
+        UT.gatherData, UT.getQData, UT.readMolParams = ns["gatherData"], ns["getQData"], ns["readMolParams"]
+        try:
+            for tag, T, P, rmin, rmax in (("L1", 296, 1013.25, 600, 700), ("L2", 250, 500.0, 640, 660)):
+                _reset_reference_state()
+                UT.BASE_RESOLUTION = .01
+                with contextlib.redirect_stdout(io.StringIO()):
+                    layer = CLS.Layer(25.0, T, P, rmin, rmax, name=tag)
+                    layer.addMolecule("co2", ppm=400)
+                    layer.addMolecule("h2o", percentage=1.2)
+                    arrays["%s.abs_coef" % tag] = np.array(CLS.getAbsCoef(layer))
+                    arrays["%s.transmittance" % tag] = np.array(CLS.getTransmittance(layer))
+                    arrays["%s.transmission" % tag] = np.array(layer.transmission(layer.planck(288)))
+                    arrays["%s.co2.xsec" % tag] = np.array(CLS.getCrossSection(layer[0]))
+                    arrays["%s.h2o.xsec" % tag] = np.array(CLS.getCrossSection(layer[1]))
+                    arrays["%s.n_lines" % tag] = np.array([len(layer[0][0]), len(layer[1][0])], dtype=np.int64)
+                    arrays["%s.line_survey" % tag] = np.array(layer.lineSurvey)
+                arrays["%s.spec_json" % tag] = np.array(json.dumps(dict(depth=25.0, T=T, P=P, rmin=rmin, rmax=rmax)))
+            arrays["layer_cases_json"] = np.array(json.dumps(["L1", "L2"]))
+        finally:
+            UT.gatherData, UT.getQData, UT.readMolParams = keep
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    save("G9_data_dir", **arrays)
+
+
+# ----------------------------------------------------------------------------
+# G10: line survey — cls:409-428 createLineSurvey, cls:589-594 / 691-696 the molecule and layer sums
+# ----------------------------------------------------------------------------
+def g10():
+    import json
+    arrays = {}
+    cases = []
+
+    def survey_case(tag, cfg):
+        _reset_reference_state()
+        ref, layer = run_reference_layer(cfg)
+        with contextlib.redirect_stdout(io.StringIO()):
+            arrays["%s.layer" % tag] = np.array(layer.lineSurvey)
+            for mi, m in enumerate(layer):
+                arrays["%s.mol%d" % (tag, mi)] = np.array(m.lineSurvey)
+                for ii, iso in enumerate(m):
+                    arrays["%s.mol%d.iso%d" % (tag, mi, ii)] = np.array(iso.lineSurvey)
+        arrays["%s.resolution" % tag] = np.float64(ref["resolution"])
+        spec = dict(depth=cfg["depth"], T=cfg["T"], P=cfg["P"], range_min=cfg["range_min"], range_max=cfg["range_max"],
+                    molecules=[dict(species=m["species"], conc=m["conc"], isotope_depth=m.get("isotope_depth", 1)) for m in cfg["molecules"]])
+        arrays["%s.spec_json" % tag] = np.array(json.dumps(spec))
+        for mi, m in enumerate(cfg["molecules"]):
+            arrays.update(pack_lines("%s.mol%d.lines" % (tag, mi), m["lines"]))
+            if m.get("isotope_depth", 1) == 2:
+                arrays.update(pack_lines("%s.mol%d.lines2" % (tag, mi), m["lines2"]))
+        cases.append(tag)
+
+    # S1: the C1 cell (2000 lines on 10^4 bins: many bins hold several lines, summed in line order)
+    survey_case("S1", synthetic.config_c1(n_lines=2000))
+    # S2: edge lines of G2 (bins decided by truncation toward zero, lines outside the range dropped)
+    rmin, rmax = 600, 700
+    nus = np.array([rmin - 4.5, rmin - 0.015, rmin - 0.005, 600.07, 600.29, 600.3, 612.345678,
+                    650.0, 699.99, rmax - 0.001, 699.995, rmax + 0.004, rmax + 0.011, rmax + 4.9])
+    n = len(nus)
+    rng = np.random.default_rng(102)
+    lines = dict(nu=nus, sw=10.0 ** rng.uniform(-22, -19, n), a=np.ones(n), elower=rng.uniform(0, 3000, n),
+                 gamma_air=rng.uniform(.05, .1, n), gamma_self=rng.uniform(.06, .12, n), delta_air=rng.uniform(-.01, 0, n),
+                 n_air=rng.uniform(.5, .8, n))
+    survey_case("S2", dict(depth=10.0, T=296, P=1013.25, range_min=rmin, range_max=rmax, base_resolution=.01,
+                           dynamic_resolution=True, molecules=[dict(species="co2", conc=dict(ppm=400), lines=lines)]))
+    # S3: resolution != BASE (10132.5 mbar -> 0.1 cm^-1): the index uses the layer resolution while the array
+    # has the base length (cls:416 vs 423), so the survey crowds into the first tenth of the array
+    P = 10132.5
+    lo, hi = synthetic.layer_window(P, 640, 660)
+    survey_case("S3", dict(depth=100.0, T=260, P=P, range_min=640, range_max=660, base_resolution=.01,
+                           dynamic_resolution=True,
+                           molecules=[dict(species="co2", conc=dict(ppm=400), lines=synthetic.make_lines(305, 120, lo, hi))]))
+    # S4: two isotopologues and three molecules (the sums of cls:589-594 and 691-696)
+    lo, hi = synthetic.layer_window(800.0, 1000, 1040)
+    survey_case("S4", dict(depth=50.0, T=280, P=800.0, range_min=1000, range_max=1040, base_resolution=.01,
+                           dynamic_resolution=True,
+                           molecules=[dict(species="co2", conc=dict(ppm=400), isotope_depth=2,
+                                           lines=synthetic.make_lines(1061, 400, lo, hi), lines2=synthetic.make_lines(1062, 150, lo, hi)),
+                                      dict(species="h2o", conc={"%": 1.5}, lines=synthetic.make_lines(1063, 300, lo, hi)),
+                                      dict(species="ch4", conc=dict(ppb=1800), lines=synthetic.make_lines(1064, 200, lo, hi))]))
+    arrays["cases_json"] = np.array(json.dumps(cases))
+    save("G10_line_survey", **arrays)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REFERENCE):
         sys.exit("needs /root/reference (build container only)")
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for name in which:
         globals()[name]()

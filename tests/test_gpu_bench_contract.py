@@ -58,3 +58,18 @@ def test_forced_single_rank_communicator_pipeline():
     d2 = run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--workload", "C1", "--no-overlap"],
                    {"PYRAD_FORCE_COMM": "1"})
     assert d2["config"]["allgather"] == "in-stream" and d2["kernel_ms_per_step"]["allgather"] > 0
+
+
+def test_self_launch_on_a_one_gpu_box_fails_loudly():
+    """`python bench.py --gpus 2` with no launcher starts its own two ranks; on a box with one GPU
+    rank 1 has no device of its own and says so, the parent ends rank 0 and returns the failure -
+    no hang, no silent sharing of a GPU.  (A real 2-rank run needs a 2-GPU node.)"""
+    from pyrad_amd import _native as nat
+    if nat.device_count() != 1:
+        pytest.skip("needs exactly one visible GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "C1", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0
+    assert "one process per GPU" in p.stderr and "LOCAL_RANK 1" in p.stderr
+    assert not p.stdout.strip()
