@@ -298,6 +298,8 @@ def main():
                     help="experiment on ONE GPU: run only shard r of a G-way sharding of the workload (no communicator): "
                          "what rank r of G would compute per step")
     ap.add_argument("--unfused", action="store_true", help="accumulate launch + separate sweep launch (A/B)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="enqueue every step kernel by kernel instead of replaying the captured graph of the step")
     ap.add_argument("--lines", type=int, default=None, help="experiment: C2 with this many lines instead of 65,536")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api-path", action="store_true", help="skip the pyrad_amd.model (drop-in API) timing leg")
@@ -388,14 +390,19 @@ def main():
     # setup also builds the host-side schedule of every resident set (dispatch order + per-span line
     # ranges, cached by the library per line lists and grid): one priming pass each, outside the
     # timed region whatever --warmup is
+    step_kwargs = (dict(layer_arrays=bool(args.column_layer_arrays)) if args.workload == "C5"
+                   else dict(surface_T=288.0, fused=not args.unfused))
+
     def prime(L):
-        if args.workload == "C5":
-            L.enqueue(layer_arrays=bool(args.column_layer_arrays))
-        else:
-            L.enqueue(surface_T=288.0, fused=not args.unfused)
+        L.enqueue(**step_kwargs)
 
     for L in layers:
         prime(L)
+    ctx.sync()
+    # The step of every resident set captured once (same kernels, same arguments): a step is then ONE
+    # graph launch on the host side.  Steps whose kernels carry timing events are enqueued kernel by
+    # kernel (events cannot sit inside the graph); both routes run the same kernels.
+    graphs = [None] * len(layers) if args.no_graph else [L.capture_step(**step_kwargs) for L in layers]
     ctx.sync()
     # ... and brings the GPU to its sustained clocks: the first few hundred steps after an idle period
     # run up to 10 % slower (C2: 0.083 ms/step over the first 50 steps, 0.0755 after 800), which a
@@ -423,20 +430,22 @@ def main():
 
     step_no = [0]
 
-    def step():
+    def step(timed_kernels=False):
         k = step_no[0]
         step_no[0] += 1
         L = layers[k % n_sets]
         if comm is not None and n_sets > 1:
             comm.fence_dev(k % n_sets)          # the gather that last used this set (step k-2) is done
         slot = (k % n_sets) if n_sets > 1 else None
-        if is_column:
-            L.enqueue(layer_arrays=bool(args.column_layer_arrays))
-            if comm is not None:
-                L.enqueue_allgather(comm, overlap_slot=slot)
+        g = graphs[k % n_sets]
+        if g is not None and not timed_kernels:
+            g.launch()
         else:
-            L.enqueue(surface_T=288.0, fused=not args.unfused)
-            if comm is not None:
+            L.enqueue(**step_kwargs)
+        if comm is not None:
+            if is_column:
+                L.enqueue_allgather(comm, overlap_slot=slot)
+            else:
                 L.enqueue_allgather(comm, gather_bufs(L), overlap_slot=slot)
 
     for _ in range(args.warmup):
@@ -457,7 +466,7 @@ def main():
         if sampled or (k % every == 1):
             ctx.profile_enable(["xsec_accumulate"] if sampled else False)
         n_sampled += sampled
-        step()
+        step(timed_kernels=sampled)
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
@@ -466,7 +475,7 @@ def main():
     ctx.profile_reset()
     n_extra = max(2, min(5, args.steps))
     for _ in range(n_extra):
-        step()
+        step(timed_kernels=True)
     barrier()
     extra = ctx.profile_read()
     for name in ("line_prep", "regrid", "layer_sweep", "column_sweep", "allgather"):
@@ -478,12 +487,12 @@ def main():
     if args.variant in (None, 5):
         ctx.set_option("accum_variant", 3)
         for _ in range(2):
-            step()
+            step(timed_kernels=True)
         barrier()
         ctx.profile_enable(["xsec_accumulate"])
         ctx.profile_reset()
         for _ in range(n_extra):
-            step()
+            step(timed_kernels=True)
         barrier()
         n_d, ms_d = ctx.profile_read()["xsec_accumulate"]
         direct_ms = ms_d / n_extra
@@ -548,6 +557,9 @@ def main():
                        "window_W": int(g["W"]), "evals_per_step": evals_total, "parallelism": "grid-range x%d" % world,
                        "gathered": args.gather, "device": info["name"], "preconditioning_s": args.precondition_seconds,
                        "shard_bounds": (None if layer.plan is None else [list(b) for b in layer.plan.bounds]),
+                       "step_launch": ("kernel by kernel" if args.no_graph else
+                                       "one hipGraph per step (K1, K2, sweep captured once); kernel by kernel in the steps "
+                                       "that carry timing events"),
                        "allgather": ("none" if comm is None else "in-stream" if n_sets == 1 else
                                      "overlapped with the next step (2 buffer sets)")},
             "roofline": {"bound": "hbm", "kernel": "xsec_accumulate_lds_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -584,6 +596,9 @@ def main():
         rdzv.cleanup()
     if comm is not None:
         comm.free()
+    for g_ in graphs:
+        if g_ is not None:
+            g_.free()
     for L in layers:
         L.free()
     red.free()

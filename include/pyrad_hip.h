@@ -262,6 +262,24 @@ int lbl_band_integral(lbl_ctx* ctx, lbl_buffer* spectrum, int64_t n, double unit
  * into the bin of each line's centre index; out has n_base elements. */
 int lbl_line_survey_dev(lbl_ctx* ctx, lbl_lines* lines, const lbl_grid* grid, lbl_buffer* out);
 
+/* ---- graph capture ------------------------------------------------------------------ */
+/* A step that repeats (same line lists, grid, buffers) can be captured once and replayed as ONE
+ * hipGraph launch: the host then spends microseconds per step instead of rebuilding and checking the
+ * launch sequence, which is what bounds a small shard's step on 8 GPUs.
+ *   run the sequence once (allocates scratch, builds schedules, uploads descriptors);
+ *   lbl_capture_begin(ctx);  the same "_dev" calls again (nothing runs, kernels are recorded);
+ *   lbl_capture_end(ctx, &g);   then lbl_graph_launch(g) per step.
+ * Inside a capture only kernel launches are possible: a call that would allocate, upload or
+ * synchronise returns LBL_ERR_STATE (and the capture must still be ended).  The all-gather is not
+ * captured (lbl_allgather_* return LBL_ERR_STATE inside a capture): enqueue it after the graph.  A graph
+ * holds pointers into the context's scratch and caches; lbl_graph_launch returns LBL_ERR_STATE once
+ * one of them has changed (another batch grew a buffer or took a descriptor slot): capture again. */
+typedef struct lbl_graph lbl_graph;
+int lbl_capture_begin(lbl_ctx* ctx);
+int lbl_capture_end(lbl_ctx* ctx, lbl_graph** out);
+int lbl_graph_launch(lbl_graph* graph);
+int lbl_graph_destroy(lbl_graph* graph);
+
 /* ---- multi-GPU: one process per GPU, grid sharded by contiguous range --------------- */
 #define LBL_UNIQUE_ID_BYTES 128
 /* Rank 0 calls lbl_comm_unique_id and hands the 128 bytes to every rank out of band

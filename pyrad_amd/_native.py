@@ -102,6 +102,10 @@ SIGNATURES = {
     "lbl_allgather_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "lbl_allgather_overlap_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int]),
     "lbl_comm_fence_dev": (C.c_int, [_P, C.c_int]),
+    "lbl_capture_begin": (C.c_int, [_P]),
+    "lbl_capture_end": (C.c_int, [_P, C.POINTER(_P)]),
+    "lbl_graph_launch": (C.c_int, [_P]),
+    "lbl_graph_destroy": (C.c_int, [_P]),
     "lbl_gather_compact_dev": (C.c_int, [_P, _P, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P]),
 }
 
@@ -248,6 +252,24 @@ class Context:
             self.check(self.lib.lbl_profile_read(self.h, kind, C.byref(n), C.byref(ms)))
             out[name] = (n.value, ms.value)
         return out
+
+    # -- graph capture -------------------------------------------------------------------
+    def capture(self, enqueue_fn) -> "Graph":
+        """Capture what ``enqueue_fn()`` enqueues into a graph (run it once yourself first)."""
+        self.check(self.lib.lbl_capture_begin(self.h))
+        err = None
+        try:
+            enqueue_fn()
+        except Exception as e:                 # the capture has to be ended whatever happened inside
+            err = e
+        h = _P()
+        rc = self.lib.lbl_capture_end(self.h, C.byref(h))
+        if err is not None:
+            if rc == LBL_OK and h:
+                self.lib.lbl_graph_destroy(h)
+            raise err
+        self.check(rc)
+        return Graph(self, h)
 
     # -- page-locked host arrays ---------------------------------------------------------
     def host_array(self, n: int) -> np.ndarray:
@@ -461,6 +483,24 @@ class Buffer:
                 self.free()
         except Exception:
             pass
+
+
+class Graph:
+    """A captured launch sequence (lbl_graph)."""
+
+    def __init__(self, ctx: Context, h):
+        self.ctx, self.h = ctx, h
+        ctx._children.insert(0, self)
+
+    def launch(self):
+        self.ctx.check(self.ctx.lib.lbl_graph_launch(self.h))
+
+    def free(self):
+        if self.h:
+            self.ctx.check(self.ctx.lib.lbl_graph_destroy(self.h))
+            self.h = None
+            if self in self.ctx._children:
+                self.ctx._children.remove(self)
 
 
 class Lines:

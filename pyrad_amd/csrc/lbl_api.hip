@@ -39,7 +39,6 @@ struct lbl_ctx {
     DeviceArena cidx;       // int32 per line
     DeviceArena work;       // work grids that need a regrid
     DeviceArena jobs;       // PrepJob[] + AccumJob[] + regime counters (3 x u64 per job)
-    DeviceArena colargs;    // ColumnArgs of the column sweep
     DeviceArena counts;     // per-block regime counts of the last batch
     DeviceArena bal;        // balanced variant: span table, counts, prefix, slab
     DeviceArena red;        // band-integral partials + result
@@ -70,6 +69,16 @@ struct lbl_ctx {
     int lpt = 3;             // longest-first worklist: 3 (default) bin-packed per CU when the launch is one round; 2 snake; 1 plain; 0 positional
     int tile_order = 1;      // 1: natural order (default; measured 8 % faster on the clustered C2 grid:
                              // all CUs work through one region together); 0: each XCD gets a contiguous run
+    // Graph capture (lbl_capture_begin / lbl_capture_end): while `capturing`, entry points only enqueue
+    // kernels; anything that would allocate, copy or synchronise fails with LBL_ERR_STATE ("run the
+    // sequence once before capturing it").  `epoch` counts every event that can invalidate a pointer a
+    // captured kernel node holds (arena growth, a descriptor / argument slot being rewritten, a schedule
+    // being evicted); a graph remembers the epoch it was captured at and refuses to launch after a change.
+    bool capturing = false;
+    uint64_t epoch = 0;
+    struct ArgSlot { std::vector<char> bytes; void* dptr = nullptr; size_t cap = 0; uint64_t used = 0; };
+    std::vector<ArgSlot> arg_cache;      // device copies of kernel argument blocks, found again by content
+    uint64_t arg_clock = 0;
     bool no_fuse = false;    // lbl_layer_step_dev as accumulate + separate sweep launch (A/B, parity tests)
     int live_objects = 0;
     // event timing (lbl_profile_*)
@@ -127,8 +136,15 @@ static int fail(lbl_ctx* ctx, int code, const char* fmt, ...) noexcept {
                         hipGetErrorString(e_), __FILE__, __LINE__);                                \
     } while (0)
 
+static int capture_refuses(lbl_ctx* ctx, const char* what) {
+    return fail(ctx, LBL_ERR_STATE, "graph capture: %s is not possible while capturing - run the same sequence once "
+                                    "before lbl_capture_begin so that buffers, schedules and descriptors exist", what);
+}
+
 static int arena_reserve(lbl_ctx* ctx, DeviceArena& a, size_t bytes) {
     if (bytes <= a.cap) return LBL_OK;
+    if (ctx->capturing) return capture_refuses(ctx, "growing a scratch buffer");
+    ctx->epoch++;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (a.ptr) HIP_TRY(ctx, hipFree(a.ptr));
     a.ptr = nullptr; a.cap = 0;
@@ -146,7 +162,7 @@ static hipEvent_t prof_event(lbl_ctx* ctx) {
     return e;
 }
 static hipEvent_t prof_begin(lbl_ctx* ctx, int kind) {
-    if (!((ctx->profiling >> kind) & 1u)) return nullptr;
+    if (ctx->capturing || !((ctx->profiling >> kind) & 1u)) return nullptr;
     hipEvent_t e = prof_event(ctx);
     if (e) (void)hipEventRecord(e, ctx->stream);
     return e;
@@ -164,6 +180,7 @@ static void prof_end(lbl_ctx* ctx, int kind, hipEvent_t start) {
 // rewritten while an earlier copy from it may still be pending.
 static int stage_alloc(lbl_ctx* ctx, size_t bytes, void** out) {
     bytes = (bytes + 255) & ~(size_t)255;
+    if (ctx->capturing) return capture_refuses(ctx, "staging a host-to-device copy");
     if (bytes > ctx->host_stage_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->host_stage) HIP_TRY(ctx, hipHostFree(ctx->host_stage));
@@ -178,6 +195,44 @@ static int stage_alloc(lbl_ctx* ctx, size_t bytes, void** out) {
     }
     *out = (char*)ctx->host_stage + ctx->host_stage_head;
     ctx->host_stage_head += bytes;
+    return LBL_OK;
+}
+
+// Device copy of a kernel argument block (column sweeps): found again by content, so a step that
+// repeats uploads nothing - which is also what lets it be captured into a graph.
+static int device_args(lbl_ctx* ctx, const void* host, size_t bytes, void** dptr) {
+    const char* hb = (const char*)host;
+    for (auto& e : ctx->arg_cache)
+        if (e.dptr && e.bytes.size() == bytes && !memcmp(e.bytes.data(), hb, bytes)) {
+            e.used = ++ctx->arg_clock;
+            *dptr = e.dptr;
+            return LBL_OK;
+        }
+    if (ctx->capturing) return capture_refuses(ctx, "uploading kernel arguments");
+    lbl_ctx::ArgSlot* slot = nullptr;
+    if (ctx->arg_cache.size() < 8) {
+        ctx->arg_cache.emplace_back();
+        slot = &ctx->arg_cache.back();
+    } else {
+        slot = &ctx->arg_cache[0];
+        for (auto& e : ctx->arg_cache) if (e.used < slot->used) slot = &e;     // least recently used
+        ctx->epoch++;                                                           // a captured graph may point at it
+    }
+    if (slot->cap < bytes) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (slot->dptr) HIP_TRY(ctx, hipFree(slot->dptr));
+        slot->dptr = nullptr; slot->cap = 0; slot->bytes.clear();
+        HIP_TRY(ctx, hipMalloc(&slot->dptr, bytes + 256));
+        slot->cap = bytes + 256;
+    }
+    void* pinned = nullptr;
+    int rc = stage_alloc(ctx, bytes, &pinned);
+    if (rc) return rc;
+    memcpy(pinned, host, bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(slot->dptr, pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    slot->bytes.assign(hb, hb + bytes);
+    slot->used = ++ctx->arg_clock;
+    *dptr = slot->dptr;
     return LBL_OK;
 }
 
@@ -247,7 +302,8 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) try {
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto& sc : ctx->schedules) { if (sc.d_list) (void)hipFree(sc.d_list); if (sc.d_tabs) (void)hipFree(sc.d_tabs); }
     for (auto& e : ctx->desc_cache) if (e.dptr) (void)hipFree(e.dptr);
-    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->colargs, &ctx->counts, &ctx->bal, &ctx->red};
+    for (auto& e : ctx->arg_cache) if (e.dptr) (void)hipFree(e.dptr);
+    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->bal, &ctx->red};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     (void)hipStreamDestroy(ctx->stream);
@@ -616,6 +672,7 @@ static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const 
             std::rotate(ctx->schedules.begin() + i, ctx->schedules.begin() + i + 1, ctx->schedules.end());
             return &ctx->schedules.back();
         }
+    if (ctx->capturing) { (void)capture_refuses(ctx, "building a dispatch schedule"); return nullptr; }
     struct Item { int count, job, tile; };
     std::vector<Item> items;
     std::vector<long long> idx;
@@ -707,6 +764,7 @@ static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const 
         return nullptr;
     }
     if (ctx->schedules.size() >= 16) {                    // small cache: drop the oldest entry
+        ctx->epoch++;
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(ctx->schedules.front().d_list);
         (void)hipFree(ctx->schedules.front().d_tabs);
@@ -805,7 +863,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             std::vector<int> members(order.begin() + k, order.begin() + e);
             const lbl_ctx::Schedule* sc = group_schedule(ctx, g.variant, members, lines, grid, g.R, g.LS,
                                                          accumulate_tile_points(g.R, g.LS, g.variant));
-            if (!sc) return fail(ctx, LBL_ERR_OOM, "schedule allocation failed");
+            if (!sc) return ctx->capturing ? LBL_ERR_STATE : fail(ctx, LBL_ERR_OOM, "schedule allocation failed");
             g.worklist = sc->d_list; g.total_tiles = sc->total; g.tabs = sc->d_tabs; g.tab_off = sc->tab_off;
         }
         groups.push_back(g);
@@ -890,6 +948,8 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     for (auto& e : ctx->desc_cache)
         if (e.dptr && e.bytes == ctx->desc_build) { d_desc = (char*)e.dptr; break; }
     if (!d_desc) {
+        if (ctx->capturing) return capture_refuses(ctx, "uploading job descriptors");
+        ctx->epoch++;                                      // the slot's old contents may be what a captured graph reads
         auto& e = ctx->desc_cache[ctx->desc_next];
         ctx->desc_next = (ctx->desc_next + 1) % 4;
         if (e.cap < ctx->desc_build.size()) {
@@ -1173,11 +1233,8 @@ extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* cons
     if ((rc = check_buf(ctx, I_out, n, "I_out", true))) return rc;
     if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
     if (!I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "need I_in or surface_T > 0");
-    void* stage = nullptr;
-    if ((rc = stage_alloc(ctx, sizeof(ColumnArgs), &stage))) return rc;
-    if ((rc = arena_reserve(ctx, ctx->colargs, sizeof(ColumnArgs)))) return rc;
-    ColumnArgs* a = (ColumnArgs*)stage;
-    memset(a, 0, sizeof *a);
+    std::vector<char> blk(sizeof(ColumnArgs), 0);
+    ColumnArgs* a = (ColumnArgs*)blk.data();
     for (int l = 0; l < n_layers; ++l) {
         if ((rc = check_buf(ctx, trans[l], n, "trans", true))) return rc;
         if (!(layer_T[l] > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "layer_T must be > 0");
@@ -1192,9 +1249,10 @@ extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* cons
     a->I_out = I_out->d;
     a->n = n; a->first = first; a->count = count;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->colargs.ptr, a, sizeof(ColumnArgs), hipMemcpyHostToDevice, ctx->stream));
+    void* d_args = nullptr;
+    if ((rc = device_args(ctx, a, sizeof(ColumnArgs), &d_args))) return rc;
     hipEvent_t ev = prof_begin(ctx, PROF_COLUMN);
-    launch_column_sweep((const ColumnArgs*)ctx->colargs.ptr, count, ctx->stream);
+    launch_column_sweep((const ColumnArgs*)d_args, count, ctx->stream);
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
@@ -1215,11 +1273,8 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
     if ((rc = check_buf(ctx, I_out, n, "I_out", true))) return rc;
     if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
     if (!I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "need I_in or surface_T > 0");
-    void* stage = nullptr;
-    if ((rc = stage_alloc(ctx, sizeof(ColumnStepArgs), &stage))) return rc;
-    if ((rc = arena_reserve(ctx, ctx->colargs, sizeof(ColumnStepArgs)))) return rc;
-    ColumnStepArgs* a = (ColumnStepArgs*)stage;
-    memset(a, 0, sizeof *a);
+    std::vector<char> blk(sizeof(ColumnStepArgs), 0);
+    ColumnStepArgs* a = (ColumnStepArgs*)blk.data();
     int iso0 = 0, mol0 = 0;
     for (int l = 0; l < n_layers; ++l) {
         if (n_iso[l] < 0 || n_mol[l] < 0 || iso0 + n_iso[l] > kMaxColumnIso || mol0 + n_mol[l] > kMaxColumnIso)
@@ -1250,9 +1305,10 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
     a->I_out = I_out->d;
     a->n = n; a->first = first; a->count = count;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->colargs.ptr, a, sizeof(ColumnStepArgs), hipMemcpyHostToDevice, ctx->stream));
+    void* d_args = nullptr;
+    if ((rc = device_args(ctx, a, sizeof(ColumnStepArgs), &d_args))) return rc;
     hipEvent_t ev = prof_begin(ctx, PROF_COLUMN);
-    launch_column_step((const ColumnStepArgs*)ctx->colargs.ptr, count, ctx->stream, (first & 1) == 0);
+    launch_column_step((const ColumnStepArgs*)d_args, count, ctx->stream, (first & 1) == 0);
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
@@ -1363,8 +1419,68 @@ extern "C" int lbl_gather_compact_dev(lbl_ctx* ctx, lbl_buffer* gathered, int wo
     return LBL_OK;
 } LBL_GUARD_END(ctx)
 
+// ----------------------------------------------------------------------------------------
+// graph capture of a launch sequence
+// ----------------------------------------------------------------------------------------
+struct lbl_graph {
+    lbl_ctx* ctx;
+    hipGraphExec_t exec;
+    uint64_t epoch;
+};
+
+extern "C" int lbl_capture_begin(lbl_ctx* ctx) try {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (ctx->capturing) return fail(ctx, LBL_ERR_STATE, "already capturing");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return LBL_OK;
+} LBL_GUARD_END(ctx)
+
+extern "C" int lbl_capture_end(lbl_ctx* ctx, lbl_graph** out) try {
+    if (!ctx || !out) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    *out = nullptr;
+    if (!ctx->capturing) return fail(ctx, LBL_ERR_STATE, "not capturing");
+    ctx->capturing = false;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (e != hipSuccess || !graph)
+        return fail(ctx, LBL_ERR_HIP, "hipStreamEndCapture: %s (a call inside the capture was not capturable)", hipGetErrorString(e));
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(ctx, LBL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    lbl_graph* g = new (std::nothrow) lbl_graph{ctx, exec, ctx->epoch};
+    if (!g) { (void)hipGraphExecDestroy(exec); return fail(ctx, LBL_ERR_OOM, "host allocation failed"); }
+    ctx->live_objects++;
+    *out = g;
+    return LBL_OK;
+} LBL_GUARD_END(ctx)
+
+extern "C" int lbl_graph_launch(lbl_graph* graph) try {
+    if (!graph) return fail(nullptr, LBL_ERR_BAD_ARG, "graph is NULL");
+    lbl_ctx* ctx = graph->ctx;
+    if (ctx->capturing) return fail(ctx, LBL_ERR_STATE, "cannot launch a graph while capturing");
+    if (graph->epoch != ctx->epoch)
+        return fail(ctx, LBL_ERR_STATE, "graph is stale: a scratch buffer, schedule or descriptor it points at has changed since "
+                                        "it was captured - capture it again");
+    HIP_TRY(ctx, hipGraphLaunch(graph->exec, ctx->stream));
+    return LBL_OK;
+} LBL_GUARD_END(graph ? graph->ctx : nullptr)
+
+extern "C" int lbl_graph_destroy(lbl_graph* graph) try {
+    if (!graph) return LBL_OK;
+    lbl_ctx* ctx = graph->ctx;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGraphExecDestroy(graph->exec));
+    ctx->live_objects--;
+    delete graph;
+    return LBL_OK;
+} LBL_GUARD_END(graph ? graph->ctx : nullptr)
+
 // hooks for lbl_comm.hip (kept out of the public header)
 namespace lbl {
 int comm_fail(lbl_ctx* ctx, int code, const char* msg) { return fail(ctx, code, "%s", msg); }
 int ctx_device(lbl_ctx* ctx) { return ctx->device; }
+bool ctx_capturing(lbl_ctx* ctx) { return ctx->capturing; }
 }  // namespace lbl

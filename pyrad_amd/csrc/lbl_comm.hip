@@ -20,6 +20,7 @@ extern "C" int lbl_comm_fence_dev(lbl_comm* comm, int slot);
 namespace lbl {
 int comm_fail(lbl_ctx* ctx, int code, const char* msg);
 int ctx_device(lbl_ctx* ctx);
+bool ctx_capturing(lbl_ctx* ctx);
 void* comm_prof_begin(lbl_ctx* ctx);
 void comm_prof_end(lbl_ctx* ctx, void* start);
 }
@@ -105,6 +106,8 @@ static int allgather_impl(lbl_comm* comm, lbl_buffer* send, int64_t send_offset,
     if (!comm || !send || !recv) return lbl::comm_fail(comm ? comm->ctx : nullptr, LBL_ERR_BAD_ARG, "NULL argument");
     lbl_ctx* ctx = comm->ctx;
     if (slot < 0 || slot > 3) return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "slot must be 0..3");
+    if (lbl::ctx_capturing(ctx))
+        return lbl::comm_fail(ctx, LBL_ERR_STATE, "the all-gather stays outside a captured graph: end the capture first");
     int64_t ns = 0, nr = 0;
     lbl_buffer_size(send, &ns);
     lbl_buffer_size(recv, &nr);

@@ -243,6 +243,15 @@ class ResidentLayer:
         self.enqueue_xsec()
         self.enqueue_sweep(I_in=I_in, surface_T=surface_T)
 
+    def capture_step(self, **enqueue_kwargs) -> nat.Graph:
+        """Capture this layer's step (``enqueue(**enqueue_kwargs)``) into a graph: run once so that scratch,
+        schedule and descriptors exist, then record.  ``graph.launch()`` replays line prep, accumulate
+        and sweep with one host call."""
+        if self.empty:
+            return None
+        self.enqueue(**enqueue_kwargs)
+        return self.ctx.capture(lambda: self.enqueue(**enqueue_kwargs))
+
     def enqueue_allgather(self, comm: nat.Comm, buffers=None, overlap_slot=None):
         """The single RCCL all-gather of the path.  Equal shards: in place on the padded buffers.
         Cost-balanced (unequal) shards: every rank sends S doubles from its own first point into a
@@ -336,6 +345,13 @@ class ResidentColumn:
         self.ctx.column_sweep_dev([L.trans for L in self.layers], [L.T for L in self.layers],
                                   self.layers[0].range_min, self.layers[0].range_max, self.n, self.I_toa,
                                   surface_T=self.surface_T, first=first, count=count)
+
+    def capture_step(self, **enqueue_kwargs) -> nat.Graph:
+        """The column step (all layers' line prep + accumulate launches + the column fold) as one graph."""
+        if self.empty:
+            return None
+        self.enqueue(**enqueue_kwargs)
+        return self.ctx.capture(lambda: self.enqueue(**enqueue_kwargs))
 
     def enqueue_allgather(self, comm: nat.Comm, overlap_slot=None):
         if self.plan is None or self.plan.in_place:

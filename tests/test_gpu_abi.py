@@ -63,3 +63,65 @@ def test_gather_compact(ctx):
     with pytest.raises(nat.LblError):                     # output too short
         ctx.gather_compact_dev(g, S, bounds, ctx.buffer(n - 1))
     g.free(); out.free()
+
+
+def test_graph_capture_replays_the_step_bit_for_bit(ctx):
+    """lbl_capture_begin / _end / lbl_graph_launch: a layer step (three line lists: line prep, accumulate,
+    sweep) and a column step replayed from their graphs give the arrays of the kernel-by-kernel route;
+    an unprimed sequence cannot be captured (and the context survives); a graph whose descriptor slot
+    was taken by other batches refuses to launch."""
+    from pyrad_amd import _native as nat, engine
+    g = engine.layer_grid(1013.25, 640, 660, .001, False)
+    mols = []
+    for s_, seed, conc in (("co2", 61, 4e-4), ("h2o", 62, 1e-2), ("ch4", 63, 1.8e-6)):
+        sp = synthetic.SPECIES[s_]
+        mols.append(dict(conc=conc, isotopologues=[dict(lines=synthetic.make_lines(seed, 700, g["eff_min"], g["eff_max"]),
+                                                        molmass=sp["molmass"], q_T=synthetic.q_value(s_, 270), q296=sp["q296"])]))
+    L = engine.ResidentLayer(ctx, 10.0, 270, 1013.25, 640, 660, mols, .001, False)
+    with pytest.raises(nat.LblError) as e:                # nothing has run yet: scratch, schedule, descriptors are missing
+        ctx.capture(lambda: L.enqueue(surface_T=288.0))
+    assert e.value.code == -6 and "capture" in str(e.value)
+    L.enqueue(surface_T=288.0)                            # the context is still usable
+    ref = L.results()
+    graph = L.capture_step(surface_T=288.0)
+    for b in (L.abs_coef, L.trans, L.I_out):
+        b.fill(0.0)
+    graph.launch()
+    got = L.results()
+    assert all(np.array_equal(got[k], ref[k]) for k in ref) and np.all(ref["abs_coef"] > 0)
+    graph.launch(); graph.launch()
+    assert all(np.array_equal(L.results()[k], ref[k]) for k in ref)
+    # a single-line-list layer (sweep fused into the accumulate kernel) and a column
+    one = engine.ResidentLayer(ctx, 10.0, 270, 1013.25, 640, 660, mols[:1], .001, False)
+    one.enqueue(surface_T=288.0)
+    ref1 = one.results()
+    g1 = one.capture_step(surface_T=288.0)
+    one.I_out.fill(0.0)
+    g1.launch()
+    assert np.array_equal(one.results()["transmission"], ref1["transmission"])
+    cfgs = [dict(depth=1e4, T=T, P=P, range_min=640, range_max=660, base_resolution=.001, dynamic_resolution=False, molecules=mols)
+            for T, P in ((285, 1013.25), (250, 300.0), (220, 30.0))]
+    col = engine.ResidentColumn(ctx, cfgs, 288.0)
+    col.enqueue(layer_arrays=False)
+    toa = col.results()["toa"]
+    gc = col.capture_step(layer_arrays=False)
+    col.I_toa.fill(0.0)
+    gc.launch()
+    assert np.array_equal(col.results()["toa"], toa)
+    # five other batches take the four descriptor slots: the graphs of the first layer are stale now
+    others = []
+    for k in range(5):
+        o = engine.ResidentLayer(ctx, 10.0, 260 + k, 1013.25, 640, 660, mols[:2], .001, False)
+        o.enqueue(surface_T=288.0)
+        others.append(o)
+    with pytest.raises(nat.LblError) as e:
+        graph.launch()
+    assert e.value.code == -6 and "stale" in str(e.value)
+    L.enqueue(surface_T=288.0)                            # the kernel-by-kernel route still works, and a new capture too
+    g2 = L.capture_step(surface_T=288.0)
+    g2.launch()
+    assert all(np.array_equal(L.results()[k], ref[k]) for k in ref)
+    for x in (graph, g1, gc, g2):
+        x.free()
+    for o in others + [L, one, col]:
+        o.free()
