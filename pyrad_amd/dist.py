@@ -144,11 +144,16 @@ SPAN = 256          # grid points a wavefront owns at R = 4 (cost model granular
 ALIGN = 1024        # shard boundaries are multiples of one workgroup's points (4 spans)
 
 
-def span_costs(centre_index, H: int, n: int) -> np.ndarray:
+def span_costs(centre_index, H: int, n: int, has_gaussian=None) -> np.ndarray:
     """Estimated K2 wave-instructions per span of 256 grid points for one line list, the host
-    model of lbl_api.hip's group_schedule: near lines (within 4 half-spans of the span, evaluated
-    point by point, ~60 % with a Gaussian pass) 5R + 29, lines reached through the far-field
-    series ~1.6, a fixed part per span.  ``centre_index`` = sorted int centre indices (cls:390)."""
+    model of lbl_api.hip's group_schedule: near lines (within 4 half-spans of the span) are
+    evaluated point by point, 5R instructions, plus a Gaussian pass of ~48 on the spans their
+    Gaussian part reaches (~0.6 of the near spans) when the line has one (pseudo-Voigt or Gaussian
+    regime); lines reached through the far-field series ~1.6; a fixed part per span.
+    ``centre_index`` = sorted int centre indices (cls:390); ``has_gaussian`` = per-line bool in the
+    same order (None: every line is taken to have a Gaussian part).  The regime matters for the
+    balance: below ~630 cm^-1 at 1 atm CO2 lines are pure Lorentz (cls:382) and cost 40 % of a
+    pseudo-Voigt line."""
     c = np.asarray(centre_index, dtype=np.int64)
     n_spans = -(-int(n) // SPAN)
     lo = np.arange(n_spans, dtype=np.int64) * SPAN
@@ -156,14 +161,41 @@ def span_costs(centre_index, H: int, n: int) -> np.ndarray:
     H = int(H)
     reach = np.searchsorted(c, hi + H, "right") - np.searchsorted(c, lo - H, "left")
     near_half = min(H, 4 * (SPAN // 2))
-    near = np.searchsorted(c, hi + near_half, "right") - np.searchsorted(c, lo - near_half, "left")
-    near = np.minimum(near, reach)
-    return near * (5.0 * 4 + 29.0) + (reach - near) * 1.6 + 600.0
+    a = np.searchsorted(c, lo - near_half, "left")
+    b = np.searchsorted(c, hi + near_half, "right")
+    near = np.minimum(b - a, reach)
+    if has_gaussian is None:
+        gauss = near
+    else:
+        pre = np.concatenate([[0], np.cumsum(np.asarray(has_gaussian, dtype=np.int64))])
+        gauss = np.minimum(pre[b] - pre[a], near)
+    return near * (5.0 * 4) + gauss * 29.0 + (reach - near) * 1.6 + 600.0
 
 
-def balanced_plan(n: int, world_size: int, rank: int, cost_per_span: np.ndarray) -> ShardPlan:
+def gaussian_part(lines: dict, T, P, conc, molmass) -> np.ndarray:
+    """Which lines carry a Gaussian term (regime select of cls:378-387: not 'Lorentz only'), from the
+    reference's own half-width expressions (cls:252-263) - a host estimate for the shard cost model
+    only; the device decides the regime itself in K1."""
+    nu = np.asarray(lines["nu"], dtype=np.float64)
+    broadened = nu + np.asarray(lines["delta_air"]) * P / 1013.25
+    lhw = ((1 - conc) * np.asarray(lines["gamma_air"]) + conc * np.asarray(lines["gamma_self"])) * (P / 1013.25) * \
+        (296.0 / T) ** np.asarray(lines["n_air"])
+    m = molmass / 1000.0 / 6.022140857E23
+    ghw = broadened * np.sqrt(2 * 1.38064852E-23 * T / m / 299792458.0 ** 2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return ~(lhw / ghw > 100.0)
+
+
+MAX_SHARD_RATIO = 1.125      # a shard is at most this much longer than n / world_size
+
+
+def balanced_plan(n: int, world_size: int, rank: int, cost_per_span: np.ndarray,
+                  max_ratio: float = MAX_SHARD_RATIO) -> ShardPlan:
     """Contiguous shards with (nearly) equal summed cost; boundaries at multiples of ALIGN grid
-    points.  ``cost_per_span``: summed over every job (isotopologue x layer) that runs on the grid."""
+    points.  ``cost_per_span``: summed over every job (isotopologue x layer) that runs on the grid.
+    Every rank sends as many doubles as the LONGEST shard holds (the all-gather's slot), so a shard
+    may not grow beyond ``max_ratio`` x the equal share: the cost balance is traded against gathered
+    bytes (at 8 ranks the all-gather of a 2.4e6-point spectrum takes about as long as the step)."""
     n = int(n)
     per_block = ALIGN // SPAN
     cost = np.asarray(cost_per_span, dtype=np.float64)
@@ -171,14 +203,18 @@ def balanced_plan(n: int, world_size: int, rank: int, cost_per_span: np.ndarray)
     pad = n_blocks * per_block - cost.size
     block = np.concatenate([cost, np.zeros(max(pad, 0))])[:n_blocks * per_block].reshape(n_blocks, per_block).sum(axis=1)
     prefix = np.concatenate([[0.0], np.cumsum(block)])
-    total = prefix[-1]
+    cap = max(int(np.ceil(max_ratio * n_blocks / world_size)), 1)
     cuts = [0]
     for r in range(1, world_size):
-        target = total * r / world_size
+        # an equal share of what is left for the ranks that are left (a capped shard hands its surplus
+        # to all later shards, not to its neighbour alone)
+        target = prefix[cuts[-1]] + (prefix[-1] - prefix[cuts[-1]]) / (world_size - r + 1)
         b = int(np.searchsorted(prefix, target, "left"))
         # the boundary nearer to the target of the two that bracket it
         if b > 0 and abs(prefix[b - 1] - target) <= abs(prefix[min(b, n_blocks)] - target):
             b -= 1
+        b = min(b, cuts[-1] + cap)                                   # this shard is at most cap blocks long ...
+        b = max(b, n_blocks - (world_size - r) * cap)                # ... and so can every shard after it be
         cuts.append(min(max(b, cuts[-1]), n_blocks))
     cuts.append(n_blocks)
     bounds = []

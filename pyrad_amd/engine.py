@@ -111,7 +111,7 @@ def balanced_shards(layer_cfgs, world: int, rank: int):
     P, range_min, range_max, base_resolution, dynamic_resolution and molecules (each with
     isotopologues = [dict(lines=...)]); all layers must share one work grid.  The cost of a span is
     the host model of K2 summed over every line list of every layer (dist.span_costs)."""
-    from .dist import span_costs, balanced_plan
+    from .dist import span_costs, balanced_plan, gaussian_part
     cost, n_work = None, None
     for c in layer_cfgs:
         g = layer_grid(c["P"], c["range_min"], c["range_max"], c.get("base_resolution"), c.get("dynamic_resolution", True))
@@ -123,8 +123,11 @@ def balanced_shards(layer_cfgs, world: int, rank: int):
         for mol in c["molecules"]:
             for iso in mol["isotopologues"]:
                 lines = select_window(iso["lines"], g["eff_min"], g["eff_max"])
-                idx = np.sort(((np.asarray(lines["nu"], dtype=np.float64) - g["range_min"]) / g["resolution"]).astype(np.int64))
-                sc = span_costs(idx, H, n_work)
+                nu = np.asarray(lines["nu"], dtype=np.float64)
+                order = np.argsort(nu, kind="stable")
+                idx = ((nu[order] - g["range_min"]) / g["resolution"]).astype(np.int64)
+                has_g = gaussian_part(lines, c["T"], c["P"], mol["conc"], iso["molmass"])[order]
+                sc = span_costs(idx, H, n_work, has_g)
                 cost = sc if cost is None else cost + sc
     if cost is None:
         return equal_plan(n_work or 0, world, rank)

@@ -70,7 +70,7 @@ def test_shard_plans_tile_the_grid():
     for world in (2, 3, 4, 8):
         eq = dist.equal_plan(2_400_000, world, 0)
         assert eq.in_place and sum(k for _, k in eq.bounds) == 2_400_000
-        bal = [dist.balanced_plan(2_400_000, world, r, cost) for r in range(world)]
+        bal = [dist.balanced_plan(2_400_000, world, r, cost, max_ratio=8.0) for r in range(world)]
         assert all(b.bounds == bal[0].bounds for b in bal)        # every rank derives the same plan
         b = bal[0]
         assert b.bounds[0][0] == 0 and sum(k for _, k in b.bounds) == 2_400_000
@@ -86,6 +86,10 @@ def test_shard_plans_tile_the_grid():
         for r, (f, k) in enumerate(b.bounds):
             gathered[r * b.S:r * b.S + k] = spec[f:f + k]
         assert np.array_equal(b.assemble(gathered), spec)
-    # more ranks than aligned blocks: trailing shards are empty, nothing is lost
+    # the default cap on a shard's length (every rank sends the longest shard's size into the all-gather)
+    capped = dist.balanced_plan(2_400_000, 8, 0, cost)
+    assert sum(k for _, k in capped.bounds) == 2_400_000
+    assert capped.S <= dist.MAX_SHARD_RATIO * 300_000 + dist.ALIGN
+    # more ranks than aligned blocks: some shards are empty, nothing is lost
     tiny = dist.balanced_plan(3000, 8, 7, dist.span_costs(np.array([10, 20, 2999]), 48, 3000))
-    assert sum(k for _, k in tiny.bounds) == 3000 and tiny.count == 0
+    assert sum(k for _, k in tiny.bounds) == 3000 and sum(1 for _, k in tiny.bounds if k == 0) == 5
