@@ -1,17 +1,17 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box:
-#   gpurun -- 'bash profiles/collect.sh r01'
+#   gpurun -- 'bash profiles/collect.sh r02 C3'     (workloads: C1 C2 C3 C5)
 # writes gpurun_out/<tag>/..., which profiles/summarize.py turns into the committed summaries.
 # Counters are collected in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass,
 # MI355X_MICROARCH.md "rocprofv3 PMC slots") and never together with the trace domains.
 set -e
-TAG=${1:-r01}
-WORKLOAD=${2:-C2}
+TAG=${1:-r02}
+WORKLOAD=${2:-C3}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="$R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload $WORKLOAD"
+CMD="$R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-api-path --workload $WORKLOAD"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$WORKLOAD -- python3 $CMD > $OUT/trace_$WORKLOAD.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$WORKLOAD -- python3 $CMD > $OUT/pmc_fetch_$WORKLOAD.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$WORKLOAD -- python3 $CMD > $OUT/pmc_write_$WORKLOAD.log 2>&1
