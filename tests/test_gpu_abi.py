@@ -125,3 +125,30 @@ def test_graph_capture_replays_the_step_bit_for_bit(ctx):
         x.free()
     for o in others + [L, one, col]:
         o.free()
+
+
+def test_empty_shard_does_nothing_and_counts_nothing(ctx):
+    """More ranks than aligned blocks: a rank whose shard is empty must not fall back to the whole grid
+    (shard_count == 0 means 'whole grid' at the C boundary): it enqueues nothing and reports 0 evals."""
+    from pyrad_amd import engine, dist
+    g = engine.layer_grid(1013.25, 600, 603, .001, False)
+    sp = synthetic.SPECIES["co2"]
+    mols = [dict(conc=4e-4, isotopologues=[dict(lines=synthetic.make_lines(5, 200, g["eff_min"], g["eff_max"]),
+                                                molmass=sp["molmass"], q_T=286.09, q296=sp["q296"])])]
+    n = g["n_work"]
+    plans = [engine.balanced_shards([dict(depth=1.0, T=296, P=1013.25, range_min=600, range_max=603, base_resolution=.001,
+                                          dynamic_resolution=False, molecules=mols)], 8, r) for r in range(8)]
+    empties = [r for r in range(8) if plans[r].count == 0]
+    assert empties and sum(p.count for p in plans[:1]) >= 0 and sum(c for _, c in plans[0].bounds) == n
+    whole = engine.ResidentLayer(ctx, 1.0, 296, 1013.25, 600, 603, mols, .001, False)
+    total = 0
+    for r in range(8):
+        L = engine.ResidentLayer(ctx, 1.0, 296, 1013.25, 600, 603, mols, .001, False, shard=plans[r])
+        L.enqueue(surface_T=288.0)
+        ctx.sync()
+        if r in empties:
+            assert L.empty and L.evals == 0 and not L.abs_coef.download(n).any()
+        total += L.evals
+        L.free()
+    assert total == whole.evals
+    whole.free()

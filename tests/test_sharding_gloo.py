@@ -81,6 +81,63 @@ def test_two_rank_sharded_spectrum_matches_unsharded(tmp_path):
     assert float(z["evals"][0]) == float(z["evals_ref"])
 
 
+def _worker_balanced(rank, world, port, out_dir):
+    """The cost-balanced form: unequal contiguous shards, every rank sends S (= longest shard) doubles
+    starting at its own first point into slot `rank` of a world*S gathered buffer; `assemble` restores
+    grid order.  Same control flow as engine.ResidentLayer.enqueue_allgather with a balanced plan."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    from pyrad_amd import synthetic, engine
+    from pyrad_amd import dist as pdist
+    from oracle import pyrad_oracle as orc
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = synthetic.config_c2(n_lines=900, range_min=640, range_max=656, seed=22)
+        # all the lines in the first third of the range: equal-width shards would be badly unbalanced
+        lines = {k: v.copy() for k, v in cfg["molecules"][0]["lines"].items()}
+        lines["nu"] = np.sort(640.0 + (lines["nu"] - lines["nu"].min()) / 3.0)
+        sp = synthetic.SPECIES["co2"]
+        mols = [dict(conc=4e-4, isotopologues=[dict(lines=lines, molmass=sp["molmass"], q_T=1.0, q296=1.0)])]
+        plan = engine.balanced_shards([dict(cfg, molecules=mols)], world, rank)
+        grid = orc.layer_grid(cfg["P"], cfg["range_min"], cfg["range_max"], cfg["base_resolution"], False)
+        assert plan.n == grid["n_work"] and not plan.in_place and plan.bounds[0][1] < plan.bounds[1][1]
+        sel = orc.select_window(lines, grid["eff_min"], grid["eff_max"])
+        mine = pdist.halo_select(sel, grid["range_min"], grid["resolution"], grid["W"], plan.first, plan.count)
+        xs, _ = orc.create_cross_section(mine, cfg["T"], cfg["P"], 4e-4, sp["molmass"],
+                                         synthetic.q_value("co2", cfg["T"]), sp["q296"], grid, regrid=False)
+        k_local = np.zeros(plan.n + plan.S)                      # the rank's spectrum buffer is S longer than the grid
+        k_local[plan.first:plan.first + plan.count] = orc.abs_coef(xs, 4e-4, cfg["P"], cfg["T"])[plan.first:plan.first + plan.count]
+        send = torch.from_numpy(k_local[plan.first:plan.first + plan.S].copy())
+        recv = [torch.zeros(plan.S, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(recv, send)
+        full = plan.assemble(np.concatenate([t.numpy() for t in recv]))
+        if rank == 0:
+            ref_xs, _ = orc.create_cross_section(sel, cfg["T"], cfg["P"], 4e-4, sp["molmass"],
+                                                 synthetic.q_value("co2", cfg["T"]), sp["q296"], grid, regrid=False)
+            np.savez(os.path.join(out_dir, "balanced.npz"), full=full, ref=orc.abs_coef(ref_xs, 4e-4, cfg["P"], cfg["T"]),
+                     bounds=np.array(plan.bounds))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_balanced_shards_padded_gather(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_balanced, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    z = np.load(tmp_path / "balanced.npz")
+    assert np.array_equal(z["full"], z["ref"])
+    assert z["bounds"][0][1] % 1024 == 0 and z["bounds"][0][1] + z["bounds"][1][1] == z["full"].size
+
+
 def test_file_rendezvous_two_ranks(tmp_path):
     """The control plane bench.py uses to hand the 128-byte RCCL unique id to every rank."""
     import multiprocessing as mp
