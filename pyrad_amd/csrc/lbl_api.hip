@@ -1113,6 +1113,18 @@ static void planck_constants(double* pa, double* pb) {
     *pb = 100 * hPlanck * cLight;                 // 100 * h * c      (pyradPlanck.py:42)
 }
 
+// RN(1/c) for the kernels' div_uniform, or 0 where its exactness proof does not hold (significand of c
+// all ones, c or 1/c not a normal number): the kernels then take the general divide
+static double uniform_rcp(double c) {
+    if (!std::isfinite(c) || c == 0.0) return 0.0;
+    uint64_t bits;
+    memcpy(&bits, &c, 8);
+    if ((bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull) return 0.0;
+    const double rc = 1.0 / c;
+    if (!std::isnormal(c) || !std::isnormal(rc)) return 0.0;
+    return rc;
+}
+
 static double axis_step(double lo, double hi, int64_t n) { return n > 1 ? (hi - lo) / (double)(n - 1) : 0.0; }
 
 static int check_buf(lbl_ctx* ctx, const lbl_buffer* b, int64_t n, const char* what, bool required) {
@@ -1151,6 +1163,7 @@ extern "C" int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* x
     if ((rc = check_buf(ctx, I_out, n, "I_out", false))) return rc;
     if (I_out && !I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "I_out needs I_in or surface_T > 0");
     a.n_iso = n_iso; a.n_mol = n_mol; a.P = P; a.T = T; a.depth = depth;
+    a.rT = uniform_rcp(T); a.r_surface_T = uniform_rcp(surface_T);
     a.start = range_min; a.stop = range_max; a.step = axis_step(range_min, range_max, n);
     planck_constants(&a.pa, &a.pb);
     a.surface_T = surface_T;
@@ -1200,6 +1213,7 @@ extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lin
         FusedSweep f;
         memset(&f, 0, sizeof f);
         f.P = iso[0].P; f.T = iso[0].T; f.depth = depth;
+        f.rT = uniform_rcp(f.T); f.r_surface_T = uniform_rcp(surface_T);
         f.start = grid->range_min; f.stop = grid->range_max; f.step = axis_step(grid->range_min, grid->range_max, n);
         planck_constants(&f.pa, &f.pb);
         f.surface_T = surface_T;
@@ -1240,11 +1254,13 @@ extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* cons
         if (!(layer_T[l] > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "layer_T must be > 0");
         a->trans[l] = trans[l]->d;
         a->layer_T[l] = layer_T[l];
+        a->r_layer_T[l] = uniform_rcp(layer_T[l]);
     }
     a->n_layers = n_layers;
     a->start = range_min; a->stop = range_max; a->step = axis_step(range_min, range_max, n);
     planck_constants(&a->pa, &a->pb);
     a->surface_T = surface_T;
+    a->r_surface_T = uniform_rcp(surface_T);
     a->I_in = I_in ? I_in->d : nullptr;
     a->I_out = I_out->d;
     a->n = n; a->first = first; a->count = count;
@@ -1292,6 +1308,7 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
         }
         for (int m = 0; m < n_mol[l]; ++m) a->conc[mol0 + m] = conc[mol0 + m];
         a->P[l] = P[l]; a->T[l] = T[l]; a->depth[l] = depth[l];
+        a->rT[l] = uniform_rcp(T[l]);
         if (abs_coef && abs_coef[l]) { if ((rc = check_buf(ctx, abs_coef[l], n, "abs_coef", true))) return rc; a->abs_coef[l] = abs_coef[l]->d; }
         if (trans && trans[l]) { if ((rc = check_buf(ctx, trans[l], n, "trans", true))) return rc; a->trans[l] = trans[l]->d; }
         iso0 += n_iso[l]; mol0 += n_mol[l];
@@ -1301,6 +1318,7 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
     a->start = range_min; a->stop = range_max; a->step = axis_step(range_min, range_max, n);
     planck_constants(&a->pa, &a->pb);
     a->surface_T = surface_T;
+    a->r_surface_T = uniform_rcp(surface_T);
     a->I_in = I_in ? I_in->d : nullptr;
     a->I_out = I_out->d;
     a->n = n; a->first = first; a->count = count;
@@ -1355,7 +1373,7 @@ extern "C" int lbl_planck_dev(lbl_ctx* ctx, double range_min, double range_max, 
     double pa, pb;
     planck_constants(&pa, &pb);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    launch_planck(out->d, n, range_min, range_max, T, pa, pb, ctx->stream);
+    launch_planck(out->d, n, range_min, range_max, T, uniform_rcp(T), pa, pb, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
 } LBL_GUARD_END(ctx)

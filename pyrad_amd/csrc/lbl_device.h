@@ -50,6 +50,7 @@ enum : int32_t {
 // arithmetic of layer_sweep_kernel; per-molecule volume fractions travel with the chain's jobs.
 struct FusedSweep {
     double P, T, depth;
+    double rT, r_surface_T;         // RN(1/T), RN(1/surface_T) for div_uniform (0: plain divide)
     double start, stop, step;       // xAxis = linspace(start, stop, n)
     double pa, pb, surface_T;
     const double* I_in;
@@ -117,6 +118,7 @@ struct SweepArgs {
     double conc[kMaxIso];
     int32_t n_iso, n_mol;
     double P, T, depth;
+    double rT, r_surface_T;         // RN(1/T), RN(1/surface_T) for div_uniform (0: plain divide)
     double start, stop, step;       // xAxis = linspace(start, stop, n)
     double pa, pb;                  // Planck constants 2E8*h*c**2 and 100*h*c
     double surface_T;               // used when I_in == nullptr
@@ -136,6 +138,8 @@ struct ColumnStepArgs {
     int32_t layer_iso0[kMaxLayers + 1]; // isotopologues of layer l: [layer_iso0[l], layer_iso0[l+1])
     int32_t layer_mol0[kMaxLayers + 1];
     double P[kMaxLayers], T[kMaxLayers], depth[kMaxLayers];
+    double rT[kMaxLayers];              // RN(1/T[l]) (0: plain divide)
+    double r_surface_T;
     double* trans[kMaxLayers];          // optional per-layer transmittance outputs
     double* abs_coef[kMaxLayers];       // optional per-layer absorption coefficients
     int32_t n_layers;
@@ -147,6 +151,8 @@ struct ColumnStepArgs {
 struct ColumnArgs {
     const double* trans[kMaxLayers];
     double layer_T[kMaxLayers];
+    double r_layer_T[kMaxLayers];       // RN(1/layer_T[l]) (0: plain divide)
+    double r_surface_T;
     int32_t n_layers;
     double start, stop, step, pa, pb, surface_T;
     const double* I_in; double* I_out;
@@ -170,7 +176,7 @@ void launch_regrid(const double* work, long long n_work, double* out, long long 
 void launch_layer_sweep(const SweepArgs& a, hipStream_t s);
 void launch_column_step(const ColumnStepArgs* d_args, long long count, hipStream_t s, bool aligned2);
 void launch_column_sweep(const ColumnArgs* d_args, long long n, hipStream_t s);
-void launch_planck(double* out, long long n, double start, double stop, double T, double pa, double pb, hipStream_t s);
+void launch_planck(double* out, long long n, double start, double stop, double T, double rT, double pa, double pb, hipStream_t s);
 int band_partial_count(long long n);
 void launch_band_integral(const double* y, long long n, double* partial, double* result, hipStream_t s);
 struct SumArgs { const double* in[kMaxIso]; int32_t n_in; double* out; long long n; };

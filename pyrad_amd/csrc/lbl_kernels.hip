@@ -77,10 +77,34 @@ __device__ __forceinline__ double linspace_at(long long j, long long n, double s
 // pyradPlanck.planckWavenumber (pyradPlanck.py:38-44): a / (exp(b) - 1),
 // a = 2E8*h*c**2 * n**3, b = 100*h*c*n/k/T.  pa = 2E8*h*c**2 and pb = 100*h*c come from the
 // host in the reference's association order.
-__device__ __forceinline__ double planck_wn(double n, double T, double pa, double pb) {
+// x / c for a launch-uniform divisor, bit for bit the IEEE quotient the reference's NumPy expression
+// produces, in 5 instructions instead of the ~14 of the general divide (the sweeps are ALU bound on
+// these: 15 fp64 divisions per grid point).  rc = RN(1/c) from the host.  q0 = RN(x rc) is within
+// (1 + 2^-52) ulp of x/c; r = x - q c is formed by one fma; q1 = RN(q0 + r rc) is a faithful
+// quotient; by Markstein's theorem one more correction with an exact residual gives RN(x/c) for every
+// x whenever rc is the correctly rounded reciprocal of a c whose significand is not all ones.  The host
+// passes rc = 0 for such a c (or a subnormal / non-finite one) and the plain divide is taken instead.
+__device__ __forceinline__ double div_uniform(double x, double c, double rc) {
+    if (rc == 0.0) return x / c;
+    double q = x * rc;
+    double r = fma(-q, c, x);
+    q = fma(r, rc, q);
+    r = fma(-q, c, x);
+    return fma(r, rc, q);
+}
+constexpr double kRcp1E4 = 1.0 / 1E4;      // correctly rounded by the compiler; neither significand is all ones
+constexpr double kRcpKB = 1.0 / kB;
+
+__device__ __forceinline__ double planck_wn(double n, double T, double rT, double pa, double pb) {
     double a = pa * (n * n * n);
-    double b = pb * n / kB / T;
+    double b = div_uniform(div_uniform(pb * n, kB, kRcpKB), T, rT);       // pb * n / kB / T
     return a / (exp(b) - 1.0);
+}
+
+// xs * conc * P / 1E4 / kB / T (pyradClasses.py:583), left to right like the reference
+__device__ __forceinline__ double abs_coef_term(double xs, double conc, double P, double T, double rT) {
+#pragma clang fp contract(off)
+    return div_uniform(div_uniform(div_uniform(xs * conc * P, 1E4, kRcp1E4), kB, kRcpKB), T, rT);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -839,7 +863,7 @@ __device__ __forceinline__ void fused_fold(const FusedSweep& A, const AccumJob& 
 #pragma clang fp contract(off)
     if (J.chain_flags & CHAIN_MOL_FIRST) xs_m = 0.0;
     xs_m += xsec;
-    if (J.chain_flags & CHAIN_MOL_LAST) kk += xs_m * J.conc * A.P / 1E4 / kB / A.T;
+    if (J.chain_flags & CHAIN_MOL_LAST) kk += abs_coef_term(xs_m, J.conc, A.P, A.T, A.rT);
 }
 
 // after the last line list: transmittance and outgoing radiance of the point
@@ -851,8 +875,8 @@ __device__ __forceinline__ void fused_finish(const FusedSweep& A, long long j, d
     if (A.trans) A.trans[j] = tr;
     if (A.I_out) {
         const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
-        const double B = planck_wn(nu, A.T, A.pa, A.pb);
-        const double Iin = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.pa, A.pb);
+        const double B = planck_wn(nu, A.T, A.rT, A.pa, A.pb);
+        const double Iin = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.r_surface_T, A.pa, A.pb);
         const double transmitted = tr * Iin;
         const double emitted = (1.0 - tr) * B;
         A.I_out[j] = transmitted + emitted;
@@ -1268,15 +1292,15 @@ __global__ __launch_bounds__(256) void layer_sweep_kernel(const SweepArgs A) {
         for (int m = 0; m < A.n_mol; ++m) {
             double xs = 0.0;
             while (i < A.n_iso && A.iso_mol[i] == m) { xs += A.xsec[i][j]; ++i; }
-            kk += xs * A.conc[m] * A.P / 1E4 / kB / A.T;
+            kk += abs_coef_term(xs, A.conc[m], A.P, A.T, A.rT);
         }
         if (A.abs_coef) A.abs_coef[j] = kk;
         const double tr = exp(-kk * A.depth);                               // pyradClasses.py:716
         if (A.trans) A.trans[j] = tr;
         if (A.I_out) {
             const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
-            const double B = planck_wn(nu, A.T, A.pa, A.pb);                // Layer.planck(self.T)
-            const double Iin = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.pa, A.pb);
+            const double B = planck_wn(nu, A.T, A.rT, A.pa, A.pb);          // Layer.planck(self.T)
+            const double Iin = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.r_surface_T, A.pa, A.pb);
             const double transmitted = tr * Iin;                            // pyradClasses.py:785
             const double emitted = (1.0 - tr) * B;                          // pyradClasses.py:786
             A.I_out[j] = transmitted + emitted;
@@ -1294,10 +1318,10 @@ __global__ __launch_bounds__(256) void column_sweep_kernel(const ColumnArgs* __r
     const long long jend = A.first + A.count;
     for (long long j = A.first + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < jend; j += stride) {
         const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
-        double I = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.pa, A.pb);
+        double I = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.r_surface_T, A.pa, A.pb);
         for (int l = 0; l < A.n_layers; ++l) {
             const double tr = A.trans[l][j];
-            const double B = planck_wn(nu, A.layer_T[l], A.pa, A.pb);
+            const double B = planck_wn(nu, A.layer_T[l], A.r_layer_T[l], A.pa, A.pb);
             const double transmitted = tr * I;
             const double emitted = (1.0 - tr) * B;
             I = transmitted + emitted;
@@ -1325,7 +1349,7 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
             live[p] = j0 + p < jend;
             const long long j = live[p] ? j0 + p : j0;
             nu[p] = linspace_at(j, A.n, A.start, A.stop, A.step);
-            I[p] = A.I_in ? A.I_in[j] : planck_wn(nu[p], A.surface_T, A.pa, A.pb);
+            I[p] = A.I_in ? A.I_in[j] : planck_wn(nu[p], A.surface_T, A.r_surface_T, A.pa, A.pb);
         }
         const bool pair = NP == 2 && live[NP - 1];
         for (int l = 0; l < A.n_layers; ++l) {
@@ -1350,7 +1374,7 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
                 }
                 const double f = A.conc[A.layer_mol0[l] + m];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) kk[p] += xs[p] * f * A.P[l] / 1E4 / kB / A.T[l];
+                for (int p = 0; p < NP; ++p) kk[p] += abs_coef_term(xs[p], f, A.P[l], A.T[l], A.rT[l]);
             }
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
@@ -1359,7 +1383,7 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
                 if (A.abs_coef[l]) A.abs_coef[l][j] = kk[p];
                 const double tr = exp(-kk[p] * A.depth[l]);
                 if (A.trans[l]) A.trans[l][j] = tr;
-                const double B = planck_wn(nu[p], A.T[l], A.pa, A.pb);
+                const double B = planck_wn(nu[p], A.T[l], A.rT[l], A.pa, A.pb);
                 const double transmitted = tr * I[p];
                 const double emitted = (1.0 - tr) * B;
                 I[p] = transmitted + emitted;
@@ -1372,9 +1396,9 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
 }
 
 __global__ __launch_bounds__(256) void planck_kernel(double* __restrict__ out, long long n, double start,
-                                                     double stop, double step, double T, double pa, double pb) {
+                                                     double stop, double step, double T, double rT, double pa, double pb) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) out[j] = planck_wn(linspace_at(j, n, start, stop, step), T, pa, pb);
+    if (j < n) out[j] = planck_wn(linspace_at(j, n, start, stop, step), T, rT, pa, pb);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1597,11 +1621,11 @@ void launch_optical(const double* trans, long long n, int kind, double* out, hip
     hipLaunchKernelGGL(optical_kernel, dim3(sweep_blocks(n)), dim3(256), 0, s, trans, n, kind, out);
 }
 
-void launch_planck(double* out, long long n, double start, double stop, double T, double pa, double pb, hipStream_t s) {
+void launch_planck(double* out, long long n, double start, double stop, double T, double rT, double pa, double pb, hipStream_t s) {
     if (n <= 0) return;
     const double step = n > 1 ? (stop - start) / (double)(n - 1) : 0.0;
     hipLaunchKernelGGL(planck_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, start, stop, step,
-                       T, pa, pb);
+                       T, rT, pa, pb);
 }
 
 int band_partial_count(long long n) {

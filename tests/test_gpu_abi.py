@@ -152,3 +152,38 @@ def test_empty_shard_does_nothing_and_counts_nothing(ctx):
         L.free()
     assert total == whole.evals
     whole.free()
+
+
+def test_sweep_divisions_are_ieee_exact(ctx):
+    """The sweeps divide by launch-uniform constants (1E4, k, T) with a 5-instruction sequence instead of
+    the general divide; it must return the IEEE quotient bit for bit, as NumPy's crossSection *
+    concentration * P / 1E4 / k / T does (pyradClasses.py:583): random cross sections over 25 decades,
+    zeros, integer and non-integer temperatures, three molecules with one or two isotopologues."""
+    k_B = 1.38064852E-23
+    rng = np.random.default_rng(77)
+    n = 200_000
+    for T, P in ((296, 1013.25), (217, 10.0), (287.65, 843.21), (1.0, 1e-3), (3000, 2e5), (255.99999999999997, 500.0)):
+        xs = [10.0 ** rng.uniform(-42, -16, n) for _ in range(4)]
+        for a in xs:
+            a[rng.integers(0, n, 500)] = 0.0
+        conc = [float(c) for c in (4e-4, 0.0123456789, 1.8e-6)]
+        iso_mol = [0, 0, 1, 2]
+        bufs = [ctx.buffer(n).upload(a) for a in xs]
+        k_dev, t_dev = ctx.buffer(n), ctx.buffer(n)
+        ctx.layer_sweep_dev(bufs, iso_mol, conc, P, T, 12.5, 600.0, 800.0, n, abs_coef=k_dev, trans=t_dev)
+        k_ref = np.zeros(n)
+        for m in range(3):
+            xs_m = np.zeros(n)
+            for i, a in enumerate(xs):
+                if iso_mol[i] == m:
+                    xs_m = xs_m + a
+            k_ref = k_ref + xs_m * conc[m] * P / 1E4 / k_B / T
+        assert np.array_equal(k_dev.download(n), k_ref), (T, P)
+        # the column step and the single-line-list fused step use the same helper
+        out = ctx.buffer(n)
+        k_col = ctx.buffer(n)
+        ctx.column_step_dev([dict(xsec=bufs, iso_mol=iso_mol, conc=conc, P=P, T=T, depth=12.5, abs_coef=k_col, trans=None)],
+                            600.0, 800.0, n, out, surface_T=288.0)
+        assert np.array_equal(k_col.download(n), k_ref), (T, P)
+        for b in bufs + [k_dev, t_dev, out, k_col]:
+            b.free()
