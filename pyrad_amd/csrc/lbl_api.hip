@@ -395,7 +395,7 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) try {
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_points_per_lane must be 0, 1, 2, 4 or 8");
         ctx->accum_R = value;
     } else if (!strcmp(key, "accum_longest_first")) {
-        if (value < 0 || value > 3) return fail(ctx, LBL_ERR_BAD_ARG, "accum_longest_first must be 0..3");
+        if (value < 0 || value > 4) return fail(ctx, LBL_ERR_BAD_ARG, "accum_longest_first must be 0..4");
         ctx->lpt = value;
     } else if (!strcmp(key, "accum_blocks_per_cu")) {
         if (value < 0 || value > 8) return fail(ctx, LBL_ERR_BAD_ARG, "accum_blocks_per_cu must be 0 (auto) .. 8");
@@ -723,9 +723,55 @@ static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const 
             items.push_back({(int)(cost + 0.5), (int)k, (int)t});
         }
     }
-    std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.count > y.count; });
     const size_t n_cu = (size_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
-    if (ctx->lpt == 2) {
+    bool xcd_done = false;
+    if (ctx->lpt == 4 && items.size() > 4 * n_cu) {
+        // XCD-partitioned longest-first (launches of several rounds): workgroup i is dispatched to XCD
+        // i mod 8, and every XCD has its own L2.  The positional sequence of tiles is cut into 8
+        // contiguous parts of equal estimated cost, each part sorted longest-first, and the parts are
+        // interleaved, so XCD x only ever reads the line records of part x (an eighth of the list plus
+        // the window halo) instead of every XCD pulling every record into its L2.
+        const int X = 8;
+        // (finer than one part per XCD: 8 chunks per XCD, dealt round-robin, so that a bias of the cost
+        // estimate in one spectral region - pure-Lorentz lines are cheaper than the model's average -
+        // does not load one XCD)
+        const int chunks = X * 8;
+        double total = 0.0;
+        for (const Item& it : items) total += it.count;
+        std::vector<std::vector<Item>> part(X);
+        double run = 0.0;
+        for (const Item& it : items) {
+            int c = (int)(run / (total / chunks + 1e-9));
+            if (c >= chunks) c = chunks - 1;
+            part[(size_t)(c % X)].push_back(it);
+            run += it.count;
+        }
+        for (auto& p : part) std::stable_sort(p.begin(), p.end(), [](const Item& a, const Item& b) { return a.count > b.count; });
+        std::vector<Item> out;
+        out.reserve(items.size());
+        std::vector<size_t> pos(X, 0);
+        while (out.size() < items.size()) {
+            for (int x = 0; x < X; ++x) {
+                int src = x;
+                if (pos[(size_t)src] >= part[(size_t)src].size()) {       // part x is exhausted: its slots take from the part with most left
+                    size_t best_left = 0;
+                    src = -1;
+                    for (int y = 0; y < X; ++y) {
+                        const size_t left = part[(size_t)y].size() - pos[(size_t)y];
+                        if (left > best_left) { best_left = left; src = y; }
+                    }
+                    if (src < 0) break;
+                }
+                out.push_back(part[(size_t)src][pos[(size_t)src]++]);
+            }
+        }
+        items.swap(out);
+        xcd_done = true;
+    }
+    if (!xcd_done)
+        std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.count > y.count; });
+    if (xcd_done) {
+    } else if (ctx->lpt == 2) {
         // snake order: on a small grid every workgroup is resident from the first cycle, nothing is
         // dispatched dynamically, and CU k receives items k, k + n_cu, k + 2 n_cu, ...: reversing
         // every other tier of n_cu items pairs the heaviest of one tier with the lightest of the next
