@@ -303,6 +303,9 @@ def main():
                          "ROCm 7.2: C1 0.021 vs 0.017 ms, C2 0.077 vs 0.074, a shard of 8 of C3 0.074 vs 0.071)")
     ap.add_argument("--lines", type=int, default=None, help="experiment: C2 with this many lines instead of 65,536")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-direct-pass", action="store_true",
+                    help="skip the extra untimed pass of the all-direct kernel (profiles/collect.sh: keeps the PMC passes "
+                         "to the kernels of the timed path)")
     ap.add_argument("--no-api-path", action="store_true", help="skip the pyrad_amd.model (drop-in API) timing leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather", default="abs_coef", choices=["abs_coef", "all"])
@@ -485,7 +488,7 @@ def main():
     # the all-direct kernel (variant 3: every (line, grid point) pair evaluated, no series) on the
     # same resident inputs, untimed, so that the line carries both numbers
     direct_ms = None
-    if args.variant in (None, 5):
+    if args.variant in (None, 5) and not args.no_direct_pass:
         ctx.set_option("accum_variant", 3)
         for _ in range(2):
             step(timed_kernels=True)

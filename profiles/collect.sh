@@ -11,7 +11,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="$R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-api-path --workload $WORKLOAD"
+CMD="$R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-api-path --no-direct-pass --workload $WORKLOAD"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$WORKLOAD -- python3 $CMD > $OUT/trace_$WORKLOAD.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$WORKLOAD -- python3 $CMD > $OUT/pmc_fetch_$WORKLOAD.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$WORKLOAD -- python3 $CMD > $OUT/pmc_write_$WORKLOAD.log 2>&1

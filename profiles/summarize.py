@@ -89,14 +89,13 @@ def main():
         allt = {}
     traffic, valu_insts, avg_us, weights = {}, {}, {}, {}
     for k, v in pmc["kernels"].items():
-        # bench.py times the far-field kernel <R, LS, FF = true, CHAIN>; its extra untimed pass runs the
-        # all-direct kernel <R, LS, false, CHAIN> (reported as valu_f64.direct_*)
+        # collect.sh profiles bench.py --no-direct-pass, so every xsec_accumulate_* launch belongs to the
+        # timed path: the far-field kernel <R, LS, true> and, for a column, the all-direct instantiations
+        # <R, LS, false> its narrow-window layer groups take; launch-weighted means over all of them
         if k.startswith("xsec_accumulate"):
-            targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
-            far = len(targs) >= 3 and targs[2] == "true"
-            base = "xsec_accumulate_kernel" if far else "xsec_accumulate_direct_kernel"
+            base = "xsec_accumulate_kernel"
         else:
-            base = k
+            base = k.split("<")[0]
         # several instantiations can share a base name (a column launches one kernel per window
         # group): launch-weighted means
         w = max(v.get("launches_fetch_pass", 1), 1)
