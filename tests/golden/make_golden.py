@@ -277,6 +277,7 @@ def g1():
             arrays["x_axis"] = ref["x_axis"]
             arrays["absorbance"] = ref["absorbance"]
             arrays["optical_depth"] = ref["optical_depth"]
+            arrays["emissivity"] = ref["emissivity"]
             arrays["planck_surface"] = ref["planck_surface"]
             arrays["W"] = np.int64(ref["W"])
     save("G1_c1_cell", **arrays)

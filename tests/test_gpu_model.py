@@ -37,6 +37,8 @@ def test_g1_layer_getters(pyrad):
     assert rel_err(pyrad.getTransmittance(layer), z["T296.transmittance"]) <= RTOL
     assert rel_err(pyrad.getAbsorbance(layer), z["absorbance"], floor=1e-300) <= 1e-9
     assert rel_err(pyrad.getOpticalDepth(layer), z["optical_depth"], floor=1e-300) <= 1e-9
+    assert np.max(np.abs(pyrad.getEmissivity(layer) - z["emissivity"])) <= 1e-11
+    assert np.array_equal(layer.emittance, layer.emissivity)
     assert np.array_equal(layer.xAxis, z["x_axis"])
     surf = layer.planck(288)
     assert rel_err(surf, z["planck_surface"]) <= 1e-14

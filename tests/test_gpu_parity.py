@@ -218,6 +218,10 @@ def test_g1_sweep_optical_properties_and_planck(ctx, orc):
     assert rel_err(out.download(), z["optical_depth"], floor=1e-300) <= 1e-9
     ctx.optical_dev(L.trans, L.n, 0, out)
     assert np.array_equal(out.download(), 1 - r["transmittance"])
+    # against the reference's own emissivity (cls:726-728).  1 - T cancels where the cell is nearly transparent,
+    # so the 1e-11 agreement of T shows up divided by the emissivity itself: absolute tolerance on the scale of T
+    assert np.max(np.abs(out.download() - z["emissivity"])) <= 1e-11
+    assert rel_err(out.download(), z["emissivity"], floor=1e-3) <= 1e-8
     L.free()
 
 

@@ -114,6 +114,7 @@ def test_g1_cell(T):
     if T == 296:
         assert rel_err(orc.absorbance(tr), z["absorbance"], floor=1e-300) <= 1e-9
         assert rel_err(orc.optical_depth(tr), z["optical_depth"], floor=1e-300) <= 1e-9
+        assert np.max(np.abs((1 - tr) - z["emissivity"])) <= 1e-12            # cls:726-728
 
 
 def test_g1_scalar_and_vector_forms_agree_bitwise():
