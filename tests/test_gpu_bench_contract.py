@@ -73,3 +73,24 @@ def test_self_launch_on_a_one_gpu_box_fails_loudly():
     assert p.returncode != 0
     assert "one process per GPU" in p.stderr and "LOCAL_RANK 1" in p.stderr
     assert not p.stdout.strip()
+
+
+@pytest.mark.parametrize("shards", ["balanced", "equal"])
+def test_sharded_step_with_the_communicator_pipeline(shards):
+    """The code path a rank of an 8-GPU run takes - a shard plan (cost-balanced: out-of-place padded
+    gather; equal: in place), two buffer sets, the all-gather of step k overlapped with step k+1, fences -
+    driven on one GPU: shard 3 of 8 of the C3 cell with the RCCL communicator forced on (one rank, so the
+    collective moves this rank's slot only).  Catches host-side mistakes in the N > 1 branch that the
+    gloo tests (no HIP) and the --shard-of runs (no communicator) do not reach."""
+    d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-api-path", "--shard-of", "8,3",
+                   "--shards", shards], {"PYRAD_FORCE_COMM": "1"})
+    assert d["config"]["allgather"].startswith("overlapped") and d["value"] > 1e12
+    b = d["config"]["shard_bounds"]
+    assert len(b) == 8 and sum(c for _, c in b) == 2400000 and d["config"]["grid_points_per_gpu"] == b[3][1]
+    d2 = run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-api-path", "--shard-of", "8,3",
+                    "--shards", shards, "--no-overlap", "--gather", "all"], {"PYRAD_FORCE_COMM": "1"})
+    assert d2["config"]["allgather"] == "in-stream" and d2["kernel_ms_per_step"]["allgather"] > 0
+    # the column takes the same route
+    d3 = run_bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--workload", "C5", "--shard-of", "8,3",
+                    "--shards", shards], {"PYRAD_FORCE_COMM": "1"})
+    assert d3["value"] > 1e11 and "column" in d3["config"]["workload"]
