@@ -203,6 +203,9 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
         // narrower profiles take one exp per point
         rc.q2 = (rc.b <= 4.0) ? exp(-2.0 * rc.b) : -1.0;
         if (!(rc.b <= 4.0)) r.flags |= REC_NO_RECUR;
+        // 16-point runs (gauss_runs16): a lane may start up to 272 points beyond the cut-off and walks 15
+        // steps; the recurrence is exact only while its seed is a normal number
+        { const double far = (double)r.dgi + 272.0; if (rc.b <= 4.0 && rc.b * far * far < 600.0) r.flags |= REC_LONG_RUN; }
         rc.KLd = r.KL;
         J.hot[i] = r;
         J.cold[i] = rc;
@@ -584,13 +587,75 @@ __device__ __forceinline__ void rf_segment(const double* __restrict__ lh, int j0
 // gmask bit j: record j's Gaussian term can matter for some point of this wave;
 // dmask bit j: record j's denominator is outside the running-fraction range -> plain divide
 // (its LDS copy carries K = 0, a2 = 1 so the hot loop adds nothing for it).
+// LDS slot of grid-point offset o within a wave's span (padded so that a lane writing its R
+// consecutive points and a lane reading every 64th point are both nearly conflict-free)
+__device__ __forceinline__ int span_slot(int o) { return o + (o >> 4); }
+
+// Transposed Gaussian pass: FOUR records at once, lane group q = lane/16 takes one of them and lane t =
+// lane%16 of the group walks the 16 consecutive points 16t .. 16t+15 of the span with the recurrence
+// g(d+1) = g(d) r(d), r(d+1) = r(d) q2: two exp per 16 points instead of per 4 (25 instead of 51 wave
+// instructions per record).  Sums go to G[16] per lane (point 16t+k of the span, partial over this
+// group's records); gauss_runs16_fold adds the four groups' partial sums to the owners of the points
+// in a fixed order.  Only interior lines (no masking) flagged REC_LONG_RUN by K1 come here.
+__device__ __forceinline__ void gauss_runs16(const double* __restrict__ lh, const double* __restrict__ lc,
+                                             unsigned long long m, double xrun, int lane, double (&G)[16]) {
+    const int q = lane >> 4;
+    while (m) {
+        const int j0 = __builtin_ctzll(m); m &= m - 1;
+        const int j1 = m ? __builtin_ctzll(m) : -1; m &= m - (m ? 1ull : 0ull);
+        const int j2 = m ? __builtin_ctzll(m) : -1; m &= m - (m ? 1ull : 0ull);
+        const int j3 = m ? __builtin_ctzll(m) : -1; m &= m - (m ? 1ull : 0ull);
+        const int j = q == 0 ? j0 : q == 1 ? j1 : q == 2 ? j2 : j3;
+        const int jj = j < 0 ? j0 : j;
+        const double cf = lh[jj * 4];
+        const double* c = lc + jj * 4;
+        const double KG = j < 0 ? 0.0 : c[0], b = c[1], q2 = c[2];
+        const double d0 = xrun - cf;
+        double g = KG * exp_clamped(-b * (d0 * d0));
+        double rr = exp_clamped(fmin(-b * (2.0 * d0 + 1.0), 700.0));
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            G[k] += g;
+            g *= rr;
+            rr *= q2;
+        }
+    }
+}
+
+// G (lane (q, t): points 16t..16t+15, partial sums of group q) -> acc (lane l: points R l .. R l + R-1), through
+// 2 KB of the wave's LDS scratch, one group per round, groups added in the order 0..3
 template <int R>
+__device__ __forceinline__ void gauss_runs16_fold(const double (&G)[16], double* scratch, int lane, double (&acc)[R]) {
+    const int q = lane >> 4, t = lane & 15;
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        __builtin_amdgcn_wave_barrier();
+        if (q == round) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) scratch[span_slot(16 * t + k)] = G[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < R; ++k) acc[k] += scratch[span_slot(lane * R + k)];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int R, bool LONGG = false>
 __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, const double* __restrict__ lc,
                                              unsigned long long gmask, unsigned long long emask,
                                              unsigned long long dmask, unsigned long long imask, double x0, double Hf,
-                                             WaveAcc<R>& S) {
+                                             WaveAcc<R>& S, unsigned long long lmask, double xrun, int lane,
+                                             double (&G16)[16]) {
     // emask bit j: record j must use one exp per point (profile too narrow for the recurrence)
     // imask bit j: record j is an interior line (every point of the wave inside its support): no masking
+    // lmask bit j: record j may take the transposed 16-point runs (LONGG kernels, R = 4)
+    if (LONGG && R == 4) {
+        const unsigned long long ml = gmask & ~emask & imask & lmask;
+        if (ml) gauss_runs16(lh, lc, ml, xrun, lane, G16);
+        gmask &= ~ml;
+    }
     unsigned long long m = gmask & ~emask & imask;
     while (m) {
         const int j = __builtin_ctzll(m);
@@ -638,10 +703,10 @@ __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, cons
 // Lines below iB or from iC on end inside the wave's span and are masked per point.
 // The wave streams the records in chunks of 64 through its own LDS (lh: hot halves, lc: cold
 // halves), with the next chunk's loads in flight while the current one is consumed.
-template <int R>
+template <int R, bool LONGG = false>
 __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRec* cold, int mA, int mD, int iB, int iC,
                                                  int wlo, int whi, double x0, double Hf, double* lh, double* lc, int lane,
-                                                 WaveAcc<R>& S, int stride = 64, int step = 1, int phase = 0) {
+                                                 WaveAcc<R>& S, double (&G16)[16], int stride = 64, int step = 1, int phase = 0) {
     // step > 1 (with stride = 64): every wave of the span walks ALL chunks but takes only the records
     // j % step == phase of each, so the split is exact to a line.  Dealing whole chunks left one wave
     // of a two-way split with 128 of a span's ~210 near lines and the other with 82.
@@ -672,6 +737,7 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
         const unsigned long long gmask = __ballot(gauss);
         const unsigned long long dmask = __ballot(direct) & stripe;
         const unsigned long long emask = __ballot((fl & REC_NO_RECUR) != 0);
+        const unsigned long long lmask = LONGG ? __ballot((fl & REC_LONG_RUN) != 0) : 0ull;
         v2f64 w0 = h0, w1 = h1;
         if (direct) { w0.y = 1.0; w1.x = 0.0; }          // a2 = 1, KL = 0 in the hot loop's copy
         reinterpret_cast<v2f64*>(lh)[lane * 2] = w0;
@@ -705,7 +771,8 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
             __builtin_amdgcn_wave_barrier();
             // records a1..b1-1 of the chunk are interior lines
             const unsigned long long imask = (b1 > a1) ? ((b1 - a1 >= 64 ? ~0ull : ((1ull << (b1 - a1)) - 1ull)) << a1) : 0ull;
-            chunk_extras<R>(lh, lc, gmask, emask, dmask, imask, x0, Hf, S);
+            chunk_extras<R, LONGG>(lh, lc, gmask, emask, dmask, imask, x0, Hf, S, lmask,
+                                   (double)(wlo + 16 * (lane & 15)), lane, G16);
         }
     }
 }
@@ -830,7 +897,8 @@ __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec
             reinterpret_cast<v2f64*>(lc)[lane * 2 + 1] = c1v;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            chunk_extras<R>(lh, lc, gmask, emask, 0ull, ~0ull, x0, Hf, S);
+            double unused[16];
+            chunk_extras<R, false>(lh, lc, gmask, emask, 0ull, ~0ull, x0, Hf, S, 0ull, 0.0, lane, unused);
             __builtin_amdgcn_wave_barrier();
         }
         const double dl = w0.x - xc;
@@ -883,12 +951,9 @@ __device__ __forceinline__ void fused_finish(const FusedSweep& A, long long j, d
     }
 }
 
-// LDS slot of grid-point offset o within a wave's span (padded so that a lane writing its R
-// consecutive points and a lane reading every 64th point are both nearly conflict-free)
-__device__ __forceinline__ int span_slot(int o) { return o + (o >> 4); }
 
 template <int R, int LS, bool FF = false>
-__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), ((R >= 8 && LS <= 4) ? 4 : 1))
+__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), ((R >= 4 && LS <= 4) ? 4 : 1))     // HIP: min waves per SIMD
 void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* __restrict__ worklist) {
     constexpr int NW = LS > 4 ? LS : 4;              // wavefronts per workgroup (LS = 8: 512 threads)
     constexpr int PG = NW / LS;                      // point groups (64*R points each) per workgroup
@@ -934,7 +999,11 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         if (tab) { iA = uniform_i32(tab[0]); iB = uniform_i32(tab[1]); iC = uniform_i32(tab[2]); iD = uniform_i32(tab[3]); }
         else wave_line_ranges(J.cidx, J.n_lines, wlo, whi, H, lane, iA, iB, iC, iD);
         // this wave's share of the span's lines: every LS-th chunk of 64, starting at chunk `part`
-        accumulate_lines<R>(J.hot, J.cold, iA + part * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64 * LS);
+        double G[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) G[k] = 0.0;
+        accumulate_lines<R, true>(J.hot, J.cold, iA + part * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64 * LS);
+        if (R == 4) gauss_runs16_fold<R>(G, s_stage[wave], lane, S.acc);
         S.flush();
     }
     if (active && FF) {
@@ -970,11 +1039,16 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         // the direct classes: left-edge, near and right-edge lines.  Without far lines (narrow window)
         // they are one contiguous run and go through the first stream alone (one prologue, not three).
         // (the LS waves of a span interleave these classes line by line; series chunks are dealt whole)
-        accumulate_lines<R>(J.hot, J.cold, iA, any_far ? iB : iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64, LS, part);
+        // (Gaussian parts of interior lines: 16-point runs into G, folded into the sums once per span)
+        double G[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) G[k] = 0.0;
+        accumulate_lines<R, true>(J.hot, J.cold, iA, any_far ? iB : iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
         if (any_far) {
-            accumulate_lines<R>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64, LS, part);
-            accumulate_lines<R>(J.hot, J.cold, iC, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, 64, LS, part);
+            accumulate_lines<R, true>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+            accumulate_lines<R, true>(J.hot, J.cold, iC, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
         }
+        if (R == 4) gauss_runs16_fold<R>(G, s_stage[wave], lane, S.acc);
         S.flush();
     }
 
@@ -1128,7 +1202,8 @@ __global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_balance
         const double Hf = (double)J.H;
         WaveAcc<R> S;
         S.init(J.flush_every);
-        accumulate_lines<R>(J.hot, J.cold, r.iA + off, r.iA + off + piece, r.iB, r.iC, wlo, whi, x0, Hf, lh, lc, lane, S);
+        double unused[16];
+        accumulate_lines<R, false>(J.hot, J.cold, r.iA + off, r.iA + off + piece, r.iB, r.iC, wlo, whi, x0, Hf, lh, lc, lane, S, unused);
         S.flush();
         // coalesced store through LDS: whole spans straight to the output, partial ones to the slab
         __builtin_amdgcn_wave_barrier();
