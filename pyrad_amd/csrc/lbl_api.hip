@@ -649,6 +649,9 @@ static void choose_shape(const lbl_ctx* ctx, int variant, long long total_points
 // span visits: they are the lower bounds of the very centre indices K1 writes, because the host
 // evaluates the same correctly rounded IEEE expression (nu - range_min) / resolution on the same
 // doubles (host and device code are built without fast-math), and truncation is shared.
+#ifndef LBL_COST_GAUSS
+#define LBL_COST_GAUSS 15.0      // wave-instructions a near line's Gaussian passes add per span (0.6 passes of ~25; 29 before the 16-point runs)
+#endif
 static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::vector<int>& jobs_in_group,
                                                lbl_lines* const* lines, const lbl_grid* grid, int R, int LS, long long tile_pts) {
     std::vector<uint64_t> key;
@@ -712,13 +715,13 @@ static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const 
         for (long long t = 0; t < n_tiles; ++t) {
             double cost = 0.0;
             for (long long q = t * spans_per_tile; q < std::min((t + 1) * spans_per_tile, n_spans); ++q) {
-                // wave-instructions of one span: near line 5R + ~0.6 Gaussian passes of 48, masked edge
+                // wave-instructions of one span: near line 5R + ~0.6 Gaussian passes (LBL_COST_GAUSS), masked edge
                 // line 8R, series line ~1.6, fixed part ~600 (variants without the series: all direct)
                 const int32_t* e = T + q * 8;
                 const double n_far = (double)((e[4] - e[1]) + (e[2] - e[5]));
                 const double n_edge = (double)((e[1] - e[0]) + (e[3] - e[2]));
                 const double n_near = (double)(e[5] - e[4]);
-                cost += n_near * (5.0 * R + 29.0) + n_edge * 8.0 * R + n_far * far_cost * 5.0 * R + 600.0;
+                cost += n_near * (5.0 * R + LBL_COST_GAUSS) + n_edge * 8.0 * R + n_far * far_cost * 5.0 * R + 600.0;
             }
             items.push_back({(int)(cost + 0.5), (int)k, (int)t});
         }

@@ -147,7 +147,7 @@ ALIGN = 1024        # shard boundaries are multiples of one workgroup's points (
 def span_costs(centre_index, H: int, n: int, has_gaussian=None) -> np.ndarray:
     """Estimated K2 wave-instructions per span of 256 grid points for one line list, the host
     model of lbl_api.hip's group_schedule: near lines (within 4 half-spans of the span) are
-    evaluated point by point, 5R instructions, plus a Gaussian pass of ~48 on the spans their
+    evaluated point by point, 5R instructions, plus a Gaussian pass of ~25 on the spans their
     Gaussian part reaches (~0.6 of the near spans) when the line has one (pseudo-Voigt or Gaussian
     regime); lines reached through the far-field series ~1.6; a fixed part per span.
     ``centre_index`` = sorted int centre indices (cls:390); ``has_gaussian`` = per-line bool in the
@@ -169,7 +169,7 @@ def span_costs(centre_index, H: int, n: int, has_gaussian=None) -> np.ndarray:
     else:
         pre = np.concatenate([[0], np.cumsum(np.asarray(has_gaussian, dtype=np.int64))])
         gauss = np.minimum(pre[b] - pre[a], near)
-    return near * (5.0 * 4) + gauss * 29.0 + (reach - near) * 1.6 + 600.0
+    return near * (5.0 * 4) + gauss * 15.0 + (reach - near) * 1.6 + 600.0
 
 
 def gaussian_part(lines: dict, T, P, conc, molmass) -> np.ndarray:
