@@ -292,8 +292,9 @@ def main():
                     help="N > 1: grow the grid with N (every rank owns one whole C-sized grid) instead of sharding the FIXED "
                          "workload (the default, BASELINE config 4; \"scaling\": \"strong\")")
     ap.add_argument("--strong", action="store_true", help="accepted for compatibility: strong scaling is the default")
-    ap.add_argument("--shards", default="balanced", choices=["balanced", "equal"],
-                    help="N > 1: cost-balanced contiguous shard boundaries from the line positions (default) or equal widths")
+    ap.add_argument("--shards", default="auto", choices=["auto", "balanced", "equal"],
+                    help="N > 1: equal-width contiguous shards, cost-balanced boundaries from the line positions, or (default) "
+                         "balanced only where the cost model expects it to pay for the longer all-gather slot")
     ap.add_argument("--shard-of", default=None, metavar="G,r",
                     help="experiment on ONE GPU: run only shard r of a G-way sharding of the workload (no communicator): "
                          "what rank r of G would compute per step")
@@ -358,7 +359,7 @@ def main():
     strong = not args.weak
     cfg, desc = build_workload(args.workload, (1 if strong else world) * args.scale)
     if world > 1:
-        desc += (" [fixed workload, grid sharded x%d, %s shards]" % (world, args.shards)) if strong else \
+        desc += (" [fixed workload, grid sharded x%d]" % world) if strong else \
                 (" [grid grows with N: x%d]" % world)
     if args.scale != 1:
         desc += " [--scale %d: not a BASELINE configuration]" % args.scale
@@ -379,11 +380,10 @@ def main():
     shard_world, shard_rank = world, rank
     if args.shard_of:
         shard_world, shard_rank = (int(v) for v in args.shard_of.split(","))
-        desc += " [ONLY shard %d of %d, %s bounds: a one-GPU experiment, not a BASELINE configuration]" % (
-            shard_rank, shard_world, args.shards)
+        desc += " [ONLY shard %d of %d: a one-GPU experiment, not a BASELINE configuration]" % (shard_rank, shard_world)
+    shard_choice = "none"
     if shard_world > 1:
-        shard = (engine.balanced_shards(layer_cfgs, shard_world, shard_rank) if args.shards == "balanced"
-                 else (shard_world, shard_rank))
+        shard, shard_choice = engine.choose_shards(layer_cfgs, shard_world, shard_rank, args.shards)
     if args.workload == "C5":
         layers = [engine.ResidentColumn(ctx, layer_cfgs, cfg["surface_T"], shard=shard) for _ in range(n_sets)]
     else:
@@ -561,6 +561,7 @@ def main():
                        "window_W": int(g["W"]), "evals_per_step": evals_total, "parallelism": "grid-range x%d" % world,
                        "gathered": args.gather, "device": info["name"], "preconditioning_s": args.precondition_seconds,
                        "shard_bounds": (None if layer.plan is None else [list(b) for b in layer.plan.bounds]),
+                       "shards": shard_choice,
                        "step_launch": ("kernel by kernel" if not args.graph else
                                        "one hipGraph per step (K1, K2, sweep captured once); kernel by kernel in the steps "
                                        "that carry timing events"),
