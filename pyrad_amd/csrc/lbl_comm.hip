@@ -139,8 +139,13 @@ extern "C" int lbl_comm_fence_dev(lbl_comm* comm, int slot) try {
     lbl_ctx_stream(comm->ctx, &s);
     for (int i = 0; i < 4; ++i) {
         if ((slot >= 0 && i != slot) || !comm->pending[i]) continue;
-        if (hipStreamWaitEvent((hipStream_t)s, comm->done[i], 0) != hipSuccess)
-            return lbl::comm_fail(comm->ctx, LBL_ERR_HIP, "stream ordering (done) failed");
+        // Usually the collective of two steps ago has long finished: ask the host side first and put a wait
+        // (a barrier packet, a few microseconds of the context stream) into the stream only if it has not
+        if (hipEventQuery(comm->done[i]) != hipSuccess) {
+            (void)hipGetLastError();                   // hipErrorNotReady is not an error here
+            if (hipStreamWaitEvent((hipStream_t)s, comm->done[i], 0) != hipSuccess)
+                return lbl::comm_fail(comm->ctx, LBL_ERR_HIP, "stream ordering (done) failed");
+        }
         comm->pending[i] = false;
     }
     return LBL_OK;
