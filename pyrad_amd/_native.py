@@ -121,18 +121,15 @@ def build(force: bool = False) -> str:
 
 
 def source_hash() -> str:
-    """sha256 over the kernel sources and build flags (csrc/*.hip, *.h, Makefile, the public header):
-    profiles/pmc_traffic.json records it so that bench.py can tell when committed PMC numbers were
-    measured on other kernels than the ones it is timing."""
+    """sha256 over what decides the kernels and their launch shapes (csrc/lbl_kernels.hip, lbl_api.hip,
+    lbl_device.h, Makefile): profiles/pmc_traffic.json records it so that bench.py can tell when
+    committed PMC numbers were measured on other kernels than the ones it is timing."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile")
-    for f in files:
+    for f in ("Makefile", "lbl_api.hip", "lbl_device.h", "lbl_kernels.hip"):
         h.update(f.encode())
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
-    with open(os.path.join(os.path.dirname(_HERE), "include", "pyrad_hip.h"), "rb") as fh:
-        h.update(fh.read())
     return h.hexdigest()[:16]
 
 
