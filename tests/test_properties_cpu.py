@@ -124,3 +124,60 @@ def test_data_dir_round_trip_equals_memory_source(tmp_path_factory, seed, n, lo,
     for f in synthetic.FIELDS:
         assert np.array_equal(a[f], b[f]), f
     assert disk.getQData(7) == q and disk.readMolParams(7)[0] == params[0]
+
+
+@settings(max_examples=120, deadline=None)
+@given(n=st.integers(1, 3_000_000), world=st.integers(1, 16), n_lines=st.integers(0, 3000), H=st.integers(0, 6000),
+       seed=st.integers(0, 2**31 - 1), clustered=st.booleans(), ratio=st.sampled_from([1.0, 1.125, 2.0, 8.0]))
+def test_balanced_plan_properties(n, world, n_lines, H, seed, clustered, ratio):
+    """Cost-balanced shard plans: every rank derives the same plan; shards tile the grid contiguously; boundaries
+    are multiples of a workgroup's points; no shard exceeds the cap (so the all-gather slot is bounded); the
+    padded gather layout round-trips; and with a loose cap the summed model cost per shard is never worse than
+    one aligned block above the equal-width plan's worst shard."""
+    rng = np.random.default_rng(seed)
+    if clustered:
+        c = np.sort((rng.normal(0.3 * n, 0.05 * n + 1, n_lines)).astype(np.int64))
+    else:
+        c = np.sort(rng.integers(-H, n + H + 1, n_lines))
+    cost = dist.span_costs(c, H, n, has_gaussian=rng.random(n_lines) < 0.5)
+    assert cost.shape == (-(-n // dist.SPAN),) and np.all(cost >= 600.0)
+    plans = [dist.balanced_plan(n, world, r, cost, max_ratio=ratio) for r in range(world)]
+    b = plans[0].bounds
+    assert all(p.bounds == b for p in plans)
+    assert b[0][0] == 0 and sum(k for _, k in b) == n
+    for (f, k), (f2, _) in zip(b, b[1:] + [(n, 0)]):
+        assert k >= 0 and f + k == f2 and (f % dist.ALIGN == 0 or f == n)
+    n_blocks = -(-n // dist.ALIGN)
+    cap_blocks = max(int(np.ceil(ratio * n_blocks / world)), 1)
+    assert plans[0].S <= cap_blocks * dist.ALIGN
+    spec = rng.random(n)
+    gathered = np.zeros(world * plans[0].S)
+    for r, (f, k) in enumerate(b):
+        gathered[r * plans[0].S:r * plans[0].S + k] = spec[f:f + k]
+    assert np.array_equal(plans[0].assemble(gathered), spec)
+    if plans[0].in_place:                                   # then slot r starts where shard r starts
+        assert all(f == min(r * plans[0].S, n) for r, (f, _) in enumerate(b))
+    if ratio >= 8.0 and world > 1:
+        prefix = np.concatenate([[0.0], np.cumsum(cost)])
+        load = lambda bounds: max(prefix[-(-(f + k) // dist.SPAN)] - prefix[f // dist.SPAN] for f, k in bounds)
+        block = float(np.max(np.add.reduceat(cost, np.arange(0, cost.size, dist.ALIGN // dist.SPAN))))
+        assert load(b) <= load(dist.equal_plan(n, world, 0).bounds) + 2 * block
+
+
+@settings(max_examples=40, deadline=None)
+@given(world=st.integers(2, 8), seed=st.integers(0, 1000), mode=st.sampled_from(["auto", "balanced", "equal"]))
+def test_choose_shards_is_rank_independent(world, seed, mode):
+    """engine.choose_shards: every rank makes the same choice and gets the same bounds (pure host arithmetic
+    on the line positions), whatever the mode."""
+    from pyrad_amd import synthetic
+    g = engine.layer_grid(1013.25, 600, 640, .001, False)
+    lines = synthetic.make_lines(seed, 400, g["eff_min"], g["eff_max"])
+    lines["nu"] = np.sort(600.0 + (lines["nu"] - lines["nu"].min()) * (0.25 + (seed % 4) * 0.25))   # more or less clustered
+    cfgs = [dict(depth=1.0, T=280, P=1013.25, range_min=600, range_max=640, base_resolution=.001, dynamic_resolution=False,
+                 molecules=[dict(conc=4e-4, isotopologues=[dict(lines=lines, molmass=43.98983, q_T=1.0, q296=1.0)])])]
+    got = [engine.choose_shards(cfgs, world, r, mode) for r in range(world)]
+    assert all(p.bounds == got[0][0].bounds and what == got[0][1] for p, what in got)
+    assert [p.rank for p, _ in got] == list(range(world))
+    assert sum(k for _, k in got[0][0].bounds) == g["n_work"]
+    if mode == "equal":
+        assert got[0][0].in_place and got[0][1] == "equal"
