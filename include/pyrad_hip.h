@@ -106,14 +106,14 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "accum_line_split"       0 (auto) | 1 | 2 | 4 | 8 waves of a workgroup share one span of points
  *                            and split its lines (variants 3 and 5)
  *   "accum_longest_first"    workgroups are dispatched from a cached (job, tile) worklist sorted by
- *                            decreasing cost: 3 (default) bin-packed per CU when the launch is a single
- *                            round of workgroups, 2 every other tier of n_cu items reversed (snake),
- *                            1 plain | 0: positional order (waves then search their line ranges themselves) |
- *                            4: as 3, but a launch of several rounds gives every XCD (workgroup i runs on XCD
- *                            i mod 8, each with its own L2) 8 contiguous chunks of the tile sequence, each
- *                            chunk list longest-first: K2's HBM fetch drops from 110 MB to 28 MB on the
- *                            100-2500 cm^-1 cell, its time rises 3 % (the XCDs no longer sample the same
- *                            cost distribution) - the kernel is not bound by that traffic
+ *                            decreasing cost: 3 bin-packed per CU when the launch is a single round of
+ *                            workgroups, 2 every other tier of n_cu items reversed (snake), 1 plain |
+ *                            0: positional order (waves then search their line ranges themselves) |
+ *                            4 (default): as 3, and a launch of several rounds is XCD-partitioned: workgroup
+ *                            i runs on XCD i mod 8, each XCD has its own L2, so every XCD gets 32 contiguous
+ *                            chunks of the tile sequence (dealt round-robin, equal estimated cost), each
+ *                            XCD's list longest-first - K2 fetches 33 MB instead of 110 MB on the
+ *                            100-2500 cm^-1 cell at the same kernel time
  *   "accum_tile_order"       positional order only: 1 (default) natural | 0 one contiguous run of
  *                            tiles per XCD | 2 golden-ratio stride
  *   "accum_blocks_per_cu"    variant 4 only: resident workgroups per CU, 0 = ask the runtime
