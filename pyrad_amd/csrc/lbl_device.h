@@ -43,8 +43,8 @@ static_assert(sizeof(HotRec) == 32 && sizeof(ColdRec) == 32, "record halves must
 enum : int32_t {
     REC_DIRECT_DIV = 1,   // Lorentz denominator outside the running-fraction range: plain divide
     REC_NO_RECUR = 2,     // Gaussian too narrow for the two-exp recurrence (b > 4): one exp per point
-    REC_LONG_RUN = 4      // Gaussian wide enough for the 16-point runs of the transposed pass: over every offset
-                          // at which the term can matter on a span (|d| <= dgi + 272) exp(-b d^2) stays a normal number
+    REC_LONG_RUN = 4      // Gaussian wide enough (b <= 1.5) for the 16-point runs of the transposed pass: a run that
+                          // starts from an underflowed seed cannot reach a point where the term still matters
 };
 
 // One accumulate job = one isotopologue of one layer (Isotope.createCrossSection).

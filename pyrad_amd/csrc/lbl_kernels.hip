@@ -203,9 +203,13 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
         // narrower profiles take one exp per point
         rc.q2 = (rc.b <= 4.0) ? exp(-2.0 * rc.b) : -1.0;
         if (!(rc.b <= 4.0)) r.flags |= REC_NO_RECUR;
-        // 16-point runs (gauss_runs16): a lane may start up to 272 points beyond the cut-off and walks 15
-        // steps; the recurrence is exact only while its seed is a normal number
-        { const double far = (double)r.dgi + 272.0; if (rc.b <= 4.0 && rc.b * far * far < 600.0) r.flags |= REC_LONG_RUN; }
+        // 16-point runs (gauss_runs16): a lane walks 15 steps from its first point, possibly TOWARDS the centre.
+        // If its seed exp(-b d0^2) has underflowed (b d0^2 > 700) the run's values stay 0; that is harmless as
+        // long as no point of the run can matter: the nearest one has b d^2 > b (sqrt(700/b) - 15)^2, which
+        // exceeds the 45 beyond which the term is below 2^-54 of the line's Lorentz part whenever b < 1.73.
+        // (Seeds that are tiny but normal keep the recurrence exact; a clamped r only lowers a value that is
+        // negligible anyway.)
+        if (rc.b <= 1.5) r.flags |= REC_LONG_RUN;
         rc.KLd = r.KL;
         J.hot[i] = r;
         J.cold[i] = rc;
@@ -596,9 +600,11 @@ __device__ __forceinline__ int span_slot(int o) { return o + (o >> 4); }
 // g(d+1) = g(d) r(d), r(d+1) = r(d) q2: two exp per 16 points instead of per 4 (25 instead of 51 wave
 // instructions per record).  Sums go to G[16] per lane (point 16t+k of the span, partial over this
 // group's records); gauss_runs16_fold adds the four groups' partial sums to the owners of the points
-// in a fixed order.  Only interior lines (no masking) flagged REC_LONG_RUN by K1 come here.
+// in a fixed order.  Lines flagged REC_LONG_RUN by K1 come here; MASKED for those whose support ends
+// inside the span.
+template <bool MASKED>
 __device__ __forceinline__ void gauss_runs16(const double* __restrict__ lh, const double* __restrict__ lc,
-                                             unsigned long long m, double xrun, int lane, double (&G)[16]) {
+                                             unsigned long long m, double xrun, double Hf, int lane, double (&G)[16]) {
     const int q = lane >> 4;
     while (m) {
         const int j0 = __builtin_ctzll(m); m &= m - 1;
@@ -615,7 +621,8 @@ __device__ __forceinline__ void gauss_runs16(const double* __restrict__ lh, cons
         double rr = exp_clamped(fmin(-b * (2.0 * d0 + 1.0), 700.0));
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            G[k] += g;
+            if (MASKED) G[k] += (fabs(d0 + (double)k) <= Hf) ? g : 0.0;      // support ends inside the span (cls:394)
+            else G[k] += g;
             g *= rr;
             rr *= q2;
         }
@@ -642,7 +649,7 @@ __device__ __forceinline__ void gauss_runs16_fold(const double (&G)[16], double*
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int R, bool LONGG = false>
+template <int R, int LONGG = 0>
 __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, const double* __restrict__ lc,
                                              unsigned long long gmask, unsigned long long emask,
                                              unsigned long long dmask, unsigned long long imask, double x0, double Hf,
@@ -652,8 +659,12 @@ __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, cons
     // imask bit j: record j is an interior line (every point of the wave inside its support): no masking
     // lmask bit j: record j may take the transposed 16-point runs (LONGG kernels, R = 4)
     if (LONGG && R == 4) {
-        const unsigned long long ml = gmask & ~emask & imask & lmask;
-        if (ml) gauss_runs16(lh, lc, ml, xrun, lane, G16);
+        // LONGG 1: interior lines only (far-field kernel: its spans see few masked Gaussian records, and the
+        // masked instantiation costs it 1 % in registers and code); 2: masked ones too (all-direct kernel,
+        // i.e. the narrow-window layers of a column, where most records end inside the span)
+        const unsigned long long ml = gmask & ~emask & lmask & (LONGG >= 2 ? ~0ull : imask);
+        if (ml & imask) gauss_runs16<false>(lh, lc, ml & imask, xrun, Hf, lane, G16);
+        if (LONGG >= 2 && (ml & ~imask)) gauss_runs16<true>(lh, lc, ml & ~imask, xrun, Hf, lane, G16);
         gmask &= ~ml;
     }
     unsigned long long m = gmask & ~emask & imask;
@@ -703,7 +714,7 @@ __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, cons
 // Lines below iB or from iC on end inside the wave's span and are masked per point.
 // The wave streams the records in chunks of 64 through its own LDS (lh: hot halves, lc: cold
 // halves), with the next chunk's loads in flight while the current one is consumed.
-template <int R, bool LONGG = false>
+template <int R, int LONGG = 0>
 __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRec* cold, int mA, int mD, int iB, int iC,
                                                  int wlo, int whi, double x0, double Hf, double* lh, double* lc, int lane,
                                                  WaveAcc<R>& S, double (&G16)[16], int stride = 64, int step = 1, int phase = 0) {
@@ -898,7 +909,7 @@ __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             double unused[16];
-            chunk_extras<R, false>(lh, lc, gmask, emask, 0ull, ~0ull, x0, Hf, S, 0ull, 0.0, lane, unused);
+            chunk_extras<R, 0>(lh, lc, gmask, emask, 0ull, ~0ull, x0, Hf, S, 0ull, 0.0, lane, unused);
             __builtin_amdgcn_wave_barrier();
         }
         const double dl = w0.x - xc;
@@ -1002,7 +1013,7 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         double G[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) G[k] = 0.0;
-        accumulate_lines<R, true>(J.hot, J.cold, iA + part * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64 * LS);
+        accumulate_lines<R, 2>(J.hot, J.cold, iA + part * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64 * LS);
         if (R == 4) gauss_runs16_fold<R>(G, s_stage[wave], lane, S.acc);
         S.flush();
     }
@@ -1043,10 +1054,10 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         double G[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) G[k] = 0.0;
-        accumulate_lines<R, true>(J.hot, J.cold, iA, any_far ? iB : iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+        accumulate_lines<R, 1>(J.hot, J.cold, iA, any_far ? iB : iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
         if (any_far) {
-            accumulate_lines<R, true>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
-            accumulate_lines<R, true>(J.hot, J.cold, iC, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+            accumulate_lines<R, 1>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+            accumulate_lines<R, 1>(J.hot, J.cold, iC, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
         }
         if (R == 4) gauss_runs16_fold<R>(G, s_stage[wave], lane, S.acc);
         S.flush();
@@ -1203,7 +1214,7 @@ __global__ __launch_bounds__(256, (R >= 8 ? 4 : 1)) void xsec_accumulate_balance
         WaveAcc<R> S;
         S.init(J.flush_every);
         double unused[16];
-        accumulate_lines<R, false>(J.hot, J.cold, r.iA + off, r.iA + off + piece, r.iB, r.iC, wlo, whi, x0, Hf, lh, lc, lane, S, unused);
+        accumulate_lines<R, 0>(J.hot, J.cold, r.iA + off, r.iA + off + piece, r.iB, r.iC, wlo, whi, x0, Hf, lh, lc, lane, S, unused);
         S.flush();
         // coalesced store through LDS: whole spans straight to the output, partial ones to the slab
         __builtin_amdgcn_wave_barrier();
