@@ -208,8 +208,9 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
         // long as no point of the run can matter: the nearest one has b d^2 > b (sqrt(700/b) - 15)^2, which
         // exceeds the 45 beyond which the term is below 2^-54 of the line's Lorentz part whenever b < 1.73.
         // (Seeds that are tiny but normal keep the recurrence exact; a clamped r only lowers a value that is
-        // negligible anyway.)
-        if (rc.b <= 1.5) r.flags |= REC_LONG_RUN;
+        // negligible anyway.)  Pure-Gaussian lines (no Lorentz part to be negligible against: their term counts
+        // until it underflows) keep the 4-point pass.
+        if (rc.b <= 1.5 && KL != 0.0) r.flags |= REC_LONG_RUN;
         rc.KLd = r.KL;
         J.hot[i] = r;
         J.cold[i] = rc;
