@@ -66,3 +66,22 @@ def test_product_code_never_imports_the_oracle():
     body_cpu = bench[bench.index("def cpu_baseline"):bench.index("def main")]
     body_chk = bench[bench.index("def oracle_check"):]
     assert len(uses) == body_cpu.count("from oracle import") + body_chk.count("from oracle import")
+
+
+def test_header_is_valid_c99_and_a_plain_c_host_links(tmp_path):
+    """include/pyrad_hip.h is a C header (the boundary has no C++ in it): examples/abi_smoke.c compiles with
+    gcc -std=c99 -pedantic, links against the shared library, and - without a GPU - reports the missing device
+    through the status code instead of computing anything."""
+    import subprocess
+    src = os.path.join(REPO, "examples", "abi_smoke.c")
+    exe = str(tmp_path / "abi_smoke")
+    lib_dir = os.path.join(REPO, "pyrad_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(REPO, "include"),
+                           src, "-L", lib_dir, "-lpyrad_hip", "-Wl,-rpath," + lib_dir, "-lm", "-o", exe])
+    from pyrad_amd import _native
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if _native.device_count() > 0:
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "rel err" in p.stdout and "0/0/1" in p.stdout and "[4502..5498]" in p.stdout
+    else:
+        assert p.returncode == 77 and "no HIP device" in p.stderr
