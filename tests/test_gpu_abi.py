@@ -187,3 +187,18 @@ def test_sweep_divisions_are_ieee_exact(ctx):
         assert np.array_equal(k_col.download(n), k_ref), (T, P)
         for b in bufs + [k_dev, t_dev, out, k_col]:
             b.free()
+
+
+def test_plain_c_host_reproduces_the_reference_peak(tmp_path):
+    """examples/abi_smoke.c (gcc -std=c99, no Python, no C++): one CO2-like line through lbl_xsec_accumulate;
+    the peak equals the reference's measured value 4.5462648814858876e-20 to 1e-12, the line
+    is counted in the pseudo-Voigt regime and its support is [4502..5498]."""
+    import os, subprocess
+    from conftest import REPO
+    exe = str(tmp_path / "abi_smoke")
+    lib_dir = os.path.join(REPO, "pyrad_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "examples", "abi_smoke.c"),
+                           "-L", lib_dir, "-lpyrad_hip", "-Wl,-rpath," + lib_dir, "-lm", "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "0/0/1" in p.stdout and "[4502..5498]" in p.stdout
