@@ -43,7 +43,7 @@ static_assert(sizeof(HotRec) == 32 && sizeof(ColdRec) == 32, "record halves must
 enum : int32_t {
     REC_DIRECT_DIV = 1,   // Lorentz denominator outside the running-fraction range: plain divide
     REC_NO_RECUR = 2,     // Gaussian too narrow for the two-exp recurrence (b > 4): one exp per point
-    REC_LONG_RUN = 4      // Gaussian wide enough (b <= 1.5) for the 16-point runs of the transposed pass: a run that
+    REC_LONG_RUN = 4      // Gaussian wide enough (b <= 1) for the 16-point runs of the transposed pass: a run that
                           // starts from an underflowed seed cannot reach a point where the term still matters
 };
 

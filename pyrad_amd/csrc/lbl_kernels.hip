@@ -204,13 +204,14 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
         rc.q2 = (rc.b <= 4.0) ? exp(-2.0 * rc.b) : -1.0;
         if (!(rc.b <= 4.0)) r.flags |= REC_NO_RECUR;
         // 16-point runs (gauss_runs16): a lane walks 15 steps from its first point, possibly TOWARDS the centre.
-        // If its seed exp(-b d0^2) has underflowed (b d0^2 > 700) the run's values stay 0; that is harmless as
-        // long as no point of the run can matter: the nearest one has b d^2 > b (sqrt(700/b) - 15)^2, which
-        // exceeds the 45 beyond which the term is below 2^-54 of the line's Lorentz part whenever b < 1.73.
-        // (Seeds that are tiny but normal keep the recurrence exact; a clamped r only lowers a value that is
-        // negligible anyway.)  Pure-Gaussian lines (no Lorentz part to be negligible against: their term counts
-        // until it underflows) keep the 4-point pass.
-        if (rc.b <= 1.5 && KL != 0.0) r.flags |= REC_LONG_RUN;
+        // If its seed KG exp(-b d0^2) has underflowed (b d0^2 > T, T = 745 - ln(1/KG) >= ~600 for any KG down
+        // to 1e-60) the run's values stay 0; that is harmless as long as no point of the run can matter: the
+        // nearest one has b d^2 > b (sqrt(T/b) - 15)^2, which exceeds the 45 beyond which the term is below
+        // 2^-54 of the line's Lorentz part whenever sqrt(b) < (sqrt(600) - sqrt(45)) / 15 = 1.19.  b <= 1
+        // (profiles at least one grid point wide) keeps a margin.  (Seeds that are tiny but normal keep the
+        // recurrence exact; a clamped r only lowers a value that is negligible anyway.)  Pure-Gaussian lines
+        // (no Lorentz part to be negligible against: their term counts until it underflows) keep the 4-point pass.
+        if (rc.b <= 1.0 && KL != 0.0) r.flags |= REC_LONG_RUN;
         rc.KLd = r.KL;
         J.hot[i] = r;
         J.cold[i] = rc;
