@@ -12,6 +12,13 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build the HIP library (hipcc
+    # cross-compiles without a GPU) and the C oracle once, as __graft_entry__.build() does
+    from pyrad_amd import _native
+    if not os.path.isfile(_native.LIB_PATH):
+        _native.build()
+    from oracle import c_oracle
+    c_oracle.build()
 
 
 def load_golden(name):
