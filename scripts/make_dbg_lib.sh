@@ -20,7 +20,8 @@ if head not in s:
 assert head in s
 s = s.replace(head, "__device__ unsigned long long g_dbg[4 * 65536 * 3];\n\n" + head, 1)
 s = s.replace("    int job = blockIdx.y, tile;\n", "    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();\n    int job = blockIdx.y, tile;\n", 1)
-marker = """                if (J.fuse.on) fused_sweep_point(J.fuse, wlo + o, t);
+marker = """                    fused_finish(J.fuse, wlo + o, kk);
+                }
             }
         }
     }
