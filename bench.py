@@ -503,6 +503,28 @@ def main():
         ctx.set_option("accum_variant", 5)
     ctx.profile_enable(False)
 
+    # With a communicator: where the sharded step's time goes, in two short untimed passes (every rank runs
+    # them in lockstep): the kernels of a step without the all-gather, and the all-gather alone, in stream.
+    # The pipelined step of the timed region cannot be faster than the longer of the two.
+    breakdown_local = None
+    if comm is not None:
+        n_b = max(5, min(20, args.steps))
+        barrier()
+        t_b = time.perf_counter()
+        for _ in range(n_b):
+            layers[0].enqueue(**step_kwargs)
+        barrier()
+        t_compute = (time.perf_counter() - t_b) / n_b
+        t_b = time.perf_counter()
+        for _ in range(n_b):
+            if is_column:
+                layers[0].enqueue_allgather(comm)
+            else:
+                layers[0].enqueue_allgather(comm, gather_bufs(layers[0]))
+        barrier()
+        t_gather = (time.perf_counter() - t_b) / n_b
+        breakdown_local = (t_compute, t_gather)
+
     # max over ranks of the elapsed time, sum over ranks of the evals — through the one comm
     evals_local = float(layer.evals)
     if comm is not None:
@@ -514,8 +536,20 @@ def main():
         evals_all = red.download(world)
         elapsed_max = float(times.max())
         evals_total = float(evals_all.sum())
+        per_rank = []
+        for v in breakdown_local:
+            red.upload(np.array([v], dtype=np.float64), offset=rank)
+            comm.allgather_dev(red, rank, 1, red)
+            per_rank.append(red.download(world).copy())
+        breakdown = {"kernels_only_ms_per_step": float(per_rank[0].max()) * 1e3,
+                     "kernels_only_ms_by_rank": [round(float(v) * 1e3, 4) for v in per_rank[0]],
+                     "allgather_alone_ms_per_step": float(per_rank[1].max()) * 1e3,
+                     "what": "two short untimed passes after the timed region, wall clock between barriers, max over "
+                             "ranks: the step's kernels with no all-gather, and the step's all-gather(s) alone in stream "
+                             "(%s); the pipelined step overlaps the two" % ("outgoing spectrum" if is_column else args.gather)}
     else:
         elapsed_max, evals_total = elapsed, evals_local
+        breakdown = None
 
     result = None
     if rank == 0:
@@ -591,6 +625,8 @@ def main():
                                    "allgather": ms_ag / args.steps},
             "setup_s": t_setup,
         }
+        if breakdown is not None:
+            result["sharded_step_breakdown"] = breakdown
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(cfg["layers"][0] if is_column else cfg, args.cpu_seconds)
         if args.check:

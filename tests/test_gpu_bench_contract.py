@@ -55,6 +55,8 @@ def test_default_contract():
 def test_forced_single_rank_communicator_pipeline():
     d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--workload", "C1"], {"PYRAD_FORCE_COMM": "1"})
     assert d["config"]["allgather"].startswith("overlapped") and d["value"] > 0
+    bd = d["sharded_step_breakdown"]       # what an N > 1 line carries: kernels without the gather, the gather alone
+    assert bd["kernels_only_ms_per_step"] > 0 and bd["allgather_alone_ms_per_step"] > 0 and len(bd["kernels_only_ms_by_rank"]) == 1
     d2 = run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--workload", "C1", "--no-overlap"],
                    {"PYRAD_FORCE_COMM": "1"})
     assert d2["config"]["allgather"] == "in-stream" and d2["kernel_ms_per_step"]["allgather"] > 0
@@ -87,6 +89,8 @@ def test_sharded_step_with_the_communicator_pipeline(shards):
     assert d["config"]["allgather"].startswith("overlapped") and d["value"] > 1e12
     b = d["config"]["shard_bounds"]
     assert len(b) == 8 and sum(c for _, c in b) == 2400000 and d["config"]["grid_points_per_gpu"] == b[3][1]
+    bd = d["sharded_step_breakdown"]
+    assert 0.03 < bd["kernels_only_ms_per_step"] < 0.2 and 0 < bd["allgather_alone_ms_per_step"] < 0.2
     d2 = run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-api-path", "--shard-of", "8,3",
                     "--shards", shards, "--no-overlap", "--gather", "all"], {"PYRAD_FORCE_COMM": "1"})
     assert d2["config"]["allgather"] == "in-stream" and d2["kernel_ms_per_step"]["allgather"] > 0
