@@ -206,6 +206,61 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
+class _Contexts:
+    """The contexts of this rank: one per step in flight (each has its own HIP stream, scratch arenas and
+    resident line lists); options and profiling apply to all of them, profile reads are summed."""
+
+    def __init__(self, ctxs):
+        self.all = list(ctxs)
+        self.first = self.all[0]
+
+    def set_option(self, key, value):
+        for c in self.all:
+            c.set_option(key, value)
+
+    def sync(self):
+        for c in self.all:
+            c.sync()
+
+    def profile_enable(self, what):
+        for c in self.all:
+            c.profile_enable(what)
+
+    def profile_reset(self):
+        for c in self.all:
+            c.profile_reset()
+
+    def profile_reserve(self, n):
+        for c in self.all:
+            c.profile_reserve(n)
+
+    def profile_read(self):
+        out = {}
+        for c in self.all:
+            for name, (n_, ms_) in c.profile_read().items():
+                a = out.get(name, (0, 0.0))
+                out[name] = (a[0] + n_, a[1] + ms_)
+        return out
+
+    def close(self):
+        for c in self.all:
+            c.close()
+
+
+def steps_in_flight(requested: str, sharded: bool, point_lists: float, n_cu: int = 256) -> int:
+    """How many independent steps a rank keeps in flight (each on a HIP stream of its own).  A shard's
+    accumulate launch is a partial round of workgroups (879 for 1024 slots at 8 shards of C3): its tail runs
+    with 1-3 wavefronts per SIMD at 50-95 % of the fp64 rate, and K1 / the sweep leave the VALU idle; a
+    second step fills both (measured on one GPU, kernels only: a shard of 8 of C3 0.063 -> 0.052 -> 0.049 ms
+    per step with 1 / 2 / 3 in flight, of 4 0.104 -> 0.090 -> 0.086, of 2 0.176 -> 0.159 -> 0.158, of 8 of the
+    column 0.82 -> 0.72; with the all-gather pipeline beside them 2 beats 3: 0.0624 / 0.0638 at 8, 0.097 /
+    0.101 at 4).  auto: 1 for an unsharded grid (what BENCH measures: every kernel alone on the chip; the
+    whole C3 cell gains 2.7 % from a second step, C2 25 %), 2 for a shard."""
+    if requested != "auto":
+        return max(1, min(3, int(requested)))
+    return 2 if sharded else 1
+
+
 # ------------------------------------------------------------------------------------------
 # self-launch: `python bench.py --gpus N` without a launcher starts N ranks itself
 # ------------------------------------------------------------------------------------------
@@ -311,6 +366,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather", default="abs_coef", choices=["abs_coef", "all"])
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-gather in stream instead of pipelined")
+    ap.add_argument("--in-flight", default="auto", choices=["auto", "1", "2", "3"],
+                    help="independent steps in flight per rank, each on a HIP stream (context) of its own; auto: 1 for an "
+                         "unsharded grid, 2-3 for a shard (see steps_in_flight)")
     ap.add_argument("--check", action="store_true", help="also compare one shard against the oracle (slow)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -332,8 +390,38 @@ def main():
     if local_rank >= ndev:
         raise SystemExit("bench.py: rank %d (LOCAL_RANK %d) has no GPU of its own: %d device(s) visible, one process "
                          "per GPU is required" % (rank, local_rank, ndev))
-    ctx = nat.Context(local_rank)
-    info = ctx.device_info()
+    strong = not args.weak
+    cfg, desc = build_workload(args.workload, (1 if strong else world) * args.scale)
+    if world > 1:
+        desc += (" [fixed workload, grid sharded x%d]" % world) if strong else \
+                (" [grid grows with N: x%d]" % world)
+    if args.scale != 1:
+        desc += " [--scale %d: not a BASELINE configuration]" % args.scale
+    if args.lines is not None and args.workload == "C2":
+        from pyrad_amd import synthetic as _syn
+        cfg = _syn.config_c2(n_lines=args.lines, range_min=500, range_max=500 + 400 * world * args.scale, seed=2)
+        desc += " [--lines %d: not a BASELINE configuration]" % args.lines
+    if args.workload == "C5":
+        layer_cfgs = [dict(c, molecules=molecules_of(c)) for c in cfg["layers"]]
+    else:
+        mols = molecules_of(cfg)
+        layer_cfgs = [dict(cfg, molecules=mols)]
+    shard = None
+    shard_world, shard_rank = world, rank
+    if args.shard_of:
+        shard_world, shard_rank = (int(v) for v in args.shard_of.split(","))
+        desc += " [ONLY shard %d of %d: a one-GPU experiment, not a BASELINE configuration]" % (shard_rank, shard_world)
+    shard_choice = "none"
+    if shard_world > 1:
+        shard, shard_choice = engine.choose_shards(layer_cfgs, shard_world, shard_rank, args.shards)
+
+    # one context (HIP stream + scratch arenas) per step in flight
+    g0 = engine.layer_grid(layer_cfgs[0]["P"], layer_cfgs[0]["range_min"], layer_cfgs[0]["range_max"],
+                           layer_cfgs[0]["base_resolution"], layer_cfgs[0].get("dynamic_resolution", True))
+    n_lists = sum(len(m["isotopologues"]) for c in layer_cfgs for m in c["molecules"])
+    n_flight = steps_in_flight(args.in_flight, shard_world > 1, float(g0["n_work"]) * n_lists / shard_world)
+    ctx = _Contexts([nat.Context(local_rank) for _ in range(n_flight)])
+    info = ctx.first.device_info()
     if args.variant is not None:
         ctx.set_option("accum_variant", args.variant)
     if args.points_per_lane is not None:
@@ -354,42 +442,21 @@ def main():
         rdzv = dist.FileRendezvous(rank, world)
         with _StdoutToStderr():
             uid = rdzv.broadcast("rccl_unique_id", nat.Comm.unique_id() if rank == 0 else None)
-            comm = nat.Comm(ctx, uid, world, rank)
+            comm = nat.Comm(ctx.first, uid, world, rank)      # ONE communicator: it orders every collective against the context that owns the buffers
 
-    strong = not args.weak
-    cfg, desc = build_workload(args.workload, (1 if strong else world) * args.scale)
-    if world > 1:
-        desc += (" [fixed workload, grid sharded x%d]" % world) if strong else \
-                (" [grid grows with N: x%d]" % world)
-    if args.scale != 1:
-        desc += " [--scale %d: not a BASELINE configuration]" % args.scale
-    if args.lines is not None and args.workload == "C2":
-        from pyrad_amd import synthetic as _syn
-        cfg = _syn.config_c2(n_lines=args.lines, range_min=500, range_max=500 + 400 * world * args.scale, seed=2)
-        desc += " [--lines %d: not a BASELINE configuration]" % args.lines
     t_setup = time.perf_counter()
-    # With a communicator the steps are software-pipelined over two buffer sets: the all-gather of
-    # step k (communicator stream) overlaps the kernels of step k+1 (context stream, other set).
-    n_sets = 2 if (comm is not None and not args.no_overlap) else 1
+    # Resident sets: one per step in flight (set s on context s).  With a communicator and one step in
+    # flight the steps are still software-pipelined over two buffer sets of the one context: the all-gather
+    # of step k (communicator stream) overlaps the kernels of step k+1 (context stream, other set).
+    n_sets = n_flight if n_flight > 1 else (2 if (comm is not None and not args.no_overlap) else 1)
+    overlap_gather = comm is not None and not args.no_overlap
+    set_ctx = [ctx.all[i % n_flight] for i in range(n_sets)]
     if args.workload == "C5":
-        layer_cfgs = [dict(c, molecules=molecules_of(c)) for c in cfg["layers"]]
+        layers = [engine.ResidentColumn(c, layer_cfgs, cfg["surface_T"], shard=shard) for c in set_ctx]
     else:
-        mols = molecules_of(cfg)
-        layer_cfgs = [dict(cfg, molecules=mols)]
-    shard = None
-    shard_world, shard_rank = world, rank
-    if args.shard_of:
-        shard_world, shard_rank = (int(v) for v in args.shard_of.split(","))
-        desc += " [ONLY shard %d of %d: a one-GPU experiment, not a BASELINE configuration]" % (shard_rank, shard_world)
-    shard_choice = "none"
-    if shard_world > 1:
-        shard, shard_choice = engine.choose_shards(layer_cfgs, shard_world, shard_rank, args.shards)
-    if args.workload == "C5":
-        layers = [engine.ResidentColumn(ctx, layer_cfgs, cfg["surface_T"], shard=shard) for _ in range(n_sets)]
-    else:
-        layers = [engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"],
+        layers = [engine.ResidentLayer(c, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"],
                                        mols, cfg["base_resolution"], cfg.get("dynamic_resolution", True),
-                                       shard=shard) for _ in range(n_sets)]
+                                       shard=shard) for c in set_ctx]
     layer = layers[0]
     # setup also builds the host-side schedule of every resident set (dispatch order + per-span line
     # ranges, cached by the library per line lists and grid): one priming pass each, outside the
@@ -419,7 +486,7 @@ def main():
     t_setup = time.perf_counter() - t_setup
 
     # small device buffers for the RCCL barrier / max-over-ranks reduction
-    red = ctx.buffer(max(world, 1))
+    red = ctx.first.buffer(max(world, 1))
 
     def gather_bufs(L):
         return (L.abs_coef,) if args.gather == "abs_coef" else (L.abs_coef, L.trans, L.I_out)
@@ -428,8 +495,9 @@ def main():
 
     def barrier():
         if comm is not None:
-            comm.fence_dev(-1)
-            comm.allgather_dev(red, rank, 1, red)
+            comm.fence_dev(-1)          # every context's stream waits for its own outstanding gathers
+            ctx.sync()                  # ... and this rank's kernels and gathers are complete
+            comm.allgather_dev(red, rank, 1, red)        # cross-rank barrier
         ctx.sync()
 
     step_no = [0]
@@ -438,9 +506,9 @@ def main():
         k = step_no[0]
         step_no[0] += 1
         L = layers[k % n_sets]
-        if comm is not None and n_sets > 1:
-            comm.fence_dev(k % n_sets)          # the gather that last used this set (step k-2) is done
-        slot = (k % n_sets) if n_sets > 1 else None
+        if overlap_gather and n_sets > 1:
+            comm.fence_dev(k % n_sets)          # the gather that last used this set (step k - n_sets) is done
+        slot = (k % n_sets) if (overlap_gather and n_sets > 1) else None
         g = graphs[k % n_sets]
         if g is not None and not timed_kernels:
             g.launch()
@@ -475,7 +543,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
     prof = ctx.profile_read()
-    ctx.profile_enable(["line_prep", "regrid", "layer_sweep", "column_sweep"] + (["allgather"] if n_sets == 1 else []))
+    ctx.profile_enable(["line_prep", "regrid", "layer_sweep", "column_sweep"] + ([] if overlap_gather else ["allgather"]))
     ctx.profile_reset()
     n_extra = max(2, min(5, args.steps))
     for _ in range(n_extra):
@@ -511,8 +579,8 @@ def main():
         n_b = max(5, min(20, args.steps))
         barrier()
         t_b = time.perf_counter()
-        for _ in range(n_b):
-            layers[0].enqueue(**step_kwargs)
+        for i_b in range(n_b):
+            layers[i_b % n_sets].enqueue(**step_kwargs)
         barrier()
         t_compute = (time.perf_counter() - t_b) / n_b
         t_b = time.perf_counter()
@@ -545,8 +613,9 @@ def main():
                      "kernels_only_ms_by_rank": [round(float(v) * 1e3, 4) for v in per_rank[0]],
                      "allgather_alone_ms_per_step": float(per_rank[1].max()) * 1e3,
                      "what": "two short untimed passes after the timed region, wall clock between barriers, max over "
-                             "ranks: the step's kernels with no all-gather, and the step's all-gather(s) alone in stream "
-                             "(%s); the pipelined step overlaps the two" % ("outgoing spectrum" if is_column else args.gather)}
+                             "ranks: the step's kernels with no all-gather (%d step(s) in flight, as in the timed region), and "
+                             "the step's all-gather(s) alone in stream (%s); the pipelined step overlaps the two"
+                             % (n_flight, "outgoing spectrum" if is_column else args.gather)}
     else:
         elapsed_max, evals_total = elapsed, evals_local
         breakdown = None
@@ -582,7 +651,7 @@ def main():
             balg_sw = 8.0 * pts * (n_arrays * n_layers + 1 + (2 * n_layers if args.column_layer_arrays else 0))
             sweep_kernel = "column_step_kernel"
         t_sw = (ms_sw / max(n_sw, 1)) * 1e-3
-        standard = args.scale == 1 and args.lines is None and world == 1 and not args.shard_of and not args.unfused
+        standard = args.scale == 1 and args.lines is None and world == 1 and not args.shard_of and not args.unfused and n_flight == 1
         pmc = load_pmc(args.workload if standard else None, nat.source_hash())
         traffic = pmc["hbm"].get("xsec_accumulate_kernel")
         result = {
@@ -596,11 +665,14 @@ def main():
                        "gathered": args.gather, "device": info["name"], "preconditioning_s": args.precondition_seconds,
                        "shard_bounds": (None if layer.plan is None else [list(b) for b in layer.plan.bounds]),
                        "shards": shard_choice,
-                       "step_launch": ("kernel by kernel" if not args.graph else
+                       "step_launch": ("" if n_flight == 1 else "%d independent steps in flight, each on a HIP stream of its "
+                                       "own (ms_per_step is the timed region / steps, not a step's latency); " % n_flight) +
+                                      ("kernel by kernel" if not args.graph else
                                        "one hipGraph per step (K1, K2, sweep captured once); kernel by kernel in the steps "
                                        "that carry timing events"),
-                       "allgather": ("none" if comm is None else "in-stream" if n_sets == 1 else
-                                     "overlapped with the next step (2 buffer sets)")},
+                       "steps_in_flight": n_flight,
+                       "allgather": ("none" if comm is None else "in-stream" if not overlap_gather else
+                                     "overlapped with the next step (%d buffer sets)" % n_sets)},
             "roofline": {"bound": "hbm", "kernel": "xsec_accumulate_lds_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_stale": (pmc["stale"] if traffic is not None else None),

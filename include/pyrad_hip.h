@@ -302,7 +302,12 @@ int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int
  * (the next step, on OTHER buffers) overlap the transfer.  `slot` (0..3) names the completion
  * event; lbl_comm_fence_dev(comm, slot) makes the context stream wait (no host sync) for the
  * collective issued with that slot, slot -1 for all of them: call it before send/recv of that
- * collective are touched again.  Collectives run, in issue order, on a stream the communicator owns. */
+ * collective are touched again.  Collectives run, in issue order, on a stream the communicator owns.
+ * "The context stream" is the stream of the context that owns send/recv (both the same, any context of
+ * the communicator's device): several contexts of one process - independent steps in flight on streams
+ * of their own - share ONE communicator, whose order of collectives stays the same on every rank.  A
+ * slot belongs to the context that used it last; reusing it from another context before its fence is
+ * LBL_ERR_STATE. */
 int lbl_allgather_overlap_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count,
                               lbl_buffer* recv, int slot);
 int lbl_comm_fence_dev(lbl_comm* comm, int slot);

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box:
 #   gpurun -- 'bash profiles/collect.sh r02 C3'     (workloads: C1 C2 C3 C5)
-# writes gpurun_out/<tag>/..., which profiles/summarize.py turns into the committed summaries.
+# writes gpurun_out/<tag>/..., which profiles/summarize.py turns into the committed summaries
+# (gpurun_out/<tag>/final/: copy its files into profiles/).
 # Counters are collected in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass,
 # MI355X_MICROARCH.md "rocprofv3 PMC slots") and never together with the trace domains.
 set -e
@@ -16,5 +17,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$WORKLOAD -- 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$WORKLOAD -- python3 $CMD > $OUT/pmc_fetch_$WORKLOAD.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$WORKLOAD -- python3 $CMD > $OUT/pmc_write_$WORKLOAD.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_valu_$WORKLOAD -- python3 $CMD > $OUT/pmc_valu_$WORKLOAD.log 2>&1
-python3 $R/bench.py --steps 20 --warmup 3 --workload $WORKLOAD > $OUT/bench_$WORKLOAD.json 2> $OUT/bench_$WORKLOAD.err
-python3 $R/profiles/summarize.py $OUT $TAG $WORKLOAD
+# summaries first (pmc_traffic.json then carries this build's source hash), then the bench line that quotes them
+python3 $R/profiles/summarize.py $OUT $TAG $WORKLOAD > $OUT/summary_$WORKLOAD.txt
+python3 $R/bench.py --steps 20 --warmup 3 --workload $WORKLOAD > $R/profiles/${TAG}_${WORKLOAD}_bench.json 2> $OUT/bench_$WORKLOAD.err
+# everything to commit, where gpurun brings it back from
+mkdir -p $OUT/final
+cp $R/profiles/${TAG}_${WORKLOAD}_* $R/profiles/pmc_traffic.json $OUT/final/
+cat $R/profiles/${TAG}_${WORKLOAD}_kernel_stats.csv

@@ -554,12 +554,15 @@ class Comm:
         return buf.raw
 
     def allgather_dev(self, send: Buffer, send_offset: int, count: int, recv: Buffer, overlap_slot=None):
-        """In-stream all-gather, or (overlap_slot 0..3) one the context stream does not wait for."""
+        """In-stream all-gather, or (overlap_slot 0..3) one the context stream does not wait for.  "The
+        context" is the one that owns send and recv (any context of the communicator's device): errors are
+        reported there."""
+        owner = send.ctx
         if overlap_slot is None:
-            self.ctx.check(self.ctx.lib.lbl_allgather_dev(self.h, send.h, int(send_offset), int(count), recv.h))
+            owner.check(owner.lib.lbl_allgather_dev(self.h, send.h, int(send_offset), int(count), recv.h))
         else:
-            self.ctx.check(self.ctx.lib.lbl_allgather_overlap_dev(self.h, send.h, int(send_offset), int(count), recv.h,
-                                                                  int(overlap_slot)))
+            owner.check(owner.lib.lbl_allgather_overlap_dev(self.h, send.h, int(send_offset), int(count), recv.h,
+                                                            int(overlap_slot)))
 
     def fence_dev(self, slot: int = -1):
         """Context stream waits (no host sync) for the collective issued with ``slot`` (-1: all)."""

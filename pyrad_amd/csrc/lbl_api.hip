@@ -1554,4 +1554,5 @@ namespace lbl {
 int comm_fail(lbl_ctx* ctx, int code, const char* msg) { return fail(ctx, code, "%s", msg); }
 int ctx_device(lbl_ctx* ctx) { return ctx->device; }
 bool ctx_capturing(lbl_ctx* ctx) { return ctx->capturing; }
+lbl_ctx* buffer_ctx(lbl_buffer* buf) { return buf->ctx; }
 }  // namespace lbl

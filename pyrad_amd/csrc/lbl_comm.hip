@@ -21,6 +21,7 @@ namespace lbl {
 int comm_fail(lbl_ctx* ctx, int code, const char* msg);
 int ctx_device(lbl_ctx* ctx);
 bool ctx_capturing(lbl_ctx* ctx);
+lbl_ctx* buffer_ctx(lbl_buffer* buf);
 void* comm_prof_begin(lbl_ctx* ctx);
 void comm_prof_end(lbl_ctx* ctx, void* start);
 }
@@ -35,6 +36,9 @@ void comm_prof_end(lbl_ctx* ctx, void* start);
 // order on every rank.  The context stream and cstream are ordered with events only, so the
 // all-gather of step k can run while the kernels of step k+1 compute (lbl_allgather_overlap_dev
 // + lbl_comm_fence_dev); lbl_allgather_dev is the same path with the fence applied at once.
+// The stream a collective is ordered against is the stream of the context that OWNS its buffers
+// (any context of the communicator's device): several contexts - independent steps in flight on
+// streams of their own - share the one communicator and its one, rank-consistent, order of collectives.
 struct lbl_comm {
     lbl_ctx* ctx;
     ncclComm_t comm;
@@ -43,6 +47,7 @@ struct lbl_comm {
     hipEvent_t ready;      // context stream -> cstream: inputs of the collective are complete
     hipEvent_t done[4];    // cstream -> context stream: the collective issued with this slot has finished
     bool pending[4];       // a collective was issued with this slot since its last fence
+    lbl_ctx* owner[4];     // context whose stream waits at the slot's fence (the owner of the slot's buffers)
 };
 
 static_assert(sizeof(ncclUniqueId) <= LBL_UNIQUE_ID_BYTES, "unique id does not fit");
@@ -75,7 +80,7 @@ extern "C" int lbl_comm_create(lbl_ctx* ctx, const char id[LBL_UNIQUE_ID_BYTES],
     bool ok = hipStreamCreateWithFlags(&cm->cstream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&cm->ready, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 4; ++i) {
-        cm->done[i] = nullptr; cm->pending[i] = false;
+        cm->done[i] = nullptr; cm->pending[i] = false; cm->owner[i] = ctx;
         ok = ok && hipEventCreateWithFlags(&cm->done[i], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {
@@ -104,8 +109,13 @@ extern "C" int lbl_comm_destroy(lbl_comm* comm) try {
 static int allgather_impl(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count, lbl_buffer* recv,
                           int slot, bool fence_now) {
     if (!comm || !send || !recv) return lbl::comm_fail(comm ? comm->ctx : nullptr, LBL_ERR_BAD_ARG, "NULL argument");
-    lbl_ctx* ctx = comm->ctx;
+    lbl_ctx* ctx = lbl::buffer_ctx(send);            // the context whose stream produced the data
+    if (lbl::buffer_ctx(recv) != ctx) return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "send and recv belong to different contexts");
+    if (lbl::ctx_device(ctx) != lbl::ctx_device(comm->ctx))
+        return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "buffers live on another device than the communicator");
     if (slot < 0 || slot > 3) return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "slot must be 0..3");
+    if (comm->pending[slot] && comm->owner[slot] != ctx)
+        return lbl::comm_fail(ctx, LBL_ERR_STATE, "slot still carries an unfenced collective of another context");
     if (lbl::ctx_capturing(ctx))
         return lbl::comm_fail(ctx, LBL_ERR_STATE, "the all-gather stays outside a captured graph: end the capture first");
     int64_t ns = 0, nr = 0;
@@ -128,6 +138,7 @@ static int allgather_impl(lbl_comm* comm, lbl_buffer* send, int64_t send_offset,
     if (r != ncclSuccess) return lbl::comm_fail(ctx, LBL_ERR_RCCL, ncclGetErrorString(r));
     if (hipEventRecord(comm->done[slot], comm->cstream) != hipSuccess) return lbl::comm_fail(ctx, LBL_ERR_HIP, "hipEventRecord(done) failed");
     comm->pending[slot] = true;
+    comm->owner[slot] = ctx;
     if (fence_now) return lbl_comm_fence_dev(comm, slot);
     return LBL_OK;
 }
@@ -135,16 +146,16 @@ static int allgather_impl(lbl_comm* comm, lbl_buffer* send, int64_t send_offset,
 extern "C" int lbl_comm_fence_dev(lbl_comm* comm, int slot) try {
     if (!comm) return lbl::comm_fail(nullptr, LBL_ERR_BAD_ARG, "comm is NULL");
     if (slot < -1 || slot > 3) return lbl::comm_fail(comm->ctx, LBL_ERR_BAD_ARG, "slot must be -1 (all) or 0..3");
-    void* s = nullptr;
-    lbl_ctx_stream(comm->ctx, &s);
     for (int i = 0; i < 4; ++i) {
         if ((slot >= 0 && i != slot) || !comm->pending[i]) continue;
+        void* s = nullptr;
+        lbl_ctx_stream(comm->owner[i], &s);
         // Usually the collective of two steps ago has long finished: ask the host side first and put a wait
         // (a barrier packet, a few microseconds of the context stream) into the stream only if it has not
         if (hipEventQuery(comm->done[i]) != hipSuccess) {
             (void)hipGetLastError();                   // hipErrorNotReady is not an error here
             if (hipStreamWaitEvent((hipStream_t)s, comm->done[i], 0) != hipSuccess)
-                return lbl::comm_fail(comm->ctx, LBL_ERR_HIP, "stream ordering (done) failed");
+                return lbl::comm_fail(comm->owner[i], LBL_ERR_HIP, "stream ordering (done) failed");
         }
         comm->pending[i] = false;
     }
@@ -152,9 +163,10 @@ extern "C" int lbl_comm_fence_dev(lbl_comm* comm, int slot) try {
 } LBL_GUARD_END(comm ? comm->ctx : nullptr)
 
 extern "C" int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count, lbl_buffer* recv) try {
-    void* ev = comm ? lbl::comm_prof_begin(comm->ctx) : nullptr;
+    lbl_ctx* pctx = (comm && send) ? lbl::buffer_ctx(send) : nullptr;
+    void* ev = pctx ? lbl::comm_prof_begin(pctx) : nullptr;
     int rc = allgather_impl(comm, send, send_offset, count, recv, 3, true);
-    if (comm) lbl::comm_prof_end(comm->ctx, ev);
+    if (pctx) lbl::comm_prof_end(pctx, ev);
     return rc;
 } LBL_GUARD_END(comm ? comm->ctx : nullptr)
 

@@ -19,27 +19,46 @@ import bench  # noqa: E402
 from pyrad_amd import _native as nat, engine  # noqa: E402
 
 
-def time_steps(ctx, obj, is_column, steps, budget_s=1.5):
-    step = (lambda: obj.enqueue(layer_arrays=False)) if is_column else (lambda: obj.enqueue(surface_T=288.0))
-    step(); ctx.sync()
+def time_steps(ctxs, objs, is_column, steps, budget_s=1.5):
+    """objs[i] lives on ctxs[i]: len(objs) independent steps in flight, dealt round-robin"""
+    kw = dict(layer_arrays=False) if is_column else dict(surface_T=288.0)
+    n = [0]
+
+    def step():
+        objs[n[0] % len(objs)].enqueue(**kw)
+        n[0] += 1
+
+    def sync():
+        for c in ctxs:
+            c.sync()
+    for _ in objs:
+        step()
+    sync()
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.2:                 # clocks
         step()
-    ctx.sync()
+    sync()
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
-        ctx.sync()
+        sync()
         best = min(best, (time.perf_counter() - t0) / steps)
     return best * 1e3
 
 
 def main():
     workloads = [w for w in sys.argv[1:] if w in ("C2", "C3", "C5")] or ["C3", "C5"]
-    ctx = nat.Context(0)
-    out = {"device": ctx.device_info()["name"], "unit": "ms per step (K1 + K2 with the sweep folded in; C5: + column step)", "rows": []}
+    in_flight = 1
+    for a in sys.argv[1:]:
+        if a.startswith("--in-flight="):
+            in_flight = int(a.split("=")[1])
+    ctxs = [nat.Context(0) for _ in range(in_flight)]
+    ctx = ctxs[0]
+    out = {"device": ctx.device_info()["name"], "steps_in_flight_sharded": in_flight,
+           "unit": "ms per step (K1 + K2 + sweep; C5: + column step); t_full with ONE step in flight (what N = 1 runs), "
+                   "shards with steps_in_flight_sharded", "rows": []}
     for wl in workloads:
         cfg, desc = bench.build_workload(wl, 1)
         is_column = wl == "C5"
@@ -49,14 +68,14 @@ def main():
             layer_cfgs = [dict(cfg, molecules=bench.molecules_of(cfg))]
         steps = 20 if is_column else 100
 
-        def build(shard):
+        def build(shard, ctx=ctx):
             if is_column:
                 return engine.ResidentColumn(ctx, layer_cfgs, cfg["surface_T"], shard=shard)
             c = layer_cfgs[0]
             return engine.ResidentLayer(ctx, c["depth"], c["T"], c["P"], c["range_min"], c["range_max"], c["molecules"],
                                         c["base_resolution"], c.get("dynamic_resolution", True), shard=shard)
         full = build(None)
-        t_full = time_steps(ctx, full, is_column, steps)
+        t_full = time_steps([ctx], [full], is_column, steps)
         evals_full = full.evals
         full.free()
         print("%s full: %.4f ms" % (wl, t_full), file=sys.stderr)
@@ -66,10 +85,11 @@ def main():
                 for r in range(G):
                     plan = engine.balanced_shards(layer_cfgs, G, r) if mode == "balanced" else engine.as_plan((G, r), full.n)
                     bounds = plan.bounds
-                    part = build(plan)
-                    ts.append(time_steps(ctx, part, is_column, steps))
-                    ev += part.evals
-                    part.free()
+                    parts = [build(plan, c) for c in ctxs]
+                    ts.append(time_steps(ctxs, parts, is_column, steps))
+                    ev += parts[0].evals
+                    for part in parts:
+                        part.free()
                 row = dict(workload=wl, G=G, bounds=mode, t_full_ms=t_full, t_r_ms=ts, max_ms=max(ts), sum_ms=sum(ts),
                            predicted_speedup=t_full / max(ts), fixed_ms_per_step=(sum(ts) - t_full) / (G - 1),
                            imbalance=max(ts) / (sum(ts) / G), evals_match=bool(ev == evals_full),

@@ -93,3 +93,11 @@ def test_shard_plans_tile_the_grid():
     # more ranks than aligned blocks: some shards are empty, nothing is lost
     tiny = dist.balanced_plan(3000, 8, 7, dist.span_costs(np.array([10, 20, 2999]), 48, 3000))
     assert sum(k for _, k in tiny.bounds) == 3000 and sum(1 for _, k in tiny.bounds if k == 0) == 5
+
+
+def test_steps_in_flight_rule():
+    """One step in flight for an unsharded grid (the BENCH line: every kernel alone on the chip); a shard keeps 2."""
+    f = bench.steps_in_flight
+    assert f("auto", False, 7.2e6) == 1 and f("auto", False, 1e4) == 1
+    assert f("auto", True, 3.6e6) == 2 and f("auto", True, 0.9e6) == 2 and f("auto", True, 27e6) == 2
+    assert f("2", False, 7.2e6) == 2 and f("3", True, 1.0) == 3 and f("1", True, 1.0) == 1

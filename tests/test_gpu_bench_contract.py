@@ -94,6 +94,11 @@ def test_sharded_step_with_the_communicator_pipeline(shards):
     d2 = run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-api-path", "--shard-of", "8,3",
                     "--shards", shards, "--no-overlap", "--gather", "all"], {"PYRAD_FORCE_COMM": "1"})
     assert d2["config"]["allgather"] == "in-stream" and d2["kernel_ms_per_step"]["allgather"] > 0
+    assert d["config"]["steps_in_flight"] == 2 and "2 buffer sets" in d["config"]["allgather"]      # a shard: two steps in flight
+    d1 = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-api-path", "--shard-of", "8,3",
+                    "--shards", shards, "--in-flight", "1"], {"PYRAD_FORCE_COMM": "1"})
+    assert d1["config"]["steps_in_flight"] == 1 and "2 buffer sets" in d1["config"]["allgather"]
+    assert d1["config"]["evals_per_step"] == d["config"]["evals_per_step"]
     # the column takes the same route
     d3 = run_bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--workload", "C5", "--shard-of", "8,3",
                     "--shards", shards], {"PYRAD_FORCE_COMM": "1"})

@@ -361,6 +361,50 @@ def test_rccl_comm_single_rank_inplace_allgather_and_overlap(ctx):
     comm.free(); a.free(); b.free()
 
 
+def test_one_communicator_orders_collectives_of_two_contexts(ctx):
+    """Steps in flight on two contexts (two HIP streams) share ONE communicator: a collective is ordered
+    after the work on the stream of the context that owns its buffers, and the slot's fence makes THAT
+    stream wait.  A slot still pending for one context refuses another; mixed owners are an error."""
+    from pyrad_amd import _native as nat, engine
+    ctx2 = nat.Context(0)
+    comm = nat.Comm(ctx, nat.Comm.unique_id(), 1, 0)
+    cfg = synthetic.config_c1(n_lines=2000)
+    mol = cfg["molecules"][0]
+    sp = synthetic.SPECIES["co2"]
+    mols = [dict(conc=4e-4, isotopologues=[dict(lines=mol["lines"], molmass=sp["molmass"],
+                                                 q_T=synthetic.q_value("co2", cfg["T"]), q296=sp["q296"])])]
+    layers = [engine.ResidentLayer(c, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"], mols,
+                                   cfg["base_resolution"], True) for c in (ctx, ctx2)]
+    n = layers[0].g["n_work"]
+    outs = [c.buffer(n).fill(-1.0) for c in (ctx, ctx2)]
+    for rep in range(3):                                    # kernels of both contexts in flight, gathers overlapped
+        for i, L in enumerate(layers):
+            comm.fence_dev(i)
+            L.enqueue(surface_T=288.0)
+            comm.allgather_dev(L.abs_coef, 0, n, outs[i], overlap_slot=i)     # ordered after L's kernels on L's stream
+    comm.fence_dev(-1)
+    ref = layers[0].abs_coef.download(n)
+    assert np.all(ref > 0)
+    for i in range(2):
+        assert np.array_equal(outs[i].download(n), ref)     # download runs on the owner's stream, after its fence
+    # slot 0 pending for ctx: ctx2 may not take it over before the fence
+    comm.allgather_dev(layers[0].abs_coef, 0, n, outs[0], overlap_slot=0)
+    with pytest.raises(nat.LblError, match="another context"):
+        comm.allgather_dev(layers[1].abs_coef, 0, n, outs[1], overlap_slot=0)
+    comm.fence_dev(0)
+    comm.allgather_dev(layers[1].abs_coef, 0, n, outs[1], overlap_slot=0)
+    comm.fence_dev(0)
+    with pytest.raises(nat.LblError, match="different contexts"):
+        comm.allgather_dev(layers[0].abs_coef, 0, n, outs[1])
+    ctx.sync(); ctx2.sync()
+    comm.free()
+    for L in layers:
+        L.free()
+    for b in outs:
+        b.free()
+    ctx2.close()
+
+
 def test_resident_column_c5_shape_vs_oracle(ctx, orc):
     """BASELINE config 5 in miniature: a 5-layer column (P 1013 -> 10 mbar, so windows from
     W = 5000 down to 50 share one batch and get different launch shapes), H2O + CO2 + O3,
