@@ -247,18 +247,60 @@ class _Contexts:
             c.close()
 
 
-def steps_in_flight(requested: str, sharded: bool, point_lists: float, n_cu: int = 256) -> int:
+def partial_round(point_lists: float, n_cu: int = 256) -> bool:
+    """Is a step's accumulate launch at most about one round of workgroups (1024 points of one line list each,
+    4 resident per CU)?  879 for 1024 slots at 8 shards of C3, 782 for C2."""
+    return point_lists <= 1.05 * 4.0 * n_cu * 1024
+
+
+def steps_in_flight(requested: str, sharded: bool) -> int:
     """How many independent steps a rank keeps in flight (each on a HIP stream of its own).  A shard's
-    accumulate launch is a partial round of workgroups (879 for 1024 slots at 8 shards of C3): its tail runs
-    with 1-3 wavefronts per SIMD at 50-95 % of the fp64 rate, and K1 / the sweep leave the VALU idle; a
-    second step fills both (measured on one GPU, kernels only: a shard of 8 of C3 0.063 -> 0.052 -> 0.049 ms
-    per step with 1 / 2 / 3 in flight, of 4 0.104 -> 0.090 -> 0.086, of 2 0.176 -> 0.159 -> 0.158, of 8 of the
-    column 0.82 -> 0.72; with the all-gather pipeline beside them 2 beats 3: 0.0624 / 0.0638 at 8, 0.097 /
-    0.101 at 4).  auto: 1 for an unsharded grid (what BENCH measures: every kernel alone on the chip; the
-    whole C3 cell gains 2.7 % from a second step, C2 25 %), 2 for a shard."""
+    accumulate launch is a partial round of workgroups or a few rounds: its tail runs with 1-3 wavefronts per
+    SIMD at 50-95 % of the fp64 rate, and K1 / the sweep leave the VALU idle; a second step fills both.
+    Measured on one GPU, kernels only: a shard of 8 of C3 0.063 -> 0.052 -> 0.049 ms per step with 1 / 2 / 3
+    in flight, of 4 0.104 -> 0.090 -> 0.086, of 2 0.176 -> 0.159 -> 0.158, of 8 of the column 0.82 -> 0.72;
+    with the all-gather pipeline beside them 2 beats 3 (0.0624 / 0.0638 at 8, 0.097 / 0.101 at 4).
+    auto: 2 for a shard; 1 for an unsharded grid, so that an N = 1 line times every kernel alone on the chip and
+    agrees with its rocprofv3 summary (the profiler does not let launches of different streams overlap the
+    way they do unobserved); what more steps in flight give a small unsharded cell (C2 0.064 -> 0.046 ms,
+    C1 0.0176 -> 0.0125 with three) is reported by an extra leg of the line, `in_flight_leg`."""
     if requested != "auto":
         return max(1, min(3, int(requested)))
     return 2 if sharded else 1
+
+
+def in_flight_leg(cfg, n_flight=3, steps=200):
+    """Throughput of the same resident cell with n_flight independent steps in flight, each on a context (HIP
+    stream) of its own, dealt round-robin: an extra leg for cells whose accumulate launch is a partial round
+    of workgroups.  Same kernels, same results; not the line's `value`."""
+    from pyrad_amd import _native as nat, engine
+    mols = molecules_of(cfg)
+    ctxs = [nat.Context(int(os.environ.get("LOCAL_RANK", "0"))) for _ in range(n_flight)]
+    layers = [engine.ResidentLayer(c, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"], mols,
+                                   cfg["base_resolution"], cfg.get("dynamic_resolution", True)) for c in ctxs]
+
+    def run(n):
+        for k in range(n):
+            layers[k % n_flight].enqueue(surface_T=288.0)
+        for c in ctxs:
+            c.sync()
+    run(n_flight)
+    t_end = time.perf_counter() + 0.5
+    while time.perf_counter() < t_end:
+        run(30)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run(steps)
+        best = min(best, (time.perf_counter() - t0) / steps)
+    evals = float(layers[0].evals)
+    for L in layers:
+        L.free()
+    for c in ctxs:
+        c.close()
+    return {"steps_in_flight": n_flight, "ms_per_step": best * 1e3, "evals_per_s": evals / best,
+            "what": "the same cell with %d independent steps in flight on %d HIP streams (contexts), %d steps, best of 3: "
+                    "further steps fill the SIMDs that a partial round of workgroups leaves underused" % (n_flight, n_flight, steps)}
 
 
 # ------------------------------------------------------------------------------------------
@@ -362,13 +404,15 @@ def main():
     ap.add_argument("--no-direct-pass", action="store_true",
                     help="skip the extra untimed pass of the all-direct kernel (profiles/collect.sh: keeps the PMC passes "
                          "to the kernels of the timed path)")
-    ap.add_argument("--no-api-path", action="store_true", help="skip the pyrad_amd.model (drop-in API) timing leg")
+    ap.add_argument("--no-api-path", action="store_true",
+                    help="skip the extra legs after the timed region: the pyrad_amd.model (drop-in API) timing and, for small "
+                         "cells, the steps-in-flight throughput")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather", default="abs_coef", choices=["abs_coef", "all"])
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-gather in stream instead of pipelined")
     ap.add_argument("--in-flight", default="auto", choices=["auto", "1", "2", "3"],
                     help="independent steps in flight per rank, each on a HIP stream (context) of its own; auto: 1 for an "
-                         "unsharded grid, 2-3 for a shard (see steps_in_flight)")
+                         "unsharded grid, 2 for a shard (see steps_in_flight)")
     ap.add_argument("--check", action="store_true", help="also compare one shard against the oracle (slow)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -419,7 +463,8 @@ def main():
     g0 = engine.layer_grid(layer_cfgs[0]["P"], layer_cfgs[0]["range_min"], layer_cfgs[0]["range_max"],
                            layer_cfgs[0]["base_resolution"], layer_cfgs[0].get("dynamic_resolution", True))
     n_lists = sum(len(m["isotopologues"]) for c in layer_cfgs for m in c["molecules"])
-    n_flight = steps_in_flight(args.in_flight, shard_world > 1, float(g0["n_work"]) * n_lists / shard_world)
+    n_flight = steps_in_flight(args.in_flight, shard_world > 1)
+    small_cell = partial_round(float(g0["n_work"]) * n_lists / shard_world)
     ctx = _Contexts([nat.Context(local_rank) for _ in range(n_flight)])
     info = ctx.first.device_info()
     if args.variant is not None:
@@ -651,7 +696,7 @@ def main():
             balg_sw = 8.0 * pts * (n_arrays * n_layers + 1 + (2 * n_layers if args.column_layer_arrays else 0))
             sweep_kernel = "column_step_kernel"
         t_sw = (ms_sw / max(n_sw, 1)) * 1e-3
-        standard = args.scale == 1 and args.lines is None and world == 1 and not args.shard_of and not args.unfused and n_flight == 1
+        standard = args.scale == 1 and args.lines is None and world == 1 and not args.shard_of and not args.unfused
         pmc = load_pmc(args.workload if standard else None, nat.source_hash())
         traffic = pmc["hbm"].get("xsec_accumulate_kernel")
         result = {
@@ -680,11 +725,13 @@ def main():
                          "algorithmic_bytes_per_launch": balg_acc, "avg_launch_ms": t_acc * 1e3, "launches": n_acc,
                          "launches_timed": "every launch of every %d-th timed step (%d of %d steps)" % (every, n_sampled, args.steps),
                          "sweep_fused_in": bool(fused_sweep),
+                         "launches_overlap": n_flight > 1,
                          "note": "compulsory traffic only (56 B/line + 8 B/grid point per array written: one cross section "
                                  "per line list, + k, transmittance and radiance when the layer sweep is fused in). This "
                                  "kernel is fp64-VALU bound by construction (SURVEY.md §8d): valu_f64.busy_frac is its "
                                  "real utilisation figure"},
-            "valu_f64": valu_block(evals_local, t_acc_step, direct_ms, args.variant, pmc, launches_per_step),
+            "valu_f64": valu_block(evals_local, t_acc_step, direct_ms, args.variant, pmc, launches_per_step,
+                                   n_flight, elapsed_max / args.steps),
             "roofline_sweep": {"fused_into": "xsec_accumulate_lds_kernel (lbl_layer_step_dev)"} if n_sw == 0 and not is_column else
                               {"bound": "hbm", "kernel": sweep_kernel,
                                "achieved": balg_sw / t_sw / 1e9 if t_sw > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -718,6 +765,8 @@ def main():
     ctx.close()
     if want_api:
         result["api_path"] = api_path(cfg)
+        if small_cell and n_flight == 1:
+            result["in_flight_leg"] = in_flight_leg(cfg)
     if rank == 0:
         print(json.dumps(result))
 
@@ -726,7 +775,7 @@ SIMDS = 256 * 4
 CLOCK_HZ = 2.4e9
 
 
-def valu_block(evals_local, t_acc_step, direct_ms, variant, pmc, launches_per_step):
+def valu_block(evals_local, t_acc_step, direct_ms, variant, pmc, launches_per_step, n_flight=1, t_step=None):
     """fp64 vector-ALU accounting of K2.
     busy_frac: the kernel's measured VALU utilisation, SQ_INSTS_VALU (wave-instructions per launch,
     from the committed rocprofv3 --pmc pass of this very command) x 4 issue cycles per fp64/VALU
@@ -740,7 +789,15 @@ def valu_block(evals_local, t_acc_step, direct_ms, variant, pmc, launches_per_st
            "far_field_series": far_field, "instr_per_eval_direct": FP64_INSTR_PER_EVAL,
            "peak_lane_instr_per_s": FP64_VALU_PEAK_INSTR}
     insts = pmc["valu"].get("xsec_accumulate_kernel" if far_field else "xsec_accumulate_direct_kernel")
-    if insts and t_acc_step > 0:
+    if insts and t_acc_step > 0 and n_flight > 1 and t_step:
+        # launches of different steps overlap: a launch's own duration no longer says how busy the chip is.
+        # K2's VALU instructions of one step over the step time of the timed region (K1 / sweep not counted)
+        out.update({"busy_frac": insts * launches_per_step * 4.0 / (SIMDS * t_step * CLOCK_HZ),
+                    "valu_wave_insts_per_launch": insts, "busy_frac_stale": pmc["stale"],
+                    "busy_frac_source": "%s SQ_INSTS_VALU x %d launch(es) per step over the timed region's %.1f us per step "
+                                        "(%d steps in flight: kernel durations overlap)" % (
+                                            pmc["source"], launches_per_step, t_step * 1e6, n_flight)})
+    elif insts and t_acc_step > 0:
         t_launch = t_acc_step / launches_per_step
         out.update({"busy_frac": insts * 4.0 / (SIMDS * t_launch * CLOCK_HZ),
                     "valu_wave_insts_per_launch": insts, "busy_frac_stale": pmc["stale"],

@@ -96,8 +96,10 @@ def test_shard_plans_tile_the_grid():
 
 
 def test_steps_in_flight_rule():
-    """One step in flight for an unsharded grid (the BENCH line: every kernel alone on the chip); a shard keeps 2."""
+    """An unsharded grid is left alone on the chip (an N = 1 line times every kernel by itself); a shard keeps 2
+    steps in flight; small unsharded cells (partial round of workgroups) get the extra in-flight leg."""
     f = bench.steps_in_flight
-    assert f("auto", False, 7.2e6) == 1 and f("auto", False, 1e4) == 1
-    assert f("auto", True, 3.6e6) == 2 and f("auto", True, 0.9e6) == 2 and f("auto", True, 27e6) == 2
-    assert f("2", False, 7.2e6) == 2 and f("3", True, 1.0) == 3 and f("1", True, 1.0) == 1
+    assert f("auto", False) == 1 and f("auto", True) == 2
+    assert f("2", False) == 2 and f("3", True) == 3 and f("1", True) == 1
+    assert bench.partial_round(4e5) and bench.partial_round(1e4) and bench.partial_round(0.9e6)      # C2, C1, C3 / 8
+    assert not bench.partial_round(7.2e6) and not bench.partial_round(1.8e6)
