@@ -269,6 +269,67 @@ def steps_in_flight(requested: str, sharded: bool) -> int:
     return 2 if sharded else 1
 
 
+def gather_batch(requested: str, batchable: bool, steps_per_set: int = 0) -> int:
+    """Steps whose shards leave in ONE all-gather.  At 8 ranks a C3 shard is 2.4 MB and a step 0.05 ms: a
+    collective per step is dominated by its start-up (a ring of 7 hops) and runs far below the links' rate;
+    the shards of B consecutive steps of a resident set are staged side by side in a batch buffer (rank r,
+    step b at [(r B + b) S, +S)) and sent as one collective of B S doubles per rank - fewer, larger
+    collectives, same bytes.  Two batch buffers per set: the gather of one batch overlaps the steps that fill
+    the other.  With ONE rank forced through the communicator a shard of 8 of C3 steps in 0.0626 ms with a
+    collective per step and 0.0537 / 0.0528 / 0.0522 with B = 2 / 4 / 8 (kernels alone: 0.0523).
+    auto (where it applies: a communicator, the pipelined single-array gather): the B in 3..8 that leaves the
+    smallest partly filled batch at the end of the timed region (a flush sends the whole buffer), larger B
+    on a tie - 5 for the driver's 20 steps over two resident sets."""
+    if not batchable:
+        return 1
+    if requested != "auto":
+        return max(1, min(16, int(requested)))
+    if steps_per_set < 3:
+        return max(1, steps_per_set)
+    best = None
+    for b in range(3, 9):
+        waste = -(-steps_per_set // b) * b - steps_per_set
+        if best is None or waste <= best[0]:
+            best = (waste, b)
+    return best[1]
+
+
+class _Batch:
+    """The two batch buffers of one resident set: world * B * S doubles each, gathered in place."""
+
+    def __init__(self, ctx, comm, rank, world, S, B, slots):
+        self.comm, self.rank, self.S, self.B, self.slots = comm, rank, S, B, slots
+        self.bufs = [ctx.buffer(world * B * S).fill(0.0) for _ in range(2)]
+        self.cur, self.fill, self.sent = 0, 0, 0
+
+    def before_step(self):
+        if self.fill == 0:
+            self.comm.fence_dev(self.slots[self.cur])     # the gather that last read this buffer (two batches ago) is done
+
+    def stage(self, src, src_offset):
+        self.bufs[self.cur].stage_from_dev(src, src_offset, self.S, dst_offset=(self.rank * self.B + self.fill) * self.S)
+        self.fill += 1
+        if self.fill == self.B:
+            self.send()
+
+    def send(self, overlap=True):
+        """one all-gather for the whole batch buffer (a partial batch at a flush sends the full buffer too)"""
+        buf = self.bufs[self.cur]
+        self.comm.allgather_dev(buf, self.rank * self.B * self.S, self.B * self.S, buf,
+                                overlap_slot=self.slots[self.cur] if overlap else None)
+        self.cur ^= 1
+        self.fill = 0
+        self.sent += 1
+
+    def flush(self):
+        if self.fill:
+            self.send()
+
+    def free(self):
+        for b in self.bufs:
+            b.free()
+
+
 def in_flight_leg(cfg, n_flight=3, steps=200):
     """Throughput of the same resident cell with n_flight independent steps in flight, each on a context (HIP
     stream) of its own, dealt round-robin: an extra leg for cells whose accumulate launch is a partial round
@@ -410,6 +471,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--gather", default="abs_coef", choices=["abs_coef", "all"])
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-gather in stream instead of pipelined")
+    ap.add_argument("--gather-batch", default="auto",
+                    help="N > 1: steps of a resident set whose shards leave in ONE all-gather (fewer, larger collectives); auto: "
+                         "3..8 by the step count for the pipelined single-array gather, 1 = a collective per step")
     ap.add_argument("--in-flight", default="auto", choices=["auto", "1", "2", "3"],
                     help="independent steps in flight per rank, each on a HIP stream (context) of its own; auto: 1 for an "
                          "unsharded grid, 2 for a shard (see steps_in_flight)")
@@ -503,6 +567,10 @@ def main():
                                        mols, cfg["base_resolution"], cfg.get("dynamic_resolution", True),
                                        shard=shard) for c in set_ctx]
     layer = layers[0]
+    is_column = args.workload == "C5"
+    n_batch = gather_batch(args.gather_batch, overlap_gather and (is_column or args.gather == "abs_coef"), args.steps // n_sets)
+    batches = ([_Batch(set_ctx[i], comm, rank, world, layers[i].S, n_batch, (2 * i, 2 * i + 1)) for i in range(n_sets)]
+               if n_batch > 1 else None)
     # setup also builds the host-side schedule of every resident set (dispatch order + per-span line
     # ranges, cached by the library per line lists and grid): one priming pass each, outside the
     # timed region whatever --warmup is
@@ -536,10 +604,11 @@ def main():
     def gather_bufs(L):
         return (L.abs_coef,) if args.gather == "abs_coef" else (L.abs_coef, L.trans, L.I_out)
 
-    is_column = args.workload == "C5"
-
     def barrier():
         if comm is not None:
+            if batches:
+                for bt in batches:
+                    bt.flush()          # a partly filled batch leaves too (every rank is at the same step)
             comm.fence_dev(-1)          # every context's stream waits for its own outstanding gathers
             ctx.sync()                  # ... and this rank's kernels and gathers are complete
             comm.allgather_dev(red, rank, 1, red)        # cross-rank barrier
@@ -551,7 +620,10 @@ def main():
         k = step_no[0]
         step_no[0] += 1
         L = layers[k % n_sets]
-        if overlap_gather and n_sets > 1:
+        bt = batches[k % n_sets] if batches else None
+        if bt is not None:
+            bt.before_step()
+        elif overlap_gather and n_sets > 1:
             comm.fence_dev(k % n_sets)          # the gather that last used this set (step k - n_sets) is done
         slot = (k % n_sets) if (overlap_gather and n_sets > 1) else None
         g = graphs[k % n_sets]
@@ -559,7 +631,9 @@ def main():
             g.launch()
         else:
             L.enqueue(**step_kwargs)
-        if comm is not None:
+        if bt is not None:
+            bt.stage(L.I_toa if is_column else L.abs_coef, L.send_range()[0])      # the batch's B-th shard sends it
+        elif comm is not None:
             if is_column:
                 L.enqueue_allgather(comm, overlap_slot=slot)
             else:
@@ -622,6 +696,8 @@ def main():
     breakdown_local = None
     if comm is not None:
         n_b = max(5, min(20, args.steps))
+        if batches:
+            n_b = max(n_batch, n_b // n_batch * n_batch)       # whole batches
         barrier()
         t_b = time.perf_counter()
         for i_b in range(n_b):
@@ -629,14 +705,49 @@ def main():
         barrier()
         t_compute = (time.perf_counter() - t_b) / n_b
         t_b = time.perf_counter()
-        for _ in range(n_b):
-            if is_column:
-                layers[0].enqueue_allgather(comm)
-            else:
-                layers[0].enqueue_allgather(comm, gather_bufs(layers[0]))
+        if batches:
+            for _ in range(n_b // n_batch):
+                batches[0].send(overlap=False)                  # the collective of one batch, in stream
+        else:
+            for _ in range(n_b):
+                if is_column:
+                    layers[0].enqueue_allgather(comm)
+                else:
+                    layers[0].enqueue_allgather(comm, gather_bufs(layers[0]))
         barrier()
         t_gather = (time.perf_counter() - t_b) / n_b
         breakdown_local = (t_compute, t_gather)
+
+    # Batched gather: one more full batch per resident set, then every slot of the gathered buffer is checked on
+    # the host - this rank's own slots against its shard bit for bit, every rank's slots finite, positive over
+    # the rank's points (non-negative, not all zero) and identical from step to step (the steps repeat the same cell).  A mismatch is fatal.
+    gather_verified = None
+    if batches:
+        def shard_src(L):
+            return L.I_toa if is_column else L.abs_coef
+        for i, bt in enumerate(batches):
+            for _ in range(n_batch):
+                bt.before_step()
+                layers[i].enqueue(**step_kwargs)
+                bt.stage(shard_src(layers[i]), layers[i].send_range()[0])
+        barrier()
+        for i, bt in enumerate(batches):
+            L = layers[i]
+            S_ = L.S
+            a = bt.bufs[bt.cur ^ 1].download(world * n_batch * S_).reshape(world, n_batch, S_)
+            own = shard_src(L).download(S_, L.send_range()[0])
+            counts = [c for _, c in L.plan.bounds] if (L.plan is not None and L.plan.world == world) else [L.count] * world
+            good = bool(np.all(np.isfinite(a)))
+            for b in range(n_batch):
+                good = good and np.array_equal(a[rank, b], own)
+                for r in range(world):
+                    good = good and np.array_equal(a[r, b], a[r, 0])
+            for r in range(world):
+                x = a[r, 0, :counts[r]]
+                good = good and (x.size == 0 or bool(np.all(x >= 0.0) and np.any(x > 0.0)))
+            if not good:
+                raise SystemExit("bench.py: rank %d: the batched all-gather of resident set %d did not deliver the shards" % (rank, i))
+        gather_verified = True
 
     # max over ranks of the elapsed time, sum over ranks of the evals — through the one comm
     evals_local = float(layer.evals)
@@ -659,8 +770,9 @@ def main():
                      "allgather_alone_ms_per_step": float(per_rank[1].max()) * 1e3,
                      "what": "two short untimed passes after the timed region, wall clock between barriers, max over "
                              "ranks: the step's kernels with no all-gather (%d step(s) in flight, as in the timed region), and "
-                             "the step's all-gather(s) alone in stream (%s); the pipelined step overlaps the two"
-                             % (n_flight, "outgoing spectrum" if is_column else args.gather)}
+                             "the step's all-gather(s) alone in stream (%s%s); the pipelined step overlaps the two"
+                             % (n_flight, "outgoing spectrum" if is_column else args.gather,
+                                "" if not batches else ", one collective per %d steps, per step" % n_batch)}
     else:
         elapsed_max, evals_total = elapsed, evals_local
         breakdown = None
@@ -716,8 +828,11 @@ def main():
                                        "one hipGraph per step (K1, K2, sweep captured once); kernel by kernel in the steps "
                                        "that carry timing events"),
                        "steps_in_flight": n_flight,
+                       "gather_batch": n_batch, "gather_verified": gather_verified,
                        "allgather": ("none" if comm is None else "in-stream" if not overlap_gather else
-                                     "overlapped with the next step (%d buffer sets)" % n_sets)},
+                                     "overlapped with the next step (%d buffer sets)" % n_sets if not batches else
+                                     "one collective per %d steps of a resident set (shards staged side by side in a batch "
+                                     "buffer), overlapped with the steps that fill the set's other batch buffer" % n_batch)},
             "roofline": {"bound": "hbm", "kernel": "xsec_accumulate_lds_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_stale": (pmc["stale"] if traffic is not None else None),
@@ -754,6 +869,9 @@ def main():
     if rdzv is not None:
         rdzv.arrive("done")
         rdzv.cleanup()
+    if batches:
+        for bt in batches:
+            bt.free()
     if comm is not None:
         comm.free()
     for g_ in graphs:

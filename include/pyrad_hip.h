@@ -299,7 +299,7 @@ int lbl_comm_destroy(lbl_comm* comm);
 int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count,
                       lbl_buffer* recv);
 /* Same collective, but the context stream does not wait for it: kernels enqueued afterwards
- * (the next step, on OTHER buffers) overlap the transfer.  `slot` (0..3) names the completion
+ * (the next step, on OTHER buffers) overlap the transfer.  `slot` (0..6) names the completion
  * event; lbl_comm_fence_dev(comm, slot) makes the context stream wait (no host sync) for the
  * collective issued with that slot, slot -1 for all of them: call it before send/recv of that
  * collective are touched again.  Collectives run, in issue order, on a stream the communicator owns.
@@ -311,6 +311,11 @@ int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int
 int lbl_allgather_overlap_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count,
                               lbl_buffer* recv, int slot);
 int lbl_comm_fence_dev(lbl_comm* comm, int slot);
+/* Fewer, larger collectives: stage the shards of several consecutive steps side by side in one batch
+ * buffer (rank r, step b of B at [(r*B + b)*S, +S)) and send them with ONE all-gather of B*S doubles per
+ * rank.  This is the staging copy: dst[dst_offset .. +n) = src[src_offset .. +n), device to device, async
+ * on the stream of the context that owns dst. */
+int lbl_gather_stage_dev(lbl_buffer* dst, int64_t dst_offset, lbl_buffer* src, int64_t src_offset, int64_t n);
 /* Cost-balanced (unequal) shards: every rank sends `slot` doubles starting at its own first point,
  * so the gathered buffer holds rank r's shard in the first count[r] entries of slot r.  This puts
  * it back in grid order: out[first[r] + i] = gathered[r * slot + i], i < count[r], r < world_size

@@ -102,6 +102,7 @@ SIGNATURES = {
     "lbl_allgather_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "lbl_allgather_overlap_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int]),
     "lbl_comm_fence_dev": (C.c_int, [_P, C.c_int]),
+    "lbl_gather_stage_dev": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int64]),
     "lbl_capture_begin": (C.c_int, [_P]),
     "lbl_capture_end": (C.c_int, [_P, C.POINTER(_P)]),
     "lbl_graph_launch": (C.c_int, [_P]),
@@ -445,6 +446,12 @@ class Buffer:
         self.h = h
         ctx._children.append(self)
 
+    def stage_from_dev(self, src: "Buffer", src_offset: int, n: int, dst_offset: int = 0):
+        """self[dst_offset : dst_offset + n] = src[src_offset : src_offset + n], device to device, async on this
+        buffer's context stream (lbl_gather_stage_dev: staging shards into an all-gather batch buffer)."""
+        self.ctx.check(self.ctx.lib.lbl_gather_stage_dev(self.h, int(dst_offset), src.h, int(src_offset), int(n)))
+        return self
+
     def upload(self, data, offset: int = 0):
         a = _as_f64(data)
         self.ctx.check(self.ctx.lib.lbl_buffer_upload(self.h, _ptr(a), a.size, int(offset)))
@@ -554,7 +561,7 @@ class Comm:
         return buf.raw
 
     def allgather_dev(self, send: Buffer, send_offset: int, count: int, recv: Buffer, overlap_slot=None):
-        """In-stream all-gather, or (overlap_slot 0..3) one the context stream does not wait for.  "The
+        """In-stream all-gather, or (overlap_slot 0..6) one the context stream does not wait for.  "The
         context" is the one that owns send and recv (any context of the communicator's device): errors are
         reported there."""
         owner = send.ctx

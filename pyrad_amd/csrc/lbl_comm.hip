@@ -39,15 +39,16 @@ void comm_prof_end(lbl_ctx* ctx, void* start);
 // The stream a collective is ordered against is the stream of the context that OWNS its buffers
 // (any context of the communicator's device): several contexts - independent steps in flight on
 // streams of their own - share the one communicator and its one, rank-consistent, order of collectives.
+constexpr int kSlots = 8;        // 0..6 for overlapped collectives, 7 for the in-stream form
 struct lbl_comm {
     lbl_ctx* ctx;
     ncclComm_t comm;
     int world, rank;
     hipStream_t cstream;
     hipEvent_t ready;      // context stream -> cstream: inputs of the collective are complete
-    hipEvent_t done[4];    // cstream -> context stream: the collective issued with this slot has finished
-    bool pending[4];       // a collective was issued with this slot since its last fence
-    lbl_ctx* owner[4];     // context whose stream waits at the slot's fence (the owner of the slot's buffers)
+    hipEvent_t done[kSlots];    // cstream -> context stream: the collective issued with this slot has finished
+    bool pending[kSlots];       // a collective was issued with this slot since its last fence
+    lbl_ctx* owner[kSlots];     // context whose stream waits at the slot's fence (the owner of the slot's buffers)
 };
 
 static_assert(sizeof(ncclUniqueId) <= LBL_UNIQUE_ID_BYTES, "unique id does not fit");
@@ -79,7 +80,7 @@ extern "C" int lbl_comm_create(lbl_ctx* ctx, const char id[LBL_UNIQUE_ID_BYTES],
     cm->cstream = nullptr; cm->ready = nullptr;
     bool ok = hipStreamCreateWithFlags(&cm->cstream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&cm->ready, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kSlots; ++i) {
         cm->done[i] = nullptr; cm->pending[i] = false; cm->owner[i] = ctx;
         ok = ok && hipEventCreateWithFlags(&cm->done[i], hipEventDisableTiming) == hipSuccess;
     }
@@ -100,7 +101,7 @@ extern "C" int lbl_comm_destroy(lbl_comm* comm) try {
     (void)hipStreamSynchronize(comm->cstream);
     ncclCommDestroy(comm->comm);
     (void)hipEventDestroy(comm->ready);
-    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(comm->done[i]);
+    for (int i = 0; i < kSlots; ++i) if (comm->done[i]) (void)hipEventDestroy(comm->done[i]);
     (void)hipStreamDestroy(comm->cstream);
     delete comm;
     return LBL_OK;
@@ -113,7 +114,7 @@ static int allgather_impl(lbl_comm* comm, lbl_buffer* send, int64_t send_offset,
     if (lbl::buffer_ctx(recv) != ctx) return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "send and recv belong to different contexts");
     if (lbl::ctx_device(ctx) != lbl::ctx_device(comm->ctx))
         return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "buffers live on another device than the communicator");
-    if (slot < 0 || slot > 3) return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "slot must be 0..3");
+    if (slot < 0 || slot >= kSlots) return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "slot must be 0..6");
     if (comm->pending[slot] && comm->owner[slot] != ctx)
         return lbl::comm_fail(ctx, LBL_ERR_STATE, "slot still carries an unfenced collective of another context");
     if (lbl::ctx_capturing(ctx))
@@ -145,8 +146,8 @@ static int allgather_impl(lbl_comm* comm, lbl_buffer* send, int64_t send_offset,
 
 extern "C" int lbl_comm_fence_dev(lbl_comm* comm, int slot) try {
     if (!comm) return lbl::comm_fail(nullptr, LBL_ERR_BAD_ARG, "comm is NULL");
-    if (slot < -1 || slot > 3) return lbl::comm_fail(comm->ctx, LBL_ERR_BAD_ARG, "slot must be -1 (all) or 0..3");
-    for (int i = 0; i < 4; ++i) {
+    if (slot < -1 || slot >= kSlots) return lbl::comm_fail(comm->ctx, LBL_ERR_BAD_ARG, "slot must be -1 (all) or 0..6");
+    for (int i = 0; i < kSlots; ++i) {
         if ((slot >= 0 && i != slot) || !comm->pending[i]) continue;
         void* s = nullptr;
         lbl_ctx_stream(comm->owner[i], &s);
@@ -165,12 +166,38 @@ extern "C" int lbl_comm_fence_dev(lbl_comm* comm, int slot) try {
 extern "C" int lbl_allgather_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count, lbl_buffer* recv) try {
     lbl_ctx* pctx = (comm && send) ? lbl::buffer_ctx(send) : nullptr;
     void* ev = pctx ? lbl::comm_prof_begin(pctx) : nullptr;
-    int rc = allgather_impl(comm, send, send_offset, count, recv, 3, true);
+    int rc = allgather_impl(comm, send, send_offset, count, recv, kSlots - 1, true);
     if (pctx) lbl::comm_prof_end(pctx, ev);
     return rc;
 } LBL_GUARD_END(comm ? comm->ctx : nullptr)
 
 extern "C" int lbl_allgather_overlap_dev(lbl_comm* comm, lbl_buffer* send, int64_t send_offset, int64_t count,
                                          lbl_buffer* recv, int slot) try {
+    if (slot == kSlots - 1) return lbl::comm_fail(comm ? comm->ctx : nullptr, LBL_ERR_BAD_ARG, "slot must be 0..6");
     return allgather_impl(comm, send, send_offset, count, recv, slot, false);
 } LBL_GUARD_END(comm ? comm->ctx : nullptr)
+
+// Fewer, larger collectives: the shards of several consecutive steps are staged side by side in one batch
+// buffer and leave in ONE all-gather.  This is the staging copy, device to device, on the stream of the
+// context that owns dst (so it follows the kernels that produced src when both belong to that context).
+extern "C" int lbl_gather_stage_dev(lbl_buffer* dst, int64_t dst_offset, lbl_buffer* src, int64_t src_offset, int64_t n) try {
+    if (!dst || !src) return lbl::comm_fail(nullptr, LBL_ERR_BAD_ARG, "NULL argument");
+    lbl_ctx* ctx = lbl::buffer_ctx(dst);
+    int64_t nd = 0, ns = 0;
+    lbl_buffer_size(dst, &nd);
+    lbl_buffer_size(src, &ns);
+    if (n < 0 || dst_offset < 0 || src_offset < 0 || dst_offset + n > nd || src_offset + n > ns)
+        return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "copy range out of bounds");
+    if (lbl::ctx_device(lbl::buffer_ctx(src)) != lbl::ctx_device(ctx))
+        return lbl::comm_fail(ctx, LBL_ERR_BAD_ARG, "buffers live on different devices");
+    if (n == 0) return LBL_OK;
+    void *pd = nullptr, *ps = nullptr, *s = nullptr;
+    lbl_buffer_devptr(dst, &pd);
+    lbl_buffer_devptr(src, &ps);
+    lbl_ctx_stream(ctx, &s);
+    if (hipSetDevice(lbl::ctx_device(ctx)) != hipSuccess) return lbl::comm_fail(ctx, LBL_ERR_HIP, "hipSetDevice failed");
+    if (hipMemcpyAsync((double*)pd + dst_offset, (const double*)ps + src_offset, (size_t)n * sizeof(double),
+                       hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess)
+        return lbl::comm_fail(ctx, LBL_ERR_HIP, "device-to-device copy failed");
+    return LBL_OK;
+} LBL_GUARD_END(dst ? lbl::buffer_ctx(dst) : nullptr)

@@ -281,6 +281,12 @@ class ResidentLayer:
         self.enqueue(**enqueue_kwargs)
         return self.ctx.capture(lambda: self.enqueue(**enqueue_kwargs))
 
+    def send_range(self):
+        """(offset, S): the S doubles of a spectrum buffer this rank contributes to the all-gather"""
+        if self.plan is None or self.plan.in_place:
+            return self.rank * self.S, self.S
+        return self.first, self.S
+
     def enqueue_allgather(self, comm: nat.Comm, buffers=None, overlap_slot=None):
         """The single RCCL all-gather of the path.  Equal shards: in place on the padded buffers.
         Cost-balanced (unequal) shards: every rank sends S doubles from its own first point into a
@@ -381,6 +387,12 @@ class ResidentColumn:
             return None
         self.enqueue(**enqueue_kwargs)
         return self.ctx.capture(lambda: self.enqueue(**enqueue_kwargs))
+
+    def send_range(self):
+        """(offset, S): the S doubles of the outgoing spectrum this rank contributes to the all-gather"""
+        if self.plan is None or self.plan.in_place:
+            return self.rank * self.S, self.S
+        return self.first, self.S
 
     def enqueue_allgather(self, comm: nat.Comm, overlap_slot=None):
         if self.plan is None or self.plan.in_place:

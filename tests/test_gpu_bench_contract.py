@@ -54,7 +54,8 @@ def test_default_contract():
 
 def test_forced_single_rank_communicator_pipeline():
     d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--workload", "C1"], {"PYRAD_FORCE_COMM": "1"})
-    assert d["config"]["allgather"].startswith("overlapped") and d["value"] > 0
+    assert d["config"]["allgather"].startswith("one collective per 3 steps") and d["value"] > 0       # 6 steps, two sets
+    assert d["config"]["gather_batch"] == 3 and d["config"]["gather_verified"] is True
     bd = d["sharded_step_breakdown"]       # what an N > 1 line carries: kernels without the gather, the gather alone
     assert bd["kernels_only_ms_per_step"] > 0 and bd["allgather_alone_ms_per_step"] > 0 and len(bd["kernels_only_ms_by_rank"]) == 1
     d2 = run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--workload", "C1", "--no-overlap"],
@@ -86,7 +87,8 @@ def test_sharded_step_with_the_communicator_pipeline(shards):
     gloo tests (no HIP) and the --shard-of runs (no communicator) do not reach."""
     d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-api-path", "--shard-of", "8,3",
                    "--shards", shards], {"PYRAD_FORCE_COMM": "1"})
-    assert d["config"]["allgather"].startswith("overlapped") and d["value"] > 1e12
+    assert d["config"]["allgather"].startswith("one collective per 3 steps") and d["value"] > 1e12
+    assert d["config"]["gather_verified"] is True
     b = d["config"]["shard_bounds"]
     assert len(b) == 8 and sum(c for _, c in b) == 2400000 and d["config"]["grid_points_per_gpu"] == b[3][1]
     bd = d["sharded_step_breakdown"]
@@ -94,12 +96,12 @@ def test_sharded_step_with_the_communicator_pipeline(shards):
     d2 = run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-api-path", "--shard-of", "8,3",
                     "--shards", shards, "--no-overlap", "--gather", "all"], {"PYRAD_FORCE_COMM": "1"})
     assert d2["config"]["allgather"] == "in-stream" and d2["kernel_ms_per_step"]["allgather"] > 0
-    assert d["config"]["steps_in_flight"] == 2 and "2 buffer sets" in d["config"]["allgather"]      # a shard: two steps in flight
+    assert d["config"]["steps_in_flight"] == 2 and d["config"]["gather_batch"] == 3      # a shard: two steps in flight, gathers batched
     d1 = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-api-path", "--shard-of", "8,3",
-                    "--shards", shards, "--in-flight", "1"], {"PYRAD_FORCE_COMM": "1"})
-    assert d1["config"]["steps_in_flight"] == 1 and "2 buffer sets" in d1["config"]["allgather"]
+                    "--shards", shards, "--in-flight", "1", "--gather-batch", "1"], {"PYRAD_FORCE_COMM": "1"})
+    assert d1["config"]["steps_in_flight"] == 1 and "2 buffer sets" in d1["config"]["allgather"] and d1["config"]["gather_batch"] == 1
     assert d1["config"]["evals_per_step"] == d["config"]["evals_per_step"]
     # the column takes the same route
-    d3 = run_bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--workload", "C5", "--shard-of", "8,3",
+    d3 = run_bench(["--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--workload", "C5", "--shard-of", "8,3",
                     "--shards", shards], {"PYRAD_FORCE_COMM": "1"})
-    assert d3["value"] > 1e11 and "column" in d3["config"]["workload"]
+    assert d3["value"] > 1e11 and "column" in d3["config"]["workload"] and d3["config"]["gather_verified"] is True

@@ -405,6 +405,30 @@ def test_one_communicator_orders_collectives_of_two_contexts(ctx):
     ctx2.close()
 
 
+def test_batch_staging_and_one_gather_for_several_steps(ctx):
+    """Fewer, larger collectives: shards of several steps staged side by side in a batch buffer
+    (lbl_gather_stage_dev) leave in one all-gather; seven overlap slots + the in-stream one."""
+    from pyrad_amd import _native as nat
+    comm = nat.Comm(ctx, nat.Comm.unique_id(), 1, 0)
+    S, B = 1000, 3
+    src = ctx.buffer(5000, np.arange(5000.0))
+    batch = ctx.buffer(B * S).fill(-1.0)
+    for b in range(B):
+        batch.stage_from_dev(src, 100 + 7 * b, S, dst_offset=b * S)
+    comm.allgather_dev(batch, 0, B * S, batch, overlap_slot=6)
+    comm.fence_dev(6)
+    got = batch.download(B * S).reshape(B, S)
+    for b in range(B):
+        assert np.array_equal(got[b], np.arange(100.0 + 7 * b, 100.0 + 7 * b + S))
+    with pytest.raises(nat.LblError):
+        batch.stage_from_dev(src, 4500, S)                   # source range out of bounds
+    with pytest.raises(nat.LblError):
+        batch.stage_from_dev(src, 0, S, dst_offset=2500)     # destination range out of bounds
+    with pytest.raises(nat.LblError):
+        comm.allgather_dev(batch, 0, S, batch, overlap_slot=7)      # 7 is the in-stream form's own slot
+    comm.free(); src.free(); batch.free()
+
+
 def test_resident_column_c5_shape_vs_oracle(ctx, orc):
     """BASELINE config 5 in miniature: a 5-layer column (P 1013 -> 10 mbar, so windows from
     W = 5000 down to 50 share one batch and get different launch shapes), H2O + CO2 + O3,
