@@ -113,3 +113,93 @@ def test_gather_batch_rule():
     assert f("auto", True, 32) == 8 and f("auto", True, 25) == 5 and f("auto", True, 3) == 3 and f("auto", True, 2) == 2
     assert f("auto", True, 7) == 7 and f("auto", True, 11) in (4, 6)     # 11 = 2 * 6 - 1 = 3 * 4 - 1
     assert f("6", True, 10) == 6 and f("1", True, 10) == 1
+
+
+class _FakeBuffer:
+    def __init__(self, n):
+        self.a = np.zeros(n)
+        self.log = []
+
+    def fill(self, v):
+        self.a[:] = v
+        return self
+
+    def stage_from_dev(self, src, src_offset, n, dst_offset=0):
+        self.a[dst_offset:dst_offset + n] = src.a[src_offset:src_offset + n]
+        return self
+
+    def free(self):
+        pass
+
+
+class _FakeCtx:
+    def buffer(self, n):
+        return _FakeBuffer(n)
+
+
+class _FakeNet:
+    """Lock-step stand-in for the communicator of `world` ranks: a collective completes when every rank has
+    issued its call with the same sequence number; then recv[r'*count : (r'+1)*count] = rank r' send range."""
+
+    def __init__(self, world):
+        self.world, self.calls = world, {}
+
+    def comm(self, rank):
+        net = self
+
+        class Comm:
+            def __init__(self):
+                self.seq, self.events = 0, []
+
+            def fence_dev(self, slot):
+                self.events.append(("fence", slot))
+
+            def allgather_dev(self, send, off, count, recv, overlap_slot=None):
+                self.events.append(("gather", overlap_slot))
+                key = self.seq
+                self.seq += 1
+                net.calls.setdefault(key, {})[rank] = (send, off, count, recv)
+                if len(net.calls[key]) == net.world:
+                    parts = net.calls.pop(key)
+                    assert len({c for _, _, c, _ in parts.values()}) == 1          # same count on every rank
+                    data = {r: s.a[o:o + c].copy() for r, (s, o, c, _) in parts.items()}
+                    for r, (_, _, c, rv) in parts.items():
+                        for rr in range(net.world):
+                            rv.a[rr * c:(rr + 1) * c] = data[rr]
+        return Comm()
+
+
+def test_batched_gather_layout_two_simulated_ranks():
+    """bench._Batch on two simulated ranks: shards of B consecutive steps staged at (rank * B + b) * S leave in one
+    in-place collective of B * S per rank; every rank then holds every rank's shard of every step of the batch; a
+    buffer is fenced before it is refilled; a partly filled batch leaves at a flush."""
+    world, S, B = 2, 7, 3
+    net = _FakeNet(world)
+    comms = [net.comm(r) for r in range(world)]
+    batches = [bench._Batch(_FakeCtx(), comms[r], r, world, S, B, (4, 5)) for r in range(world)]
+    src = [_FakeBuffer(world * S + 5) for _ in range(world)]          # a rank's padded spectrum buffer
+    for step in range(2 * B + 1):                                     # two full batches and one step of a third
+        for r in range(world):
+            src[r].a[r * S:(r + 1) * S] = 1000.0 * r + step + np.arange(S) / 100.0
+            batches[r].before_step()
+            batches[r].stage(src[r], r * S)
+        if step == B - 1 or step == 2 * B - 1:                        # a batch just left: check the buffer it left from
+            first_step = step - (B - 1)
+            for r in range(world):
+                got = batches[r].bufs[batches[r].cur ^ 1].a.reshape(world, B, S)
+                for rr in range(world):
+                    for b in range(B):
+                        assert np.array_equal(got[rr, b], 1000.0 * rr + first_step + b + np.arange(S) / 100.0)
+    for r in range(world):
+        assert batches[r].fill == 1 and batches[r].sent == 2
+        batches[r].flush()
+        assert batches[r].fill == 0 and batches[r].sent == 3
+    for r in range(world):
+        got = batches[r].bufs[batches[r].cur ^ 1].a.reshape(world, B, S)
+        for rr in range(world):
+            assert np.array_equal(got[rr, 0], 1000.0 * rr + 2 * B + np.arange(S) / 100.0)
+        ev = comms[r].events
+        # fence of a buffer's slot before its first copy, gathers alternate between the two slots
+        assert ev[0] == ("fence", 4) and [e for e in ev if e[0] == "gather"] == [("gather", 4), ("gather", 5), ("gather", 4)]
+        assert [e for e in ev if e[0] == "fence"] == [("fence", 4), ("fence", 5), ("fence", 4)]
+    assert not net.calls                                              # every collective was matched by every rank
