@@ -808,8 +808,11 @@ def main():
             balg_sw = 8.0 * pts * (n_arrays * n_layers + 1 + (2 * n_layers if args.column_layer_arrays else 0))
             sweep_kernel = "column_step_kernel"
         t_sw = (ms_sw / max(n_sw, 1)) * 1e-3
-        standard = args.scale == 1 and args.lines is None and world == 1 and not args.shard_of and not args.unfused
-        pmc = load_pmc(args.workload if standard else None, nat.source_hash())
+        # committed PMC passes: of the whole cell, or - for a rank of a G-way sharded run - of one shard of G
+        # ("C3s8": shard 4 of 8, profiles/collect.sh r02 C3 8,4): a shard's launch shape, not this rank's exact lines
+        standard = args.scale == 1 and args.lines is None and not args.unfused and (strong or world == 1)
+        pmc_key = args.workload if shard_world == 1 else "%ss%d" % (args.workload, shard_world)
+        pmc = load_pmc(pmc_key if standard else None, nat.source_hash())
         traffic = pmc["hbm"].get("xsec_accumulate_kernel")
         result = {
             "metric": "line*gridpoint evals/sec (whole job)", "value": value, "unit": "evals/s",

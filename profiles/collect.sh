@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box:
-#   gpurun -- 'bash profiles/collect.sh r02 C3'     (workloads: C1 C2 C3 C5)
+#   gpurun -- 'bash profiles/collect.sh r02 C3'     (workloads: C1 C2 C3 C5; a third argument G,r profiles one shard)
 # writes gpurun_out/<tag>/..., which profiles/summarize.py turns into the committed summaries
 # (gpurun_out/<tag>/final/: copy its files into profiles/).
 # Counters are collected in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass,
@@ -8,19 +8,23 @@
 set -e
 TAG=${1:-r02}
 WORKLOAD=${2:-C3}
+SHARD=$3          # optional "G,r": shard r of a G-way sharding (what a rank of a G-GPU run computes); label <workload>s<G>
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="$R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-api-path --no-direct-pass --workload $WORKLOAD"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$WORKLOAD -- python3 $CMD > $OUT/trace_$WORKLOAD.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$WORKLOAD -- python3 $CMD > $OUT/pmc_fetch_$WORKLOAD.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$WORKLOAD -- python3 $CMD > $OUT/pmc_write_$WORKLOAD.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_valu_$WORKLOAD -- python3 $CMD > $OUT/pmc_valu_$WORKLOAD.log 2>&1
+WL=$WORKLOAD
+EXTRA=""
+if [ -n "$SHARD" ]; then WL=${WORKLOAD}s${SHARD%%,*}; EXTRA="--shard-of $SHARD"; fi
+CMD="$R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-api-path --no-direct-pass --workload $WORKLOAD $EXTRA"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$WL -- python3 $CMD > $OUT/trace_$WL.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$WL -- python3 $CMD > $OUT/pmc_fetch_$WL.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$WL -- python3 $CMD > $OUT/pmc_write_$WL.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_valu_$WL -- python3 $CMD > $OUT/pmc_valu_$WL.log 2>&1
 # summaries first (pmc_traffic.json then carries this build's source hash), then the bench line that quotes them
-python3 $R/profiles/summarize.py $OUT $TAG $WORKLOAD > $OUT/summary_$WORKLOAD.txt
-python3 $R/bench.py --steps 20 --warmup 3 --workload $WORKLOAD > $R/profiles/${TAG}_${WORKLOAD}_bench.json 2> $OUT/bench_$WORKLOAD.err
+python3 $R/profiles/summarize.py $OUT $TAG $WL > $OUT/summary_$WL.txt
+python3 $R/bench.py --steps 20 --warmup 3 --workload $WORKLOAD $EXTRA > $R/profiles/${TAG}_${WL}_bench.json 2> $OUT/bench_$WL.err
 # everything to commit, where gpurun brings it back from
 mkdir -p $OUT/final
-cp $R/profiles/${TAG}_${WORKLOAD}_* $R/profiles/pmc_traffic.json $OUT/final/
-cat $R/profiles/${TAG}_${WORKLOAD}_kernel_stats.csv
+cp $R/profiles/${TAG}_${WL}_* $R/profiles/pmc_traffic.json $OUT/final/
+cat $R/profiles/${TAG}_${WL}_kernel_stats.csv
