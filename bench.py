@@ -191,6 +191,51 @@ def api_path(cfg, reps=5):
         engine.shutdown()
 
 
+def api_path_column(cfg, reps=3):
+    """The drop-in route for the column: pyrad_amd.model's Atmosphere -> addLayer -> addMolecule ->
+    Atmosphere.transmission(surfaceTemperature) on the bench column, host array out.  ms_per_call = one
+    transmission after every layer's changeTemperature has invalidated its cross sections: all layers' line
+    lists go through ONE batched accumulate launch sequence and one column-step kernel, then one download."""
+    from pyrad_amd import model, data, settings, engine
+    keep = (settings.RES_MULTIPLIER, data._source, model.Layer.hasAtmosphere)
+    try:
+        c0 = cfg["layers"][0]
+        settings.set_resolution_multiplier(c0["base_resolution"] / .01)
+        data.set_source(data.synthetic_source({m["species"]: m["lines"] for m in c0["molecules"]}))
+        model.Layer.hasAtmosphere = False
+        t0 = time.perf_counter()
+        atm = model.Atmosphere("bench column")
+        for c in cfg["layers"]:
+            layer = atm.addLayer(c["depth"], c["T"], c["P"], c["range_min"], c["range_max"], name=c["name"],
+                                 dynamicResolution=c.get("dynamic_resolution", True))
+            for m in c["molecules"]:
+                layer.addMolecule(m["species"], **m["conc"])
+        t_build = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        spec = atm.transmission(surfaceTemperature=cfg["surface_T"])       # first call: uploads the lines, builds the schedules
+        t_first = time.perf_counter() - t0
+        evals = sum(engine.eval_count(iso._lines["nu"], L.rangeMin, L.resolution, L._grid()["W"], L._grid()["n_work"])
+                    for L in atm for m in L for iso in m)
+        t_call = []
+        for _ in range(reps):
+            for L in atm:
+                L.changeTemperature(L.T)                    # marks every cross section of the layer dirty (cls:741-743)
+            t0 = time.perf_counter()
+            spec = atm.transmission(surfaceTemperature=cfg["surface_T"])
+            t_call.append(time.perf_counter() - t0)
+        ms_call = 1e3 * float(np.median(t_call))
+        return {"ms_per_call": ms_call, "evals_per_s": evals / (ms_call * 1e-3), "ms_build_atmosphere": 1e3 * t_build,
+                "ms_first_call": 1e3 * t_first, "bytes_downloaded_per_call": 8 * int(spec.size),
+                "what": "model.Atmosphere.transmission(surfaceTemperature) after changeTemperature on all %d layers "
+                        "(recompute on resident line lists, column step, download of the outgoing spectrum); median of %d; "
+                        "checks: %d points, finite %s" % (len(cfg["layers"]), reps, spec.size, bool(np.isfinite(spec).all()))}
+    finally:
+        settings.set_resolution_multiplier(keep[0])
+        data.set_source(keep[1])
+        model.Layer.hasAtmosphere = keep[2]
+        engine.shutdown()
+
+
 class _StdoutToStderr:
     """RCCL prints a version banner on stdout when a communicator is created; rank 0 must print
     exactly one JSON line there, so file descriptor 1 points at stderr while RCCL initialises."""
@@ -868,7 +913,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(cfg["layers"][0] if is_column else cfg, args.cpu_seconds)
         if args.check:
             result["check"] = oracle_check(layer, cfg)
-    want_api = rank == 0 and world == 1 and not is_column and not args.no_api_path and not args.shard_of
+    want_api = rank == 0 and world == 1 and not args.no_api_path and not args.shard_of
     if rdzv is not None:
         rdzv.arrive("done")
         rdzv.cleanup()
@@ -884,7 +929,9 @@ def main():
         L.free()
     red.free()
     ctx.close()
-    if want_api:
+    if want_api and is_column:
+        result["api_path"] = api_path_column(cfg)
+    elif want_api:
         result["api_path"] = api_path(cfg)
         if small_cell and n_flight == 1:
             result["in_flight_leg"] = in_flight_leg(cfg)

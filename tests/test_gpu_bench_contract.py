@@ -105,3 +105,11 @@ def test_sharded_step_with_the_communicator_pipeline(shards):
     d3 = run_bench(["--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--workload", "C5", "--shard-of", "8,3",
                     "--shards", shards], {"PYRAD_FORCE_COMM": "1"})
     assert d3["value"] > 1e11 and "column" in d3["config"]["workload"] and d3["config"]["gather_verified"] is True
+
+
+def test_column_line_carries_the_atmosphere_api_leg():
+    """C5: the line's api_path is pyrad_amd.model.Atmosphere.transmission on the same 30-layer column."""
+    d = run_bench(["--workload", "C5", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-direct-pass"])
+    a = d["api_path"]
+    assert a["ms_per_call"] > 0 and a["bytes_downloaded_per_call"] == 8 * 2400000 and "30 layers" in a["what"] and "finite True" in a["what"]
+    assert a["evals_per_s"] > 1e11 and d["roofline_sweep"]["kernel"] == "column_step_kernel"
