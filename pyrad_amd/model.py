@@ -1136,7 +1136,7 @@ class Atmosphere(list):
                 raise ValueError("give surfaceSpectrum or surfaceTemperature")
             ctx.column_step_dev(desc, first.rangeMin, first.rangeMax, n, out, I_in=I_in,
                                 surface_T=float(surfaceTemperature or 0.0))
-            return out.download(n)
+            return out.download(n, pinned=True)
         finally:
             for b in tmp:
                 b.free()

@@ -1,0 +1,29 @@
+"""cProfile of model.Atmosphere.transmission on the bench column (where the host time of the API leg goes)."""
+import cProfile, pstats, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench
+from pyrad_amd import model, data, settings, engine
+cfg, _ = bench.build_workload("C5", 1)
+c0 = cfg["layers"][0]
+settings.set_resolution_multiplier(c0["base_resolution"] / .01)
+data.set_source(data.synthetic_source({m["species"]: m["lines"] for m in c0["molecules"]}))
+model.Layer.hasAtmosphere = False
+atm = model.Atmosphere("col")
+for c in cfg["layers"]:
+    L = atm.addLayer(c["depth"], c["T"], c["P"], c["range_min"], c["range_max"], name=c["name"], dynamicResolution=False)
+    for m in c["molecules"]:
+        L.addMolecule(m["species"], **m["conc"])
+atm.transmission(surfaceTemperature=288)
+for L in atm:
+    L.changeTemperature(L.T)
+atm.transmission(surfaceTemperature=288)
+pr = cProfile.Profile()
+for L in atm:
+    L.changeTemperature(L.T)
+t0 = time.perf_counter()
+pr.enable()
+atm.transmission(surfaceTemperature=288)
+pr.disable()
+print("call: %.3f ms" % ((time.perf_counter() - t0) * 1e3))
+pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+engine.shutdown()
