@@ -307,8 +307,8 @@ def steps_in_flight(requested: str, sharded: bool) -> int:
     with the all-gather pipeline beside them 2 beats 3 (0.0624 / 0.0638 at 8, 0.097 / 0.101 at 4).
     auto: 2 for a shard; 1 for an unsharded grid, so that an N = 1 line times every kernel alone on the chip and
     agrees with its rocprofv3 summary (the profiler does not let launches of different streams overlap the
-    way they do unobserved); what more steps in flight give a small unsharded cell (C2 0.064 -> 0.046 ms,
-    C1 0.0176 -> 0.0125 with three) is reported by an extra leg of the line, `in_flight_leg`."""
+    way they do unobserved); what more steps in flight give a small unsharded cell (C2 0.066 -> 0.043 ms,
+    C1 0.0185 -> 0.0087 with three) is reported by an extra leg of the line, `in_flight_leg`."""
     if requested != "auto":
         return max(1, min(3, int(requested)))
     return 2 if sharded else 1
