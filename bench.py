@@ -523,6 +523,8 @@ def main():
                     help="independent steps in flight per rank, each on a HIP stream (context) of its own; auto: 1 for an "
                          "unsharded grid, 2 for a shard (see steps_in_flight)")
     ap.add_argument("--check", action="store_true", help="also compare one shard against the oracle (slow)")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="experiment: lbl_set_option(KEY, VALUE) on every context (e.g. accum_skew=0)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -588,6 +590,9 @@ def main():
         ctx.set_option("accum_blocks_per_cu", args.blocks_per_cu)
     if args.longest_first is not None:
         ctx.set_option("accum_longest_first", args.longest_first)
+    for kv in args.set:
+        key, _, val = kv.partition("=")
+        ctx.set_option(key, int(val))
 
     comm = None
     rdzv = None

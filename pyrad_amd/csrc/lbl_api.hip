@@ -79,6 +79,11 @@ struct lbl_ctx {
     struct ArgSlot { std::vector<char> bytes; void* dptr = nullptr; size_t cap = 0; uint64_t used = 0; };
     std::vector<ArgSlot> arg_cache;      // device copies of kernel argument blocks, found again by content
     uint64_t arg_clock = 0;
+    int skew = 1;            // line lists whose window has no far line (narrower than 5 half-spans of 128 points): 1 (default) the
+                             // skewed-range kernel when they fill the chip; 0 the all-direct span kernel; 2 EVERY job through the
+                             // skewed-range kernel whatever its window and the grid size (parity tests)
+    int skew_R = 4;          // points per lane of the skewed-range kernel
+    int ablate = 0;          // diagnostics: AccumJob.ablate
     bool no_fuse = false;    // lbl_layer_step_dev as accumulate + separate sweep launch (A/B, parity tests)
     int live_objects = 0;
     // event timing (lbl_profile_*)
@@ -407,6 +412,15 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) try {
         if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_line_split must be 0, 1, 2, 4 or 8");
         ctx->accum_LS = value;
+    } else if (!strcmp(key, "accum_skew")) {
+        if (value < 0 || value > 2) return fail(ctx, LBL_ERR_BAD_ARG, "accum_skew must be 0, 1 or 2");
+        ctx->skew = value;
+    } else if (!strcmp(key, "accum_skew_points_per_lane")) {
+        if (!(value == 1 || value == 2 || value == 4 || value == 8))
+            return fail(ctx, LBL_ERR_BAD_ARG, "accum_skew_points_per_lane must be 1, 2, 4 or 8");
+        ctx->skew_R = value;
+    } else if (!strcmp(key, "debug_ablate")) {
+        ctx->ablate = value;        // timing experiments only: results are wrong when non-zero
     } else if (!strcmp(key, "layer_step_fused")) {
         if (value < 0 || value > 1) return fail(ctx, LBL_ERR_BAD_ARG, "layer_step_fused must be 0 or 1");
         ctx->no_fuse = value == 0;
@@ -890,7 +904,19 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         const long long r = ctx->accum_R ? ctx->accum_R : r_cap(j);
         return H >= 32 * r * (far_half_spans + 1) ? 1 : 0;
     };
-    auto group_key = [&](int j) { return r_cap(j) * 2 + has_far(j); };
+    // Narrow windows (no far line on any span) go to the skewed-range kernel, all in ONE group whatever their
+    // width (its lanes walk per-lane line ranges, so a span may be wider than a line's support), provided the
+    // group fills the chip: at least 8 wavefronts per CU, else the span kernel's line split serves small grids better.
+    bool skew_on = false;
+    if (ctx->accum_variant == 5 && ctx->skew && !ctx->accum_R && !ctx->accum_LS) {
+        long long pts = 0;
+        for (int j = 0; j < n_jobs; ++j)
+            if (ctx->skew == 2 || !has_far(j)) { long long f, c; shard_range(grid[j], &f, &c); pts += c; }
+        const long long cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
+        skew_on = ctx->skew == 2 || pts / (64LL * ctx->skew_R) >= 8 * cus;
+    }
+    auto is_skew = [&](int j) { return skew_on && (ctx->skew == 2 || !has_far(j)); };
+    auto group_key = [&](int j) { return is_skew(j) ? 0 : r_cap(j) * 2 + has_far(j); };
     std::vector<int> order(n_jobs);
     for (int j = 0; j < n_jobs; ++j) order[j] = j;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return group_key(a) > group_key(b); });
@@ -908,13 +934,17 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             ++e;
         }
         Group g{k, e - k, 0, 0, 0, ctx->accum_variant, nullptr, 0, nullptr, {}};
-        choose_shape(ctx, g.variant, pts, lns, mh, &g.R, &g.LS);
-        // with the R actually chosen (a small grid may have shrunk it): does any job of the group have far lines?
-        if (ctx->accum_variant == 5 && mxh < 32LL * g.R * (far_half_spans + 1)) g.variant = 3;
-        if ((g.variant == 3 || g.variant == 5) && ctx->lpt) {
+        if (is_skew(order[k])) {
+            g.R = ctx->skew_R; g.LS = 1; g.variant = 6;
+        } else {
+            choose_shape(ctx, g.variant, pts, lns, mh, &g.R, &g.LS);
+            // with the R actually chosen (a small grid may have shrunk it): does any job of the group have far lines?
+            if (ctx->accum_variant == 5 && mxh < 32LL * g.R * (far_half_spans + 1)) g.variant = 3;
+        }
+        if ((g.variant == 3 || g.variant == 5 || g.variant == 6) && ctx->lpt) {
             // cached host schedule of this group: dispatch order + the line ranges of every span
             std::vector<int> members(order.begin() + k, order.begin() + e);
-            const lbl_ctx::Schedule* sc = group_schedule(ctx, g.variant, members, lines, grid, g.R, g.LS,
+            const lbl_ctx::Schedule* sc = group_schedule(ctx, g.variant == 6 ? 3 : g.variant, members, lines, grid, g.R, g.LS,
                                                          accumulate_tile_points(g.R, g.LS, g.variant));
             if (!sc) return ctx->capturing ? LBL_ERR_STATE : fail(ctx, LBL_ERR_OOM, "schedule allocation failed");
             g.worklist = sc->d_list; g.total_tiles = sc->total; g.tabs = sc->d_tabs; g.tab_off = sc->tab_off;
@@ -968,6 +998,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             a.n_tiles = (int32_t)((sc + tile_pts - 1) / tile_pts);
             a.flush_every = (a.H + 64 * g.R + 1 <= 40000) ? 32 : 16;
             a.pad = ctx->tile_order;
+            a.ablate = ctx->ablate;
             a.span_tab = g.tabs ? g.tabs + g.tab_off[(size_t)(k - g.first)] : nullptr;
             if (fuse && n_jobs == 1) {
                 a.chain_flags = CHAIN_MOL_FIRST | CHAIN_MOL_LAST;
@@ -1043,6 +1074,8 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             double* slab = (double*)(base + ((S * sizeof(SpanRec) + S * sizeof(unsigned int) + (S + 1) * sizeof(unsigned long long) + 255) & ~(size_t)255));
             launch_accumulate_balanced(da + g.first, g.count, (int)S, g.R, group_workers[gi], spans, cnts, prefix, slab,
                                        ctx->stream);
+        } else if (g.variant == 6) {
+            launch_accumulate_skew(da + g.first, g.count, g.max_tiles, g.R, g.worklist, g.total_tiles, ctx->stream);
         } else {
             launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, g.variant, g.worklist, g.total_tiles,
                               ctx->stream);

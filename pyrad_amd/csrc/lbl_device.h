@@ -82,7 +82,8 @@ struct AccumJob {
     const int32_t* span_tab;
     // Fused layer step of a single-line-list layer (lbl_layer_step_dev): the sweep of a point runs in
     // this job's output stage with the molecule's volume fraction `conc`.
-    int32_t chain_flags, pad2;
+    int32_t chain_flags;
+    int32_t ablate;        // diagnostics (lbl_set_option debug_ablate): timing-only builds of the skewed-range kernel skip parts of its work
     double conc;
     FusedSweep fuse;       // fuse.on: sweep every point right after its cross section is final
 };
@@ -166,6 +167,9 @@ struct ColumnArgs {
 void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStream_t s);
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
                        const int2* worklist, int total_tiles, hipStream_t s);
+// narrow windows: every lane walks the lines that reach its own R points (skewed ranges); tiles of 256 R points
+void launch_accumulate_skew(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, const int2* worklist, int total_tiles,
+                            hipStream_t s);
 int accumulate_tile_points(int R, int LS, int variant);
 void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost);
 // balanced variant (4): span ranges -> prefix sum -> equal shares of (span, line) pairs per wave -> slab reduce

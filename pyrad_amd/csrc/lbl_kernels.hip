@@ -1098,6 +1098,317 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
     }
 }
 
+// ---- narrow windows: skewed line ranges ---------------------------------------------------------
+// The upper layers of a column have windows of 50-640 points (pyradClasses.py:655: 5 P / 1013.25 cm^-1).
+// In the span kernel above a wave walks every line that reaches ANY of its 64 R points, and most of
+// those end inside the span: masked lanes (8 instead of 5 instructions per point, half of them for
+// nothing), and a span may not be wider than a line's support, so the narrowest layers run R = 1.
+// Here every LANE walks the lines that reach ITS R points: sorted centre indices make that a
+// contiguous range [A', B') of records per lane, shifted by R points from lane to lane, so at
+// iteration t lane l is on record A'(l) + t: the lanes run down the line list side by side, each at
+// about the same offset from its current line (a skewed, systolic walk).  Every lane has the same
+// number of lines up to density fluctuations, none of them masked except the few (0-2 per lane)
+// that cover only part of the lane's R points: per lane  [A', A) partial, [A, B) full, [B, B') partial,
+//     A' = #{c < p0 - H}   A = #{c < p0 + R-1 - H}   B = #{c <= p0 + H}   B' = #{c <= p0 + R-1 + H}.
+// The four counts of all 64 lanes come from one scatter + scan per chunk: record j adds itself to the
+// first threshold above its centre (ds_max of j+1: centres are sorted, so the count IS the largest
+// such j+1), then a prefix maximum over the thresholds (R per lane, DPP scan across lanes).
+// Records are staged per chunk of 112 in the wave's LDS (hot 32 B + cold 32 B) and read back with
+// per-lane addresses (neighbouring lanes read the same or the next record: conflict-free).
+// The Gaussian part of a line is evaluated by the lanes whose points it can still change (|d| < dgi, K1's
+// cut-off), two exp per lane and line, in a walk of its own over per-lane ranges counted the same way, so
+// that all lanes are at the cores of their current lines at the same time.  Summation order per point:
+// Lorentz terms of the partially covering lines, then of the fully covering ones, ascending; then the
+// Gaussian terms, ascending: fixed, so reruns are bit-identical.
+// Records per chunk: what fits beside the counters so that four workgroups share a CU's 160 KB of LDS.
+template <int R> struct SkewChunk { static constexpr int value = R >= 8 ? 80 : 112; };
+
+__device__ __forceinline__ unsigned int dpp_max_u32(unsigned int v, unsigned int moved) { return v > moved ? v : moved; }
+
+// inclusive prefix maximum over the 64 lanes
+__device__ __forceinline__ unsigned int wave_prefix_max_u32(unsigned int v) {
+    v = dpp_max_u32(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = dpp_max_u32(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = dpp_max_u32(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = dpp_max_u32(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = dpp_max_u32(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    v = dpp_max_u32(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// cnt[i] = #{records of the chunk with centre < base + i}, i = 0 .. 64 R; returns this lane's counts at
+// i = R lane (lo) and i = R lane + R - 1 (hi).  cnt holds j+1 of the last record whose first counted
+// threshold is i (0: none) when called.
+template <int R>
+__device__ __forceinline__ void skew_counts(const unsigned int* __restrict__ cnt, int lane, int& lo, int& hi) {
+    unsigned int m[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) m[k] = cnt[lane * R + k];
+#pragma unroll
+    for (int k = 1; k < R; ++k) m[k] = m[k] > m[k - 1] ? m[k] : m[k - 1];
+    const unsigned int inc = wave_prefix_max_u32(m[R - 1]);
+    unsigned int ex = (unsigned int)__shfl_up((int)inc, 1, 64);
+    if (lane == 0) ex = 0u;
+    lo = (int)(ex > m[0] ? ex : m[0]);
+    hi = (int)inc;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {        // v >= 0; the result is wave-uniform
+    return __builtin_amdgcn_readlane((int)wave_prefix_max_u32((unsigned int)v), 63);
+}
+
+// One lane's Lorentz walk over the records [ja, ja + la) and then (TWO) [jb, jb + lb) of the chunk (per-lane
+// bounds), into the running fraction.  The trip count is the longest walk of the wave (one DPP maximum); a
+// lane that has finished reads the chunk's sentinel record (K = 0, centre at the span start so that its
+// denominators stay small).  The loop is branch-free (a lane-dependent `if` around the loop-carried sums
+// costs dozens of register copies per iteration), in blocks of at most `every` iterations between flushes
+// of the running fraction; the next record's LDS read is issued before the current record's arithmetic.
+// `it` counts the wave's iterations since the last flush, so every lane's product of denominators stays bounded.
+template <int R, bool MASKED, bool TWO>
+__device__ __forceinline__ void skew_lorentz(const double* __restrict__ lh, int sentinel, int ja, int la, int jb, int lb,
+                                             double x0, double Hf, WaveAcc<R>& S, int& it) {
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    const v2f64* rec = reinterpret_cast<const v2f64*>(lh);
+    la = max(la, 0);
+    const int len = la + (TWO ? max(lb, 0) : 0);
+    const int T = wave_max_i32(len);
+    const int jb_off = jb - la;
+    auto index = [&](int t) {
+        if (TWO) return t < la ? ja + t : (t < len ? jb_off + t : sentinel);
+        return t < la ? ja + t : sentinel;
+    };
+    for (int t0 = 0; t0 < T;) {
+        const int nb = min(S.every - it, T - t0);
+        int jj = index(t0);
+        v2f64 n0 = rec[jj * 2], n1 = rec[jj * 2 + 1];
+#pragma unroll 2
+        for (int t = 0; t < nb; ++t) {
+            const v2f64 c0 = n0, c1 = n1;
+            jj = index(t0 + t + 1);
+            n0 = rec[jj * 2]; n1 = rec[jj * 2 + 1];
+            const double d0 = x0 - c0.x;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double d = d0 + (double)k;
+                const double den = fma(d, d, c0.y);
+                double K = c1.x;
+                if (MASKED) K = (fabs(d) <= Hf) ? K : 0.0;
+                const double tt = K * S.D[k];
+                S.N[k] = fma(S.N[k], den, tt);
+                S.D[k] *= den;
+            }
+        }
+        it += nb;
+        t0 += nb;
+        if (it >= S.every) { S.flush(); it = 0; }
+    }
+}
+
+// One lane's walk over the records [g0, g1) whose Gaussian part may reach its R points (a per-lane range
+// again, from the largest reach of the chunk; K1's own cut-off of every record decides inside): two exp per
+// lane and line, all lanes at the cores of their current lines at the same time.  Branches are wave-uniform;
+// a lane that does not need the term runs it with amplitude 0.  MASKED: points beyond the line's support are
+// switched off (needed only when the largest reach of the chunk comes within R points of the support's end).
+template <int R, bool MASKED>
+__device__ __forceinline__ void skew_gauss(const double* __restrict__ lh, int cold_off, int sentinel, int g0, int g1,
+                                           double x0, double Hf, WaveAcc<R>& S) {
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    const v2f64* rec = reinterpret_cast<const v2f64*>(lh);
+    const int len = max(g1 - g0, 0);
+    const int T = wave_max_i32(len);
+    for (int t = 0; t < T; ++t) {
+        const int jc = t < len ? g0 + t : sentinel;
+        const v2f64 h0 = rec[jc * 2];
+        const double gf = lh[(jc * 2 + 1) * 2 + 1];
+        const v2f64 gg = rec[cold_off + jc * 2];                     // KG, b
+        const double q2 = lh[(cold_off + jc * 2 + 1) * 2];
+        const double d0 = x0 - h0.x;
+        const bool need = fabs(d0 + 0.5 * (R - 1)) < gf;           // the sentinel's reach is 0
+        const bool recur = q2 >= 0.0 && R >= 4;
+        const bool need_r = need && recur, need_n = need && !recur;
+        if (__any(need_r))
+            gauss_term<R, 1, MASKED>(need_r ? gg.x : 0.0, need_r ? gg.y : 0.0, true, d0, Hf, need_r ? q2 : 1.0, S.acc);
+        if (__any(need_n))
+            gauss_term<R, 0, MASKED>(need_n ? gg.x : 0.0, need_n ? gg.y : 0.0, false, d0, Hf, 0.0, S.acc);
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void xsec_accumulate_skew_kernel(const AccumJob* __restrict__ jobs,
+                                                                   const int2* __restrict__ worklist) {
+    constexpr int SKEW_CH = SkewChunk<R>::value;
+    constexpr int NROUND = (SKEW_CH + 63) / 64;
+    constexpr int NCNT = 64 * R + 8;                 // thresholds 0 .. 64 R, one dump slot, padding
+    constexpr int COLD = (SKEW_CH + 1) * 2;           // first cold record, in 16-byte units
+    __shared__ double s_rec[4][(SKEW_CH + 1) * 8];   // per wave: hot records 0 .. CH (CH: the sentinel), then the cold records 0 .. CH
+    __shared__ unsigned int s_cnt[4][2][NCNT];
+    int job = blockIdx.y, tile;
+    if (worklist) {
+        const int2 wk = worklist[blockIdx.x];
+        job = wk.x; tile = wk.y;
+    } else {
+        tile = xcd_tile(blockIdx.x, jobs[job].n_tiles, jobs[job].pad);
+    }
+    const AccumJob& J = jobs[job];
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform_i32(threadIdx.x >> 6);
+    const int n_end = J.p_end;
+    const long long wave_lo_ll = (long long)J.p_begin + (long long)(tile < 0 ? 0 : tile) * (256LL * R) + (long long)wave * (64LL * R);
+    if (tile < 0 || wave_lo_ll >= n_end) return;     // waves are independent: no workgroup barrier below
+    const int wlo = (int)wave_lo_ll;
+    const int whi = min(wlo + 64 * R - 1, n_end - 1);
+    const int H = J.H;
+    const int p0 = wlo + lane * R;
+    const double x0 = (double)p0;
+    const double Hf = (double)H;
+    WaveAcc<R> S;
+    S.init(J.flush_every);
+    double* lh = s_rec[wave];
+    double* lc = s_rec[wave] + COLD * 2;
+    unsigned int* cntL = s_cnt[wave][0];
+    unsigned int* cntR = s_cnt[wave][1];
+
+    int iA, iD;
+    if (J.span_tab) {
+        const int32_t* tab = J.span_tab + (size_t)((wlo - J.p_begin) / (64 * R)) * 8;
+        iA = uniform_i32(tab[0]); iD = uniform_i32(tab[3]);
+    } else {
+        int iB, iC;
+        wave_line_ranges(J.cidx, J.n_lines, wlo, whi, H, lane, iA, iB, iC, iD);
+    }
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    typedef const v2f64 __attribute__((address_space(1)))* GlobalF64x2;
+    const GlobalF64x2 gh = (GlobalF64x2)(unsigned long long)J.hot;
+    const GlobalF64x2 gc = (GlobalF64x2)(unsigned long long)J.cold;
+    auto zero_counters = [&]() {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < R; ++k) { cntL[lane * R + k] = 0u; cntR[lane * R + k] = 0u; }
+        if (lane < 8) { cntL[64 * R + lane] = 0u; cntR[64 * R + lane] = 0u; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // every centre of [iA, iD) lies in [wlo - H, whi + H], so these differences fit an int
+    auto slot = [&](int c, int base) { const int i = c - base + 1; return i < 0 ? 0 : (i > 64 * R + 1 ? 64 * R + 1 : i); };
+    const int ablate = J.ablate;
+    int it = 0;
+    if (lane == 0) {                                      // the sentinel: centre at the span start, a2 = 1, K = 0, no Gaussian reach
+        lh[SKEW_CH * 4] = (double)wlo; lh[SKEW_CH * 4 + 1] = 1.0; lh[SKEW_CH * 4 + 2] = 0.0; lh[SKEW_CH * 4 + 3] = 0.0;
+        lc[SKEW_CH * 4] = 0.0; lc[SKEW_CH * 4 + 1] = 0.0; lc[SKEW_CH * 4 + 2] = 1.0; lc[SKEW_CH * 4 + 3] = 0.0;
+    }
+    for (int c0 = iA; c0 < iD; c0 += SKEW_CH) {
+        const int n = min(SKEW_CH, iD - c0);
+        zero_counters();
+        unsigned long long dmask[NROUND];
+        int cen[NROUND];
+        bool live[NROUND];
+        int reach = 0;
+#pragma unroll
+        for (int r = 0; r < NROUND; ++r) {
+            dmask[r] = 0ull; cen[r] = 0; live[r] = false;
+            if (r * 64 >= n) continue;                    // (wave-uniform)
+            const int s = r * 64 + lane;
+            const bool valid = s < n;
+            v2f64 h0 = {0, 1}, h1 = {0, 0}, q0 = {0, 0}, q1 = {0, 0};
+            if (valid) {
+                const long long g = (long long)(c0 + s) * 2;
+                h0 = gh[g]; h1 = gh[g + 1];
+                q0 = gc[g]; q1 = gc[g + 1];
+            }
+            const int dgi = valid ? __double2loint(h1.y) : 0, fl = __double2hiint(h1.y);
+            const bool direct = valid && (fl & REC_DIRECT_DIV) != 0;
+            dmask[r] = __ballot(direct);
+            if (direct) { h0.y = 1.0; h1.x = 0.0; }                           // a2 = 1, KL = 0 in the walk's copy
+            // Gaussian reach as a double: the term can matter for a lane whose R points come within dgi of the centre
+            h1.y = dgi > 0 ? (double)dgi + 0.5 * (R - 1) : 0.0;
+            reach = max(reach, dgi);
+            live[r] = valid;
+            cen[r] = (int)h0.x;
+            if (valid) {
+                reinterpret_cast<v2f64*>(lh)[s * 2] = h0;
+                reinterpret_cast<v2f64*>(lh)[s * 2 + 1] = h1;
+                reinterpret_cast<v2f64*>(lc)[s * 2] = q0;
+                reinterpret_cast<v2f64*>(lc)[s * 2 + 1] = q1;
+                // left family: base wlo - H (A', A); right family: base wlo + H + 1 (B, B')
+                atomicMax(&cntL[slot(cen[r], wlo - H)], (unsigned int)(s + 1));
+                atomicMax(&cntR[slot(cen[r], wlo + H + 1)], (unsigned int)(s + 1));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int a_part, a_full, b_full, b_part;
+        skew_counts<R>(cntL, lane, a_part, a_full);
+        skew_counts<R>(cntR, lane, b_full, b_part);
+        if (a_full >= b_full) { a_full = b_part; b_full = b_part; }         // support narrower than the lane's R points: all masked
+        // Gaussian ranges from the largest reach of the chunk: records with centre in [p0 - g, p0 + R-1 + g], g = reach - 1
+        int g_lo = 0, g_hi = 0;
+        const int gmax = wave_max_i32(reach);
+        if (gmax > 0 && !(ablate & 1)) {
+            const int g = gmax - 1;
+            zero_counters();
+#pragma unroll
+            for (int r = 0; r < NROUND; ++r) {
+                if (live[r]) {
+                    atomicMax(&cntL[slot(cen[r], wlo - g)], (unsigned int)(r * 64 + lane + 1));
+                    atomicMax(&cntR[slot(cen[r], wlo + g + 1)], (unsigned int)(r * 64 + lane + 1));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int unused;
+            skew_counts<R>(cntL, lane, g_lo, unused);
+            skew_counts<R>(cntR, lane, unused, g_hi);
+            g_lo = max(g_lo, a_part); g_hi = min(g_hi, b_part);             // only lines whose support reaches the lane's points
+        }
+        if (!(ablate & 2)) skew_lorentz<R, true, true>(lh, SKEW_CH, a_part, a_full - a_part, b_full, b_part - b_full, x0, Hf, S, it);
+        if (!(ablate & 4)) skew_lorentz<R, false, false>(lh, SKEW_CH, a_full, b_full - a_full, 0, 0, x0, Hf, S, it);
+        // a record within reach g of a lane's block has |d| <= g + R - 1 at every point of the lane
+        if (gmax + R - 2 <= H) skew_gauss<R, false>(lh, COLD, SKEW_CH, g_lo, g_hi, x0, Hf, S);
+        else skew_gauss<R, true>(lh, COLD, SKEW_CH, g_lo, g_hi, x0, Hf, S);
+        // lines whose denominator is outside the running-fraction range (K1: REC_DIRECT_DIV): plain divide
+#pragma unroll
+        for (int r = 0; r < NROUND; ++r) {
+            unsigned long long dm = dmask[r];
+            while (dm) {
+                const int s = r * 64 + __builtin_ctzll(dm);
+                dm &= dm - 1;
+                const double d0 = x0 - lh[s * 4];
+                const double* c = lc + s * 4;
+                const double a2 = 1.0 / c[1], KL = c[3];
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const double d = d0 + (double)k;
+                    const double t = KL / fma(d, d, a2);
+                    S.acc[k] += (fabs(d) <= Hf) ? t : 0.0;
+                }
+            }
+        }
+    }
+    S.flush();
+
+    // results leave through LDS so that every store instruction writes 512 contiguous bytes
+    double* mine = s_rec[wave];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < R; ++k) mine[span_slot(lane * R + k)] = S.acc[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double* __restrict__ out = J.out;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int o = i * 64 + lane;
+        const double t = mine[span_slot(o)];
+        if (wlo + o < n_end) {
+            out[wlo + o] = t;
+            if (J.fuse.on) {
+                double xs_m = 0.0, kk = 0.0;
+                fused_fold(J.fuse, J, t, xs_m, kk);
+                fused_finish(J.fuse, wlo + o, kk);
+            }
+        }
+    }
+}
+
 // ---- variant 4: balanced single-round partition -----------------------------------------------
 // Small grids do not fill the chip evenly with one workgroup per span: C2 has 1.5-3 rounds of
 // workgroups of very different length (line density varies 7x) and ran with the VALU only 55-69 %
@@ -1582,6 +1893,22 @@ static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, 
         case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
         case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
         default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
+    }
+}
+
+void launch_accumulate_skew(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, const int2* worklist, int total_tiles,
+                            hipStream_t s) {
+    if (n_jobs <= 0 || max_tiles <= 0) return;
+    dim3 grid(((max_tiles + 7) / 8) * 8, n_jobs);
+    if (worklist) {
+        if (total_tiles <= 0) return;
+        grid = dim3(total_tiles, 1);
+    }
+    switch (R) {
+        case 8: hipLaunchKernelGGL((xsec_accumulate_skew_kernel<8>), grid, dim3(256), 0, s, d_jobs, worklist); break;
+        case 2: hipLaunchKernelGGL((xsec_accumulate_skew_kernel<2>), grid, dim3(256), 0, s, d_jobs, worklist); break;
+        case 1: hipLaunchKernelGGL((xsec_accumulate_skew_kernel<1>), grid, dim3(256), 0, s, d_jobs, worklist); break;
+        default: hipLaunchKernelGGL((xsec_accumulate_skew_kernel<4>), grid, dim3(256), 0, s, d_jobs, worklist); break;
     }
 }
 

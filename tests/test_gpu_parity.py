@@ -748,3 +748,102 @@ def test_host_span_tables_agree_with_device_search(ctx):
         b, cb, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, rmin, rmax, res, False, 5, R, LS)
         assert tuple(ca) == tuple(cb)
         assert np.array_equal(a, b), (R, LS)
+
+
+def random_cell(rng, seed, orc, max_evals=2e6):
+    """a random gas cell as in test_random_cells_against_oracle: (lines, species, conc, T, P, rmin, rmax, base, dyn, g)"""
+    base = float(rng.choice([0.01, 0.001, 0.0001]))
+    dyn = bool(rng.integers(0, 2))
+    P = float(np.exp(rng.uniform(np.log(0.05), np.log(20000.0))))
+    T = int(rng.integers(150, 351))
+    rmin = float(rng.choice([0.0, 0.5, 37.0, 600.0, 2499.3, 12000.0]))
+    g0 = orc.layer_grid(P, rmin, rmin + 1.0, base, dyn)
+    width = float(min(rng.uniform(0.02, 30.0), 60000 * g0["resolution"], 20000 * base))
+    rmax = rmin + width
+    g = orc.layer_grid(P, rmin, rmax, base, dyn)
+    if g["W"] < 1 or g["n_base"] < 1 or g["n_work"] < 1:
+        return None
+    n_lines = int(rng.choice([0, 1, 2, 17, 150, 400, 1500]))
+    n_lines = int(min(n_lines, max(1, max_evals // max(g["W"], 1)))) if n_lines else 0
+    if n_lines:
+        lines = synthetic.make_lines(7000 + seed, n_lines, g["eff_min"], g["eff_max"], decimals=int(rng.choice([3, 7])))
+    else:
+        lines = {k: np.zeros(0) for k in synthetic.FIELDS}
+    species = str(rng.choice(["co2", "h2o", "ch4", "o3"]))
+    conc = float(rng.choice([4e-4, 1e-2, 0.5, 1.8e-6]))
+    return lines, species, conc, T, P, rmin, rmax, base, dyn, g
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_skew_kernel_random_cells(ctx, orc, seed):
+    """The skewed-range kernel (narrow windows; lbl_set_option accum_skew 2 sends EVERY job through it) on random
+    gas cells: windows from 1 point to thousands (also far wider than it is meant for), all regimes, duplicate
+    centres (lines rounded to 3 decimals on a 0.0001 grid pile up on one index), empty lists, every R; whole
+    spectrum against the oracle with the per-point tolerance, and against the span kernel."""
+    from conftest import point_tolerance, rel_err_points
+    rng = np.random.default_rng(3000 + seed)
+    cell = random_cell(rng, seed, orc)
+    if cell is None:
+        pytest.skip("degenerate grid (the reference raises)")
+    lines, species, conc, T, P, rmin, rmax, base, dyn, g = cell
+    sp = synthetic.SPECIES[species]
+    ref, rc = orc.create_cross_section(orc.select_window(lines, g["eff_min"], g["eff_max"]), T, P, conc, sp["molmass"],
+                                       synthetic.q_value(species, T), sp["q296"], g)
+    tol = point_tolerance(orc.x_axis(rmin, rmax, base), T, g["dfc"])
+    floor = float(np.max(np.abs(ref))) * FLOOR_REL if ref.size else 0.0
+    span, _, _, _, _ = device_xsec(ctx, lines, species, conc, T, P, rmin, rmax, base, dyn)
+    try:
+        ctx.set_option("accum_skew", 2)
+        for R in (4, 8, 2, 1):
+            ctx.set_option("accum_skew_points_per_lane", R)
+            xs, counts, gd, sel, _ = device_xsec(ctx, lines, species, conc, T, P, rmin, rmax, base, dyn)
+            assert tuple(counts) == tuple(rc)
+            e = rel_err_points(xs, ref, floor)
+            assert np.all(e <= tol), (R, float(e.max()), int(np.argmax(e / tol)), g["W"], len(sel["nu"]))
+            assert np.all(rel_err_points(xs, span, floor) <= 2 * tol), R
+            xs2, _, _, _, _ = device_xsec(ctx, lines, species, conc, T, P, rmin, rmax, base, dyn)
+            assert np.array_equal(xs, xs2)                       # bit-identical rerun
+    finally:
+        ctx.set_option("accum_skew", 1)
+        ctx.set_option("accum_skew_points_per_lane", 4)
+
+
+def test_skew_kernel_resident_column_matches_span_kernel(ctx, orc):
+    """A 6-layer column whose windows run from 5000 down to 60 points, on a grid large enough for the default
+    routing to pick the skewed-range kernel for the narrow layers: the outgoing spectrum and every layer's
+    transmittance against the same column with the span kernel only (accum_skew 0), and the sharded column."""
+    from pyrad_amd import engine
+    sp = {k: synthetic.SPECIES[k] for k in ("co2", "h2o")}
+    rmin, rmax = 600.0, 1200.0                      # 600,000 points at 0.001
+    cfgs = []
+    for i, P in enumerate((1013.25, 400.0, 150.0, 60.0, 25.0, 12.0)):
+        g = orc.layer_grid(P, rmin, rmax, .001, False)
+        T = 288 - 12 * i
+        mols = [dict(conc=c, isotopologues=[dict(lines=synthetic.make_lines(40 + s, 20000, g["eff_min"], g["eff_max"]),
+                                                 molmass=sp[k]["molmass"], q_T=synthetic.q_value(k, T), q296=sp[k]["q296"])])
+                for s, (k, c) in enumerate((("co2", 4e-4), ("h2o", 1e-2)))]
+        cfgs.append(dict(depth=1e4 * (i + 1), T=T, P=P, range_min=rmin, range_max=rmax, molecules=mols,
+                         base_resolution=.001, dynamic_resolution=False))
+    res = {}
+    for skew in (1, 0):
+        ctx.set_option("accum_skew", skew)
+        try:
+            col = engine.ResidentColumn(ctx, cfgs, 288.0)
+            col.enqueue(layer_arrays=True)
+            res[skew] = col.results()
+            col.free()
+        finally:
+            ctx.set_option("accum_skew", 1)
+    assert rel_err(res[1]["toa"], res[0]["toa"]) <= 1e-13
+    for a, b in zip(res[1]["transmittance"], res[0]["transmittance"]):
+        # transmittance = exp(-k depth): a relative difference e of k is a relative difference e * (-ln tr) of tr
+        ok = b > 1e-290                              # below: exp() underflows gradually, compare for presence only
+        assert np.all(np.abs(a[ok] - b[ok]) <= (1e-13 * -np.log(b[ok]) + 4e-16) * b[ok]) and np.all(a[~ok] <= 1e-289)
+    assert not np.array_equal(res[1]["transmittance"][5], res[0]["transmittance"][5])      # it WAS another kernel
+    toa = np.zeros(res[1]["toa"].size)
+    for rank in range(3):
+        part = engine.ResidentColumn(ctx, cfgs, 288.0, shard=(3, rank))
+        part.enqueue()
+        toa[part.first:part.first + part.count] = part.results()["toa"][part.first:part.first + part.count]
+        part.free()
+    assert rel_err(toa, res[1]["toa"]) <= 1e-13
