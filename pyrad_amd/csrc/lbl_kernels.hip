@@ -934,170 +934,6 @@ __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec
     }
 }
 
-// Fused sweep of a layer with ONE line list (lbl_layer_step_dev): the arithmetic and operation order of
-// layer_sweep_kernel applied in the accumulate kernel's output stage, where the cross section of a point
-// is in a register:  xs_m = 0 + cross section (pyradClasses.py:566-571), k = 0 + xs_m * conc * P / 1E4 /
-// kB / T (pyradClasses.py:583, 707-712).  Layers with several line lists keep the separate sweep launch:
-// both ways of folding them into this kernel were built and measured slower (DESIGN.md "what did not help":
-// one workgroup walking all line lists of its points, -6 %; the last workgroup of a tile folding it, -3 %).
-__device__ __forceinline__ void fused_fold(const FusedSweep& A, const AccumJob& J, double xsec, double& xs_m, double& kk) {
-#pragma clang fp contract(off)
-    if (J.chain_flags & CHAIN_MOL_FIRST) xs_m = 0.0;
-    xs_m += xsec;
-    if (J.chain_flags & CHAIN_MOL_LAST) kk += abs_coef_term(xs_m, J.conc, A.P, A.T, A.rT);
-}
-
-// after the last line list: transmittance and outgoing radiance of the point
-// (pyradClasses.py:716, 784-787; pyradPlanck.py:38-44)
-__device__ __forceinline__ void fused_finish(const FusedSweep& A, long long j, double kk) {
-#pragma clang fp contract(off)
-    if (A.abs_coef) A.abs_coef[j] = kk;
-    const double tr = exp(-kk * A.depth);
-    if (A.trans) A.trans[j] = tr;
-    if (A.I_out) {
-        const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
-        const double B = planck_wn(nu, A.T, A.rT, A.pa, A.pb);
-        const double Iin = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.r_surface_T, A.pa, A.pb);
-        const double transmitted = tr * Iin;
-        const double emitted = (1.0 - tr) * B;
-        A.I_out[j] = transmitted + emitted;
-    }
-}
-
-
-template <int R, int LS, bool FF = false>
-__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), ((R >= 4 && LS <= 4) ? 4 : 1))     // HIP: min waves per SIMD
-void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* __restrict__ worklist) {
-    constexpr int NW = LS > 4 ? LS : 4;              // wavefronts per workgroup (LS = 8: 512 threads)
-    constexpr int PG = NW / LS;                      // point groups (64*R points each) per workgroup
-    // per wave: hot records [0,256), cold records [256,512); after the line loop the same words
-    // hold the wave's 64*R sums in point order (+ padding) for the coalesced store
-    constexpr int STAGE_MIN = FF ? 576 : 512;        // FF: 8 x 72 doubles for wave_sum_rows
-    constexpr int STAGE = (68 * R > STAGE_MIN) ? 68 * R : STAGE_MIN;
-    __shared__ double s_stage[NW][STAGE];
-
-    // worklist: (job, tile) pairs of the whole launch sorted by decreasing line count (longest
-    // first), built once per (line lists, grid) on the host; without it blockIdx.y is the job
-    int job = blockIdx.y, tile;
-    if (worklist) {
-        const int2 wk = worklist[blockIdx.x];
-        job = wk.x; tile = wk.y;
-    } else {
-        tile = xcd_tile(blockIdx.x, jobs[job].n_tiles, jobs[job].pad);
-    }
-    const AccumJob& J = jobs[job];
-    const int lane = threadIdx.x & 63;
-    const int wave = uniform_i32(threadIdx.x >> 6);
-    const int grp = wave / LS, part = wave % LS;
-    const int n_end = J.p_end;
-    const long long wave_lo_ll = (long long)J.p_begin + (long long)(tile < 0 ? 0 : tile) * (64LL * R * PG) + (long long)grp * (64LL * R);
-    const bool active = tile >= 0 && wave_lo_ll < n_end;
-    if (LS == 1 && !active) return;                  // no workgroup barrier below when waves do not share points
-    const int wlo = active ? (int)wave_lo_ll : 0;
-    const int whi = active ? min(wlo + 64 * R - 1, n_end - 1) : 0;
-    const int H = J.H;
-    const int p0 = wlo + lane * R;
-    const double x0 = (double)p0;
-    const double Hf = (double)H;
-    WaveAcc<R> S;
-    S.init(J.flush_every);
-    double* lh = s_stage[wave];
-    double* lc = s_stage[wave] + 256;
-
-    // line ranges of this span: tabulated by the host with the schedule, else searched here
-    const int32_t* tab = nullptr;
-    if (active && J.span_tab) tab = J.span_tab + (size_t)((wlo - J.p_begin) / (64 * R)) * 8;
-    if (active && !FF) {
-        int iA, iB, iC, iD;
-        if (tab) { iA = uniform_i32(tab[0]); iB = uniform_i32(tab[1]); iC = uniform_i32(tab[2]); iD = uniform_i32(tab[3]); }
-        else wave_line_ranges(J.cidx, J.n_lines, wlo, whi, H, lane, iA, iB, iC, iD);
-        // this wave's share of the span's lines: every LS-th chunk of 64, starting at chunk `part`
-        double G[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) G[k] = 0.0;
-        accumulate_lines<R, 2>(J.hot, J.cold, iA + part * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64 * LS);
-        if (R == 4) gauss_runs16_fold<R>(G, s_stage[wave], lane, S.acc);
-        S.flush();
-    }
-    if (active && FF) {
-        // interior lines at least FF_FAR half-spans from the span centre go through the series; the
-        // chunks of every class are dealt round-robin to the LS waves, each class starting at a
-        // different wave so that the short classes do not all land on wave 0
-        const long long fl = (long long)wlo + 32 * R - 1 - (long long)FF_FAR * 32 * R;
-        const long long fr = (long long)wlo + 32 * R + (long long)FF_FAR * 32 * R;
-        const double xc = (double)wlo + (32.0 * R - 0.5);
-        int iA, iB, iC, iD, iF1, iF2;
-        if (tab) {           // wave-uniform values: keep them in scalar registers
-            iA = uniform_i32(tab[0]); iB = uniform_i32(tab[1]); iC = uniform_i32(tab[2]); iD = uniform_i32(tab[3]);
-            iF1 = uniform_i32(tab[4]); iF2 = uniform_i32(tab[5]);
-        }
-        else wave_line_ranges_far(J.cidx, J.n_lines, wlo, whi, H, fl, fr, lane, iA, iB, iC, iD, iF1, iF2);
-        const bool any_far = (iF1 - iB) + (iC - iF2) > 0;
-        if (any_far) {
-            double C[FF_NT];
-#pragma unroll
-            for (int n = 0; n < FF_NT; ++n) C[n] = 0.0;
-            far_field_lines<R>(J.hot, J.cold, iB + ((part + 1) % LS) * 64, iF1, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S);
-            far_field_lines<R>(J.hot, J.cold, iF2 + ((part + 2) % LS) * 64, iC, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S);
-            wave_sum_rows<FF_NT>(C, s_stage[wave], lane);
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const double tau = ((x0 + (double)k) - xc) * (1.0 / (32.0 * R));
-                double v = C[FF_NT - 1];
-#pragma unroll
-                for (int n = FF_NT - 2; n >= 0; --n) v = fma(v, tau, C[n]);
-                S.acc[k] += v;
-            }
-        }
-        // the direct classes: left-edge, near and right-edge lines.  Without far lines (narrow window)
-        // they are one contiguous run and go through the first stream alone (one prologue, not three).
-        // (the LS waves of a span interleave these classes line by line; series chunks are dealt whole)
-        // (Gaussian parts of interior lines: 16-point runs into G, folded into the sums once per span)
-        double G[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) G[k] = 0.0;
-        accumulate_lines<R, 1>(J.hot, J.cold, iA, any_far ? iB : iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
-        if (any_far) {
-            accumulate_lines<R, 1>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
-            accumulate_lines<R, 1>(J.hot, J.cold, iC, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
-        }
-        if (R == 4) gauss_runs16_fold<R>(G, s_stage[wave], lane, S.acc);
-        S.flush();
-    }
-
-    // Results leave through LDS so that every store instruction writes 512 contiguous bytes
-    // (a lane owns R CONSECUTIVE points; storing them directly would touch 64 cache lines per
-    // instruction).  With LS > 1 the LS partial sums of a span meet here in a fixed order.
-    double* mine = s_stage[wave];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < R; ++k) mine[span_slot(lane * R + k)] = S.acc[k];
-    if (LS > 1) __syncthreads();
-    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-    if (active) {
-        // the LS waves of a span share its output rows (and the fused sweep of their points); every
-        // point is summed over the waves in the same order whichever wave stores it
-        double* __restrict__ out = J.out;
-        const int w0 = wave - part;                      // first wave of this span
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            if (LS > 1 && (i % LS) != part) continue;        // row i belongs to wave i % LS of the span
-            const int o = i * 64 + lane;
-            double t = s_stage[w0][span_slot(o)];
-            for (int q = 1; q < LS; ++q) t += s_stage[w0 + q][span_slot(o)];
-            if (wlo + o < n_end) {
-                out[wlo + o] = t;
-                if (J.fuse.on) {
-                    // a layer with ONE line list: the sweep of a point right here, its cross section is in a register
-                    double xs_m = 0.0, kk = 0.0;
-                    fused_fold(J.fuse, J, t, xs_m, kk);
-                    fused_finish(J.fuse, wlo + o, kk);
-                }
-            }
-        }
-    }
-}
-
 // ---- narrow windows: skewed line ranges ---------------------------------------------------------
 // The upper layers of a column have windows of 50-640 points (pyradClasses.py:655: 5 P / 1013.25 cm^-1).
 // In the span kernel above a wave walks every line that reaches ANY of its 64 R points, and most of
@@ -1201,6 +1037,246 @@ __device__ __forceinline__ void skew_lorentz(const double* __restrict__ lh, int 
         it += nb;
         t0 += nb;
         if (it >= S.every) { S.flush(); it = 0; }
+    }
+}
+
+// Edge lines of a span of the far-field kernel (support ends inside the span) through the skewed walk: the
+// left-edge lines [iA, iB) and the right-edge lines [iC, iD) are staged side by side (64 + 64 records per
+// round), every lane counts the ones that reach its R points - a lane near the left end of the span has
+// many left-edge and few right-edge lines, a lane near the right end the opposite, the sum is the same for
+// all lanes - and walks them in one unmasked loop (lines covering all its points) and one masked loop (the
+// 0-2 lines that cover only some).  14 unmasked iterations for all lanes instead of 28 masked ones.
+// Rounds with a record whose Gaussian part reaches the span, or whose denominator needs the plain divide,
+// take the masked span path (accumulate_lines); K1's cut-off makes that rare for windows this wide.
+template <int R>
+__device__ __forceinline__ void skew_edges(const HotRec* hot, const ColdRec* cold, int iA, int iB, int iC, int iD, int wlo,
+                                           int whi, int H, double x0, double Hf, double* lh, double* lc,
+                                           unsigned int* cntL, unsigned int* cntR, int lane, WaveAcc<R>& S) {
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    typedef const v2f64 __attribute__((address_space(1)))* GlobalF64x2;
+    const GlobalF64x2 gh = (GlobalF64x2)(unsigned long long)hot;
+    constexpr int SENT = 128;                             // records 0..63: left-edge, 64..127: right-edge, 128: the sentinel
+    auto slot = [&](int c, int base) { const int i = c - base + 1; return i < 0 ? 0 : (i > 64 * R + 1 ? 64 * R + 1 : i); };
+    for (int cL = iA, cR = iC; cL < iB || cR < iD; cL += 64, cR += 64) {
+        const int nL = max(min(iB - cL, 64), 0), nR = max(min(iD - cR, 64), 0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < R; ++k) { cntL[lane * R + k] = 0u; cntR[lane * R + k] = 0u; }
+        if (lane < 8) { cntL[64 * R + lane] = 0u; cntR[64 * R + lane] = 0u; }
+        if (lane == 0) { lh[SENT * 4] = (double)wlo; lh[SENT * 4 + 1] = 1.0; lh[SENT * 4 + 2] = 0.0; lh[SENT * 4 + 3] = 0.0; }
+        v2f64 l0 = {0, 1}, l1 = {0, 0}, r0 = {0, 1}, r1 = {0, 0};
+        const bool vL = lane < nL, vR = lane < nR;
+        if (vL) { const long long g = (long long)(cL + lane) * 2; l0 = gh[g]; l1 = gh[g + 1]; }
+        if (vR) { const long long g = (long long)(cR + lane) * 2; r0 = gh[g]; r1 = gh[g + 1]; }
+        const int ciL = (int)l0.x, ciR = (int)r0.x;
+        // the walk adds Lorentz terms only: a record with a Gaussian part that reaches the span, or outside the
+        // running-fraction range, sends this round through the masked span path
+        const bool oddL = vL && (max(0, max(ciL - whi, wlo - ciL)) < __double2loint(l1.y) || (__double2hiint(l1.y) & REC_DIRECT_DIV));
+        const bool oddR = vR && (max(0, max(ciR - whi, wlo - ciR)) < __double2loint(r1.y) || (__double2hiint(r1.y) & REC_DIRECT_DIV));
+        if (__any(oddL || oddR)) {
+            double unused[16];                             // (no 16-point Gaussian runs on this path: 4-point passes into the sums)
+            if (nL > 0) accumulate_lines<R, 0>(hot, cold, cL, cL + nL, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, unused, 64, 1, 0);
+            if (nR > 0) accumulate_lines<R, 0>(hot, cold, cR, cR + nR, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, unused, 64, 1, 0);
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (vL) {
+            reinterpret_cast<v2f64*>(lh)[lane * 2] = l0;
+            reinterpret_cast<v2f64*>(lh)[lane * 2 + 1] = l1;
+            atomicMax(&cntL[slot(ciL, wlo - H)], (unsigned int)(lane + 1));              // A', A
+        }
+        if (vR) {
+            reinterpret_cast<v2f64*>(lh)[(64 + lane) * 2] = r0;
+            reinterpret_cast<v2f64*>(lh)[(64 + lane) * 2 + 1] = r1;
+            atomicMax(&cntR[slot(ciR, wlo + H + 1)], (unsigned int)(lane + 1));          // B, B'
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int a_part, a_full, b_full, b_part;
+        skew_counts<R>(cntL, lane, a_part, a_full);
+        skew_counts<R>(cntR, lane, b_full, b_part);
+        int it = S.cnt;
+        // lines covering all of the lane's points: left-edge [a_full, nL), right-edge [0, b_full); then the partial ones
+        skew_lorentz<R, false, true>(lh, SENT, a_full, nL - a_full, 64, b_full, x0, Hf, S, it);
+        skew_lorentz<R, true, true>(lh, SENT, a_part, a_full - a_part, 64 + b_full, b_part - b_full, x0, Hf, S, it);
+        S.cnt = it;
+    }
+}
+
+// Fused sweep of a layer with ONE line list (lbl_layer_step_dev): the arithmetic and operation order of
+// layer_sweep_kernel applied in the accumulate kernel's output stage, where the cross section of a point
+// is in a register:  xs_m = 0 + cross section (pyradClasses.py:566-571), k = 0 + xs_m * conc * P / 1E4 /
+// kB / T (pyradClasses.py:583, 707-712).  Layers with several line lists keep the separate sweep launch:
+// both ways of folding them into this kernel were built and measured slower (DESIGN.md "what did not help":
+// one workgroup walking all line lists of its points, -6 %; the last workgroup of a tile folding it, -3 %).
+__device__ __forceinline__ void fused_fold(const FusedSweep& A, const AccumJob& J, double xsec, double& xs_m, double& kk) {
+#pragma clang fp contract(off)
+    if (J.chain_flags & CHAIN_MOL_FIRST) xs_m = 0.0;
+    xs_m += xsec;
+    if (J.chain_flags & CHAIN_MOL_LAST) kk += abs_coef_term(xs_m, J.conc, A.P, A.T, A.rT);
+}
+
+// after the last line list: transmittance and outgoing radiance of the point
+// (pyradClasses.py:716, 784-787; pyradPlanck.py:38-44)
+__device__ __forceinline__ void fused_finish(const FusedSweep& A, long long j, double kk) {
+#pragma clang fp contract(off)
+    if (A.abs_coef) A.abs_coef[j] = kk;
+    const double tr = exp(-kk * A.depth);
+    if (A.trans) A.trans[j] = tr;
+    if (A.I_out) {
+        const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
+        const double B = planck_wn(nu, A.T, A.rT, A.pa, A.pb);
+        const double Iin = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.r_surface_T, A.pa, A.pb);
+        const double transmitted = tr * Iin;
+        const double emitted = (1.0 - tr) * B;
+        A.I_out[j] = transmitted + emitted;
+    }
+}
+
+
+template <int R, int LS, bool FF = false>
+__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), ((R >= 4 && LS <= 4) ? 4 : 1))     // HIP: min waves per SIMD
+void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* __restrict__ worklist) {
+    constexpr int NW = LS > 4 ? LS : 4;              // wavefronts per workgroup (LS = 8: 512 threads)
+    constexpr int PG = NW / LS;                      // point groups (64*R points each) per workgroup
+    // per wave: hot records [0,256), cold records [256,512); after the line loop the same words
+    // hold the wave's 64*R sums in point order (+ padding) for the coalesced store
+    constexpr int STAGE_MIN = FF ? 576 : 512;        // FF: 8 x 72 doubles for wave_sum_rows
+    constexpr int STAGE = (68 * R > STAGE_MIN) ? 68 * R : STAGE_MIN;
+    __shared__ double s_stage[NW][STAGE];
+    // edge lines through the skewed walk (skew_edges): the production shape only (unsplit spans of 256 points)
+    constexpr bool EDGE_SKEW = FF && LS == 1 && R == 4;
+    __shared__ unsigned int s_ecnt[EDGE_SKEW ? NW : 1][2][EDGE_SKEW ? 64 * R + 8 : 1];
+
+    // worklist: (job, tile) pairs of the whole launch sorted by decreasing line count (longest
+    // first), built once per (line lists, grid) on the host; without it blockIdx.y is the job
+    int job = blockIdx.y, tile;
+    if (worklist) {
+        const int2 wk = worklist[blockIdx.x];
+        job = wk.x; tile = wk.y;
+    } else {
+        tile = xcd_tile(blockIdx.x, jobs[job].n_tiles, jobs[job].pad);
+    }
+    const AccumJob& J = jobs[job];
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform_i32(threadIdx.x >> 6);
+    const int grp = wave / LS, part = wave % LS;
+    const int n_end = J.p_end;
+    const long long wave_lo_ll = (long long)J.p_begin + (long long)(tile < 0 ? 0 : tile) * (64LL * R * PG) + (long long)grp * (64LL * R);
+    const bool active = tile >= 0 && wave_lo_ll < n_end;
+    if (LS == 1 && !active) return;                  // no workgroup barrier below when waves do not share points
+    const int wlo = active ? (int)wave_lo_ll : 0;
+    const int whi = active ? min(wlo + 64 * R - 1, n_end - 1) : 0;
+    const int H = J.H;
+    const int p0 = wlo + lane * R;
+    const double x0 = (double)p0;
+    const double Hf = (double)H;
+    WaveAcc<R> S;
+    S.init(J.flush_every);
+    double* lh = s_stage[wave];
+    double* lc = s_stage[wave] + 256;
+
+    // line ranges of this span: tabulated by the host with the schedule, else searched here
+    const int32_t* tab = nullptr;
+    if (active && J.span_tab) tab = J.span_tab + (size_t)((wlo - J.p_begin) / (64 * R)) * 8;
+    if (active && !FF) {
+        int iA, iB, iC, iD;
+        if (tab) { iA = uniform_i32(tab[0]); iB = uniform_i32(tab[1]); iC = uniform_i32(tab[2]); iD = uniform_i32(tab[3]); }
+        else wave_line_ranges(J.cidx, J.n_lines, wlo, whi, H, lane, iA, iB, iC, iD);
+        // this wave's share of the span's lines: every LS-th chunk of 64, starting at chunk `part`
+        double G[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) G[k] = 0.0;
+        accumulate_lines<R, 2>(J.hot, J.cold, iA + part * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64 * LS);
+        if (R == 4) gauss_runs16_fold<R>(G, s_stage[wave], lane, S.acc);
+        S.flush();
+    }
+    if (active && FF) {
+        // interior lines at least FF_FAR half-spans from the span centre go through the series; the
+        // chunks of every class are dealt round-robin to the LS waves, each class starting at a
+        // different wave so that the short classes do not all land on wave 0
+        const long long fl = (long long)wlo + 32 * R - 1 - (long long)FF_FAR * 32 * R;
+        const long long fr = (long long)wlo + 32 * R + (long long)FF_FAR * 32 * R;
+        const double xc = (double)wlo + (32.0 * R - 0.5);
+        int iA, iB, iC, iD, iF1, iF2;
+        if (tab) {           // wave-uniform values: keep them in scalar registers
+            iA = uniform_i32(tab[0]); iB = uniform_i32(tab[1]); iC = uniform_i32(tab[2]); iD = uniform_i32(tab[3]);
+            iF1 = uniform_i32(tab[4]); iF2 = uniform_i32(tab[5]);
+        }
+        else wave_line_ranges_far(J.cidx, J.n_lines, wlo, whi, H, fl, fr, lane, iA, iB, iC, iD, iF1, iF2);
+        const bool any_far = (iF1 - iB) + (iC - iF2) > 0;
+        // edge lines first (skewed walk), while neither the series coefficients nor the Gaussian run sums are live
+        const bool edges_done = EDGE_SKEW && any_far && !(J.ablate & 8);
+        if (edges_done)
+            skew_edges<R>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, lh, lc, s_ecnt[EDGE_SKEW ? wave : 0][0],
+                          s_ecnt[EDGE_SKEW ? wave : 0][1], lane, S);
+        if (any_far) {
+            double C[FF_NT];
+#pragma unroll
+            for (int n = 0; n < FF_NT; ++n) C[n] = 0.0;
+            far_field_lines<R>(J.hot, J.cold, iB + ((part + 1) % LS) * 64, iF1, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S);
+            far_field_lines<R>(J.hot, J.cold, iF2 + ((part + 2) % LS) * 64, iC, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S);
+            wave_sum_rows<FF_NT>(C, s_stage[wave], lane);
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double tau = ((x0 + (double)k) - xc) * (1.0 / (32.0 * R));
+                double v = C[FF_NT - 1];
+#pragma unroll
+                for (int n = FF_NT - 2; n >= 0; --n) v = fma(v, tau, C[n]);
+                S.acc[k] += v;
+            }
+        }
+        // the direct classes: left-edge, near and right-edge lines.  Without far lines (narrow window)
+        // they are one contiguous run and go through the first stream alone (one prologue, not three).
+        // (the LS waves of a span interleave these classes line by line; series chunks are dealt whole)
+        // (Gaussian parts of interior lines: 16-point runs into G, folded into the sums once per span)
+        double G[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) G[k] = 0.0;
+        if (edges_done) {
+            accumulate_lines<R, 1>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+        } else {
+            accumulate_lines<R, 1>(J.hot, J.cold, iA, any_far ? iB : iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+            if (any_far) {
+                accumulate_lines<R, 1>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+                accumulate_lines<R, 1>(J.hot, J.cold, iC, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+            }
+        }
+        if (R == 4) gauss_runs16_fold<R>(G, s_stage[wave], lane, S.acc);
+        S.flush();
+    }
+
+    // Results leave through LDS so that every store instruction writes 512 contiguous bytes
+    // (a lane owns R CONSECUTIVE points; storing them directly would touch 64 cache lines per
+    // instruction).  With LS > 1 the LS partial sums of a span meet here in a fixed order.
+    double* mine = s_stage[wave];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < R; ++k) mine[span_slot(lane * R + k)] = S.acc[k];
+    if (LS > 1) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    if (active) {
+        // the LS waves of a span share its output rows (and the fused sweep of their points); every
+        // point is summed over the waves in the same order whichever wave stores it
+        double* __restrict__ out = J.out;
+        const int w0 = wave - part;                      // first wave of this span
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            if (LS > 1 && (i % LS) != part) continue;        // row i belongs to wave i % LS of the span
+            const int o = i * 64 + lane;
+            double t = s_stage[w0][span_slot(o)];
+            for (int q = 1; q < LS; ++q) t += s_stage[w0 + q][span_slot(o)];
+            if (wlo + o < n_end) {
+                out[wlo + o] = t;
+                if (J.fuse.on) {
+                    // a layer with ONE line list: the sweep of a point right here, its cross section is in a register
+                    double xs_m = 0.0, kk = 0.0;
+                    fused_fold(J.fuse, J, t, xs_m, kk);
+                    fused_finish(J.fuse, wlo + o, kk);
+                }
+            }
+        }
     }
 }
 
