@@ -42,6 +42,8 @@ struct lbl_ctx {
     DeviceArena counts;     // per-block regime counts of the last batch
     DeviceArena bal;        // balanced variant: span table, counts, prefix, slab
     DeviceArena red;        // band-integral partials + result
+    DeviceArena zeros;      // an array of zeros: the cross section of a column layer without line lists
+    size_t zeros_set = 0;
     void* host_stage = nullptr;   // pinned staging ring for job descriptors
     size_t host_stage_cap = 0;
     size_t host_stage_head = 0;
@@ -308,7 +310,7 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) try {
     for (auto& sc : ctx->schedules) { if (sc.d_list) (void)hipFree(sc.d_list); if (sc.d_tabs) (void)hipFree(sc.d_tabs); }
     for (auto& e : ctx->desc_cache) if (e.dptr) (void)hipFree(e.dptr);
     for (auto& e : ctx->arg_cache) if (e.dptr) (void)hipFree(e.dptr);
-    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->bal, &ctx->red};
+    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->bal, &ctx->red, &ctx->zeros};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     (void)hipStreamDestroy(ctx->stream);
@@ -1240,9 +1242,9 @@ extern "C" int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* x
         if (iso_mol[i] < 0 || iso_mol[i] >= n_mol || (i > 0 && iso_mol[i] < iso_mol[i - 1]))
             return fail(ctx, LBL_ERR_BAD_ARG, "iso_mol must be non-decreasing and < n_mol");
         a.xsec[i] = xsec[i]->d;
-        a.iso_mol[i] = iso_mol[i];
+        a.term_conc[i] = conc[iso_mol[i]];
+        a.term_flags[i] = (i == n_iso - 1 || iso_mol[i + 1] != iso_mol[i]) ? TERM_LAST_MOL : 0;
     }
-    for (int m = 0; m < n_mol; ++m) a.conc[m] = conc[m];
     if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
     if ((rc = check_buf(ctx, abs_coef, n, "abs_coef", false))) return rc;
     if ((rc = check_buf(ctx, trans, n, "trans", false))) return rc;
@@ -1377,29 +1379,44 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
     if (!I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "need I_in or surface_T > 0");
     std::vector<char> blk(sizeof(ColumnStepArgs), 0);
     ColumnStepArgs* a = (ColumnStepArgs*)blk.data();
-    int iso0 = 0, mol0 = 0;
+    int iso0 = 0, mol0 = 0, nt = 0;
     for (int l = 0; l < n_layers; ++l) {
-        if (n_iso[l] < 0 || n_mol[l] < 0 || iso0 + n_iso[l] > kMaxColumnIso || mol0 + n_mol[l] > kMaxColumnIso)
-            return fail(ctx, LBL_ERR_BAD_ARG, "at most %d isotopologues per column", kMaxColumnIso);
+        if (n_iso[l] < 0 || n_mol[l] < 0 || nt + n_iso[l] + 1 > kMaxColumnIso || mol0 + n_mol[l] > kMaxColumnIso)
+            return fail(ctx, LBL_ERR_BAD_ARG, "at most %d isotopologues per column", kMaxColumnIso - 1);
         if (!(T[l] > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "layer %d: T must be > 0", l);
         if ((n_iso[l] > 0 && (!xsec || !iso_mol)) || (n_mol[l] > 0 && !conc)) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
-        a->layer_iso0[l] = iso0; a->layer_mol0[l] = mol0;
+        // the layer's terms: one per cross-section array, molecule after molecule (a molecule without line
+        // lists adds 0 to the absorption coefficient: no term; a layer without any gets one empty term)
         for (int i = 0; i < n_iso[l]; ++i) {
             if ((rc = check_buf(ctx, xsec[iso0 + i], n, "xsec", true))) return rc;
             const int32_t m = iso_mol[iso0 + i];
             if (m < 0 || m >= n_mol[l] || (i > 0 && m < iso_mol[iso0 + i - 1]))
                 return fail(ctx, LBL_ERR_BAD_ARG, "layer %d: iso_mol must be non-decreasing and < n_mol", l);
-            a->xsec[iso0 + i] = xsec[iso0 + i]->d;
-            a->iso_mol[iso0 + i] = m;
+            a->xsec[nt] = xsec[iso0 + i]->d;
+            a->term_conc[nt] = conc[mol0 + m];
+            a->term_flags[nt] = (i == n_iso[l] - 1 || iso_mol[iso0 + i + 1] != m) ? TERM_LAST_MOL : 0;
+            ++nt;
         }
-        for (int m = 0; m < n_mol[l]; ++m) a->conc[mol0 + m] = conc[mol0 + m];
-        a->P[l] = P[l]; a->T[l] = T[l]; a->depth[l] = depth[l];
-        a->rT[l] = uniform_rcp(T[l]);
-        if (abs_coef && abs_coef[l]) { if ((rc = check_buf(ctx, abs_coef[l], n, "abs_coef", true))) return rc; a->abs_coef[l] = abs_coef[l]->d; }
-        if (trans && trans[l]) { if ((rc = check_buf(ctx, trans[l], n, "trans", true))) return rc; a->trans[l] = trans[l]->d; }
+        if (n_iso[l] == 0) {
+            // a layer without line lists: one term that reads zeros (grown on first use; absorbs nothing)
+            if ((rc = arena_reserve(ctx, ctx->zeros, (size_t)n * sizeof(double)))) return rc;
+            if (ctx->zeros_set < ctx->zeros.cap) {
+                HIP_TRY(ctx, hipMemsetAsync(ctx->zeros.ptr, 0, ctx->zeros.cap, ctx->stream));
+                ctx->zeros_set = ctx->zeros.cap;
+            }
+            a->xsec[nt] = (const double*)ctx->zeros.ptr; a->term_conc[nt] = 0.0; a->term_flags[nt] = TERM_LAST_MOL; ++nt;
+        }
+        a->term_flags[nt - 1] |= TERM_LAST_LAYER;
+        for (int t = nt - std::max(n_iso[l], 1); t < nt; ++t) {
+            a->term_P[t] = P[l]; a->term_T[t] = T[l]; a->term_depth[t] = depth[l];
+            a->term_rT[t] = uniform_rcp(T[l]);
+        }
+        if (abs_coef && abs_coef[l]) { if ((rc = check_buf(ctx, abs_coef[l], n, "abs_coef", true))) return rc; a->abs_coef[l] = abs_coef[l]->d; a->layer_arrays = 1; }
+        if (trans && trans[l]) { if ((rc = check_buf(ctx, trans[l], n, "trans", true))) return rc; a->trans[l] = trans[l]->d; a->layer_arrays = 1; }
         iso0 += n_iso[l]; mol0 += n_mol[l];
     }
-    a->layer_iso0[n_layers] = iso0; a->layer_mol0[n_layers] = mol0;
+    a->n_terms = nt;
+    a->ablate = ctx->ablate;
     a->n_layers = n_layers;
     a->start = range_min; a->stop = range_max; a->step = axis_step(range_min, range_max, n);
     planck_constants(&a->pa, &a->pb);
@@ -1412,7 +1429,7 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
     void* d_args = nullptr;
     if ((rc = device_args(ctx, a, sizeof(ColumnStepArgs), &d_args))) return rc;
     hipEvent_t ev = prof_begin(ctx, PROF_COLUMN);
-    launch_column_step((const ColumnStepArgs*)d_args, count, ctx->stream, (first & 1) == 0);
+    launch_column_step((const ColumnStepArgs*)d_args, count, ctx->stream);
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;

@@ -115,10 +115,14 @@ struct PrepJob {
 
 // ---- fused sweep arguments (passed by value / by pointer to the sweep kernels) ----------
 constexpr int kMaxIso = 48;
+// A sweep walks a flat list of terms, one per cross-section array, molecule after molecule (and, in a column,
+// layer after layer from the bottom): the flags say where a molecule's isotopologue sum is complete
+// (pyradClasses.py:566-571 -> 583) and where a layer's molecules are (pyradClasses.py:707-716).
+enum : int32_t { TERM_LAST_MOL = 1, TERM_LAST_LAYER = 2 };
 struct SweepArgs {
     const double* xsec[kMaxIso];
-    int32_t iso_mol[kMaxIso];
-    double conc[kMaxIso];
+    double term_conc[kMaxIso];      // volume fraction of the term's molecule
+    int32_t term_flags[kMaxIso];
     int32_t n_iso, n_mol;
     double P, T, depth;
     double rT, r_surface_T;         // RN(1/T), RN(1/surface_T) for div_uniform (0: plain divide)
@@ -131,21 +135,22 @@ struct SweepArgs {
     long long first, count;         // swept sub-range
 };
 constexpr int kMaxLayers = 128;
-constexpr int kMaxColumnIso = 512;      // isotopologue cross sections of a whole column
+constexpr int kMaxColumnIso = 512;      // cross-section arrays (terms) of a whole column
 // Column step from the cross sections: per layer the arithmetic of layer_sweep_kernel (absorption
 // coefficient, transmittance), folded bottom to top like column_sweep_kernel, in one pass.
 struct ColumnStepArgs {
-    const double* xsec[kMaxColumnIso];
-    int32_t iso_mol[kMaxColumnIso];     // molecule of the isotopologue, 0-based inside its layer
-    double conc[kMaxColumnIso];         // [layer_mol0[l] + m]
-    int32_t layer_iso0[kMaxLayers + 1]; // isotopologues of layer l: [layer_iso0[l], layer_iso0[l+1])
-    int32_t layer_mol0[kMaxLayers + 1];
-    double P[kMaxLayers], T[kMaxLayers], depth[kMaxLayers];
-    double rT[kMaxLayers];              // RN(1/T[l]) (0: plain divide)
+    const double* xsec[kMaxColumnIso];  // (a layer without line lists: one term reading the context's array of zeros)
+    double term_conc[kMaxColumnIso];
+    // the layer's scalars repeated per term, so that every load of a batch of terms has an address that depends
+    // on the term index only (the kernel fetches them with wide scalar loads ahead of the arithmetic)
+    double term_P[kMaxColumnIso], term_T[kMaxColumnIso], term_rT[kMaxColumnIso], term_depth[kMaxColumnIso];   // rT = RN(1/T) (0: plain divide)
+    int32_t term_flags[kMaxColumnIso];
+    int32_t n_terms, n_layers;
+    int32_t ablate;                     // diagnostics (lbl_set_option debug_ablate): timing-only variants
+    int32_t layer_arrays;               // any of trans[] / abs_coef[] set
     double r_surface_T;
     double* trans[kMaxLayers];          // optional per-layer transmittance outputs
     double* abs_coef[kMaxLayers];       // optional per-layer absorption coefficients
-    int32_t n_layers;
     double start, stop, step, pa, pb, surface_T;
     const double* I_in; double* I_out;
     long long n;
@@ -180,7 +185,7 @@ void launch_accumulate_balanced(const AccumJob* d_jobs, int n_jobs, int total_sp
 void launch_regrid(const double* work, long long n_work, double* out, long long n_base, double start, double stop,
                    hipStream_t s);
 void launch_layer_sweep(const SweepArgs& a, hipStream_t s);
-void launch_column_step(const ColumnStepArgs* d_args, long long count, hipStream_t s, bool aligned2);
+void launch_column_step(const ColumnStepArgs* d_args, long long count, hipStream_t s);
 void launch_column_sweep(const ColumnArgs* d_args, long long n, hipStream_t s);
 void launch_planck(double* out, long long n, double start, double stop, double T, double rT, double pa, double pb, hipStream_t s);
 int band_partial_count(long long n);

@@ -95,10 +95,43 @@ __device__ __forceinline__ double div_uniform(double x, double c, double rc) {
 constexpr double kRcp1E4 = 1.0 / 1E4;      // correctly rounded by the compiler; neither significand is all ones
 constexpr double kRcpKB = 1.0 / kB;
 
-__device__ __forceinline__ double planck_wn(double n, double T, double rT, double pa, double pb) {
-    double a = pa * (n * n * n);
-    double b = div_uniform(div_uniform(pb * n, kB, kRcpKB), T, rT);       // pb * n / kB / T
+// exp(x) for x <= 700 without the range tests of the library routine (22 -> 17 instructions); exact
+// to the library's accuracy for x >= -745, 0 (through v_ldexp_f64) below, finite garbage-free
+// down to about -1e18, so callers clamp only when their argument can be more extreme:
+// n = rint(x log2 e), r = x - n ln2 (two-part), degree-11 polynomial on |r| <= ln2/2 (the
+// coefficients of the ROCm device library's double-precision exp), scaled by 2^n with v_ldexp_f64,
+// which also delivers the gradual underflow.  Callers clamp the argument.
+__device__ __forceinline__ double exp_clamped(double x) {
+    const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = fma(n, -0x1.62e42fefa39efp-1, x);
+    r = fma(n, -0x1.abc9e3b39803fp-56, r);
+    double p = fma(0x1.ade156a5dcb37p-26, r, 0x1.28af3fca7ab0cp-22);
+    p = fma(p, r, 0x1.71dee623fde64p-19);
+    p = fma(p, r, 0x1.a01997c89e6b0p-16);
+    p = fma(p, r, 0x1.a01a014761f6ep-13);
+    p = fma(p, r, 0x1.6c16c1852b7b0p-10);
+    p = fma(p, r, 0x1.1111111122322p-7);
+    p = fma(p, r, 0x1.55555555502a1p-5);
+    p = fma(p, r, 0x1.5555555555511p-3);
+    p = fma(p, r, 0x1.000000000000bp-1);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// the part that depends on the grid point only (a, and pb * n / kB): hoisted out of loops over temperatures
+__device__ __forceinline__ void planck_point(double n, double pa, double pb, double& a, double& bn) {
+    a = pa * (n * n * n);
+    bn = div_uniform(pb * n, kB, kRcpKB);
+}
+__device__ __forceinline__ double planck_at(double a, double bn, double T, double rT) {
+    const double b = div_uniform(bn, T, rT);                              // pb * n / kB / T
     return a / (exp(b) - 1.0);
+}
+__device__ __forceinline__ double planck_wn(double n, double T, double rT, double pa, double pb) {
+    double a, bn;
+    planck_point(n, pa, pb, a, bn);
+    return planck_at(a, bn, T, rT);
 }
 
 // xs * conc * P / 1E4 / kB / T (pyradClasses.py:583), left to right like the reference
@@ -246,30 +279,6 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t* __restrict__ a, in
         if ((long long)a[mid] < target) lo = mid + 1; else hi = mid;
     }
     return lo;
-}
-
-// exp(x) for x <= 700 without the range tests of the library routine (22 -> 17 instructions); exact
-// to the library's accuracy for x >= -745, 0 (through v_ldexp_f64) below, finite garbage-free
-// down to about -1e18, so callers clamp only when their argument can be more extreme:
-// n = rint(x log2 e), r = x - n ln2 (two-part), degree-11 polynomial on |r| <= ln2/2 (the
-// coefficients of the ROCm device library's double-precision exp), scaled by 2^n with v_ldexp_f64,
-// which also delivers the gradual underflow.  Callers clamp the argument.
-__device__ __forceinline__ double exp_clamped(double x) {
-    const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
-    double r = fma(n, -0x1.62e42fefa39efp-1, x);
-    r = fma(n, -0x1.abc9e3b39803fp-56, r);
-    double p = fma(0x1.ade156a5dcb37p-26, r, 0x1.28af3fca7ab0cp-22);
-    p = fma(p, r, 0x1.71dee623fde64p-19);
-    p = fma(p, r, 0x1.a01997c89e6b0p-16);
-    p = fma(p, r, 0x1.a01a014761f6ep-13);
-    p = fma(p, r, 0x1.6c16c1852b7b0p-10);
-    p = fma(p, r, 0x1.1111111122322p-7);
-    p = fma(p, r, 0x1.55555555502a1p-5);
-    p = fma(p, r, 0x1.5555555555511p-3);
-    p = fma(p, r, 0x1.000000000000bp-1);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
 }
 
 // Gaussian part of one line for a lane's R consecutive points (d0 = offset of the lane's
@@ -1754,28 +1763,53 @@ __global__ __launch_bounds__(256) void regrid_kernel(const double* __restrict__ 
 // ----------------------------------------------------------------------------------------
 // K4: fused layer sweep
 // ----------------------------------------------------------------------------------------
+// Cross sections are read in batches of NB independent loads (the term list is wave-uniform: pointers and
+// flags come from the argument block by scalar loads; explicit global address space, so that a load does not
+// wait for the scalar ones).  The first version walked molecules and isotopologues with dependent scalar
+// loads and waited for every value before asking for the next: 0.52 of the HBM rate.
+typedef const double __attribute__((address_space(1)))* GlobalF64;
+__device__ __forceinline__ double load_global_f64(const double* p, long long j) {
+    return ((GlobalF64)(unsigned long long)p)[j];
+}
+
 __global__ __launch_bounds__(256) void layer_sweep_kernel(const SweepArgs A) {
 #pragma clang fp contract(off)
+    constexpr int NB = 4;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long jend = A.first + A.count;
+    const int n_full = A.n_iso - A.n_iso % NB;
     for (long long j = A.first + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < jend; j += stride) {
         // Layer.absCoef (pyradClasses.py:707-712): zeros + sum over molecules of
         // Molecule.absCoef = crossSection * concentration * P / 1E4 / k / T (pyradClasses.py:583),
         // Molecule.crossSection = zeros + sum over isotopologues (pyradClasses.py:566-571)
-        double kk = 0.0;
-        int i = 0;
-        for (int m = 0; m < A.n_mol; ++m) {
-            double xs = 0.0;
-            while (i < A.n_iso && A.iso_mol[i] == m) { xs += A.xsec[i][j]; ++i; }
-            kk += abs_coef_term(xs, A.conc[m], A.P, A.T, A.rT);
+        double kk = 0.0, xs = 0.0;
+        auto term = [&](int t, double v) {
+            xs += v;
+            if (A.term_flags[t] & TERM_LAST_MOL) { kk += abs_coef_term(xs, A.term_conc[t], A.P, A.T, A.rT); xs = 0.0; }
+        };
+        for (int t0 = 0; t0 < n_full; t0 += NB) {
+            double v[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) v[u] = load_global_f64(A.xsec[t0 + u], j);
+#pragma unroll
+            for (int u = 0; u < NB; ++u) term(t0 + u, v[u]);
+        }
+        {
+            double v[NB];
+#pragma unroll
+            for (int u = 0; u < NB - 1; ++u) v[u] = n_full + u < A.n_iso ? load_global_f64(A.xsec[n_full + u], j) : 0.0;
+#pragma unroll
+            for (int u = 0; u < NB - 1; ++u) if (n_full + u < A.n_iso) term(n_full + u, v[u]);
         }
         if (A.abs_coef) A.abs_coef[j] = kk;
         const double tr = exp(-kk * A.depth);                               // pyradClasses.py:716
         if (A.trans) A.trans[j] = tr;
         if (A.I_out) {
             const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
-            const double B = planck_wn(nu, A.T, A.rT, A.pa, A.pb);          // Layer.planck(self.T)
-            const double Iin = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.r_surface_T, A.pa, A.pb);
+            double pa_n, pb_n;
+            planck_point(nu, A.pa, A.pb, pa_n, pb_n);
+            const double B = planck_at(pa_n, pb_n, A.T, A.rT);                  // Layer.planck(self.T)
+            const double Iin = A.I_in ? A.I_in[j] : planck_at(pa_n, pb_n, A.surface_T, A.r_surface_T);
             const double transmitted = tr * Iin;                            // pyradClasses.py:785
             const double emitted = (1.0 - tr) * B;                          // pyradClasses.py:786
             A.I_out[j] = transmitted + emitted;
@@ -1809,64 +1843,65 @@ __global__ __launch_bounds__(256) void column_sweep_kernel(const ColumnArgs* __r
 // bottom to top: absorption coefficient and transmittance exactly as layer_sweep_kernel computes
 // them, then the fold of column_sweep_kernel.  One pass over the cross sections replaces one sweep
 // launch per layer plus the fold, and the per-layer arrays are written only if asked for.
-// NP grid points per thread (2: 16-byte loads, two independent fold chains in flight).
-template <int NP>
+// The column is a flat list of terms (one per cross-section array, bottom layer first; flags mark the last
+// term of a molecule and of a layer).  NB terms are loaded at once, independent of one another; everything
+// that depends on the grid point only (2E8 h c^2 n^3 and 100 h c n / k of pyradPlanck.py:41-42) is computed
+// once per point, not once per layer.
 __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* __restrict__ Ap) {
 #pragma clang fp contract(off)
+    constexpr int NB = 6;
     const ColumnStepArgs& A = *Ap;
-    const long long stride = (long long)gridDim.x * blockDim.x * NP;
+    const long long stride = (long long)gridDim.x * blockDim.x;
     const long long jend = A.first + A.count;
-    for (long long j0 = A.first + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * NP; j0 < jend; j0 += stride) {
-        double nu[NP], I[NP];
-        bool live[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            live[p] = j0 + p < jend;
-            const long long j = live[p] ? j0 + p : j0;
-            nu[p] = linspace_at(j, A.n, A.start, A.stop, A.step);
-            I[p] = A.I_in ? A.I_in[j] : planck_wn(nu[p], A.surface_T, A.r_surface_T, A.pa, A.pb);
-        }
-        const bool pair = NP == 2 && live[NP - 1];
-        for (int l = 0; l < A.n_layers; ++l) {
-            double kk[NP];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) kk[p] = 0.0;
-            int i = A.layer_iso0[l];
-            const int iend = A.layer_iso0[l + 1];
-            const int n_mol = A.layer_mol0[l + 1] - A.layer_mol0[l];
-            for (int m = 0; m < n_mol; ++m) {
-                double xs[NP];
-#pragma unroll
-                for (int p = 0; p < NP; ++p) xs[p] = 0.0;
-                while (i < iend && A.iso_mol[i] == m) {
-                    if (pair) {
-                        const double2 v = *reinterpret_cast<const double2*>(A.xsec[i] + j0);
-                        xs[0] += v.x; xs[NP - 1] += v.y;
-                    } else {
-                        xs[0] += A.xsec[i][j0];
-                    }
-                    ++i;
+    const int n_terms = A.n_terms;
+    const int n_full = n_terms - n_terms % NB;
+    const bool layer_arrays = A.layer_arrays != 0;
+    for (long long j = A.first + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < jend; j += stride) {
+        const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
+        double pa_n, pb_n;
+        planck_point(nu, A.pa, A.pb, pa_n, pb_n);
+        double I = A.I_in ? A.I_in[j] : planck_at(pa_n, pb_n, A.surface_T, A.r_surface_T);
+        double kk = 0.0, xs = 0.0;
+        int l = 0;
+        auto term = [&](int t, double v) {
+            const int f = A.term_flags[t];
+            xs += v;
+            if (A.ablate & 16) { I += v; return; }                 // (diagnostics: memory traffic only)
+            if (f & TERM_LAST_MOL) { kk += abs_coef_term(xs, A.term_conc[t], A.term_P[t], A.term_T[t], A.term_rT[t]); xs = 0.0; }
+            if (f & TERM_LAST_LAYER) {
+                const double tr = exp(-kk * A.term_depth[t]);
+                if (layer_arrays) {
+                    if (A.abs_coef[l]) A.abs_coef[l][j] = kk;
+                    if (A.trans[l]) A.trans[l][j] = tr;
+                    ++l;
                 }
-                const double f = A.conc[A.layer_mol0[l] + m];
-#pragma unroll
-                for (int p = 0; p < NP; ++p) kk[p] += abs_coef_term(xs[p], f, A.P[l], A.T[l], A.rT[l]);
-            }
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                if (!live[p]) continue;
-                const long long j = j0 + p;
-                if (A.abs_coef[l]) A.abs_coef[l][j] = kk[p];
-                const double tr = exp(-kk[p] * A.depth[l]);
-                if (A.trans[l]) A.trans[l][j] = tr;
-                const double B = planck_wn(nu[p], A.T[l], A.rT[l], A.pa, A.pb);
-                const double transmitted = tr * I[p];
+                const double B = planck_at(pa_n, pb_n, A.term_T[t], A.term_rT[t]);
+                const double transmitted = tr * I;
                 const double emitted = (1.0 - tr) * B;
-                I[p] = transmitted + emitted;
+                I = transmitted + emitted;
+                kk = 0.0;
             }
-        }
+        };
+        // two batches of NB loads in flight: the next batch is requested before the current one is consumed
+        double cur[NB], nxt[NB];
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
-            if (live[p]) A.I_out[j0 + p] = I[p];
+        for (int u = 0; u < NB; ++u) { cur[u] = 0.0; nxt[u] = 0.0; }
+        if (n_full > 0) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) cur[u] = (A.ablate & 32) ? 1e-22 * (double)(j & 7) : load_global_f64(A.xsec[u], j);
+        }
+        for (int t0 = 0; t0 < n_full; t0 += NB) {
+            if (t0 + NB < n_full) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) nxt[u] = (A.ablate & 32) ? 1e-22 * (double)(j & 7) : load_global_f64(A.xsec[t0 + NB + u], j);
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) term(t0 + u, cur[u]);
+#pragma unroll
+            for (int u = 0; u < NB; ++u) cur[u] = nxt[u];
+        }
+        for (int t = n_full; t < n_terms; ++t) term(t, load_global_f64(A.xsec[t], j));
+        A.I_out[j] = I;
     }
 }
 
@@ -2038,7 +2073,7 @@ void launch_regrid(const double* work, long long n_work, double* out, long long 
                        n_base, start, stop, step_w, step_b);
 }
 
-static int sweep_blocks(long long n) {
+static int sweep_blocks(long long n) {       // (one point per thread on a larger grid measured no faster: 442 vs 433 us for the column)
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
@@ -2048,13 +2083,9 @@ void launch_layer_sweep(const SweepArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(layer_sweep_kernel, dim3(sweep_blocks(a.count)), dim3(256), 0, s, a);
 }
 
-void launch_column_step(const ColumnStepArgs* d_args, long long count, hipStream_t s, bool aligned2) {
+void launch_column_step(const ColumnStepArgs* d_args, long long count, hipStream_t s) {
     if (count <= 0) return;
-    if (aligned2) {      // first point even: two points per thread with 16-byte loads
-        hipLaunchKernelGGL(column_step_kernel<2>, dim3(sweep_blocks((count + 1) / 2)), dim3(256), 0, s, d_args);
-        return;
-    }
-    hipLaunchKernelGGL(column_step_kernel<1>, dim3(sweep_blocks(count)), dim3(256), 0, s, d_args);
+    hipLaunchKernelGGL(column_step_kernel, dim3(sweep_blocks(count)), dim3(256), 0, s, d_args);
 }
 
 void launch_column_sweep(const ColumnArgs* d_args, long long count, hipStream_t s) {
