@@ -82,65 +82,91 @@ def molecules_of(cfg):
     return mols
 
 
-def cpu_baseline(cfg, seconds_target=15.0):
-    """Time the faithful scalar restatement of the reference's hot loop (oracle, kind 'port')
-    on one host core, on a bounded sample of the same workload; plus the plain-C oracle."""
+def cpu_baseline(layer_cfgs, workload, seconds_target=15.0):
+    """The reference's hot loop on ONE host core (the reference is single-threaded), SURVEY.md §8(d): three
+    restatements - the faithful Python/NumPy scalar loop (kind "port": the reported value), the vectorised NumPy
+    form and the plain-C port - ALL timed on the SAME seeded sample of the workload's lines, drawn uniformly from
+    every line list of every layer and sized so that the Python leg takes about ``seconds_target``; and the C and
+    vectorised legs once more at §8(d)'s extent: the whole workload for C1 and C2, a seeded 1/16 of every line
+    list for C3 and C5 (linear in the eval count, stated as such)."""
     from oracle import pyrad_oracle as orc
     from oracle import c_oracle
     from pyrad_amd import synthetic
-    mol = cfg["molecules"][0]            # a multi-molecule cell is sampled through its first molecule's line list
-    sp = synthetic.SPECIES[mol["species"]]
-    grid = orc.layer_grid(cfg["P"], cfg["range_min"], cfg["range_max"], cfg["base_resolution"],
-                          cfg.get("dynamic_resolution", True))
-    conc = orc.concentration(**mol["conc"])
-    lines = orc.select_window(mol["lines"], grid["eff_min"], grid["eff_max"])
-    qT = synthetic.q_value(mol["species"], cfg["T"])
-    # calibrate on a handful of lines, then size the sample for ~seconds_target
-    rng = np.random.default_rng(0)
-    pick = np.sort(rng.choice(len(lines["nu"]), size=min(40, len(lines["nu"])), replace=False))
-    sub = {k: v[pick] for k, v in lines.items()}
-    t0 = time.perf_counter()
-    orc.create_cross_section_scalar(sub, cfg["T"], cfg["P"], conc, sp["molmass"], qT, sp["q296"], grid, regrid=False)
-    dt = time.perf_counter() - t0
-    n_sample = int(max(40, min(len(lines["nu"]), len(pick) * seconds_target / max(dt, 1e-6))))
-    pick = np.sort(rng.choice(len(lines["nu"]), size=n_sample, replace=False))
-    sub = {k: v[pick] for k, v in lines.items()}
-    lq = orc.line_quantities(sub, cfg["T"], cfg["P"], conc, sp["molmass"], grid["range_min"], grid["resolution"])
-    evals = orc.eval_count(lq["index"], grid["W"], grid["n_work"])
-    t0 = time.perf_counter()
-    xs_py, _ = orc.create_cross_section_scalar(sub, cfg["T"], cfg["P"], conc, sp["molmass"], qT, sp["q296"], grid,
-                                               regrid=False)
-    t_py = time.perf_counter() - t0
-    # plain C port of the same loop on a larger sample (about 2 s)
-    n_c = int(min(len(lines["nu"]), max(n_sample, 4000)))
-    pick_c = np.sort(rng.choice(len(lines["nu"]), size=n_c, replace=False))
-    sub_c = {k: v[pick_c] for k, v in lines.items()}
-    t0 = time.perf_counter()
-    _, _, evals_c = c_oracle.create_cross_section_work(sub_c, cfg["T"], cfg["P"], conc, sp["molmass"], qT, sp["q296"], grid)
-    t_c = time.perf_counter() - t0
-    # the vectorised NumPy restatement (slice adds instead of the per-point Python loop): what a
-    # NumPy-literate rewrite of the reference's loop reaches on one core (BASELINE.md §3)
-    n_v = int(min(len(lines["nu"]), max(n_sample * 20, 2000)))
-    pick_v = np.sort(rng.choice(len(lines["nu"]), size=n_v, replace=False))
-    sub_v = {k: v[pick_v] for k, v in lines.items()}
-    lq_v = orc.line_quantities(sub_v, cfg["T"], cfg["P"], conc, sp["molmass"], grid["range_min"], grid["resolution"])
-    evals_v = orc.eval_count(lq_v["index"], grid["W"], grid["n_work"])
-    t0 = time.perf_counter()
-    orc.create_cross_section(sub_v, cfg["T"], cfg["P"], conc, sp["molmass"], qT, sp["q296"], grid, regrid=False)
-    t_v = time.perf_counter() - t0
+    jobs = []
+    for cfg in layer_cfgs:
+        grid = orc.layer_grid(cfg["P"], cfg["range_min"], cfg["range_max"], cfg["base_resolution"],
+                              cfg.get("dynamic_resolution", True))
+        for mol in cfg["raw_molecules"]:
+            sp = synthetic.SPECIES[mol["species"]]
+            lines = orc.select_window(mol["lines"], grid["eff_min"], grid["eff_max"])
+            jobs.append(dict(lines=lines, args=(cfg["T"], cfg["P"], orc.concentration(**mol["conc"]), sp["molmass"],
+                                                synthetic.q_value(mol["species"], cfg["T"]), sp["q296"], grid)))
+
+    def subset(fraction, seed):
+        out = []
+        for i, j in enumerate(jobs):
+            n = len(j["lines"]["nu"])
+            if fraction >= 1.0:
+                out.append(j["lines"])
+                continue
+            rng = np.random.default_rng(seed + i)
+            pick = np.sort(rng.choice(n, size=max(1, int(round(n * fraction))), replace=False)) if n else np.zeros(0, np.int64)
+            out.append({k: v[pick] for k, v in j["lines"].items()})
+        return out
+
+    def evals_of(sub):
+        total = 0
+        for lines, j in zip(sub, jobs):
+            T, P, conc, molmass, qT, q296, grid = j["args"]
+            lq = orc.line_quantities(lines, T, P, conc, molmass, grid["range_min"], grid["resolution"])
+            total += int(orc.eval_count(lq["index"], grid["W"], grid["n_work"]))
+        return total
+
+    def run(kind, sub):
+        t0 = time.perf_counter()
+        for lines, j in zip(sub, jobs):
+            if kind == "python":
+                orc.create_cross_section_scalar(lines, *j["args"], regrid=False)
+            elif kind == "numpy":
+                orc.create_cross_section(lines, *j["args"], regrid=False)
+            else:
+                c_oracle.create_cross_section_work(lines, *j["args"])
+        return time.perf_counter() - t0
+
+    c_oracle.load()
+    e_total = evals_of([j["lines"] for j in jobs])
+    n_total = sum(len(j["lines"]["nu"]) for j in jobs)
+    # calibrate the Python leg on a sliver, then size the common sample
+    f0 = min(1.0, 2.0e6 / max(e_total, 1))
+    cal = subset(f0, 100)
+    rate0 = evals_of(cal) / max(run("python", cal), 1e-9)
+    f = min(1.0, seconds_target * rate0 / max(e_total, 1))
+    S = subset(f, 0)
+    e_S, n_S = evals_of(S), sum(len(x["nu"]) for x in S)
+    t_py, t_np, t_c = run("python", S), run("numpy", S), run("c", S)
+    f_big = 1.0 if workload in ("C1", "C2") else 1.0 / 16.0
+    B = subset(f_big, 0) if f_big != f else S
+    e_B, n_B = evals_of(B), sum(len(x["nu"]) for x in B)
+    tb_np, tb_c = run("numpy", B), run("c", B)
+    what_B = ("the WHOLE workload" if f_big >= 1.0 else
+              "a seeded 1/16 of every line list (SURVEY.md 8d; the whole workload extrapolates linearly in the eval count: %.3g evals)" % e_total)
     return {
-        "vectorised_value": evals_v / t_v,
-        "vectorised_sample": "vectorised NumPy restatement (oracle.create_cross_section, 1 core): %d lines, %d evals in %.2f s" % (
-            n_v, evals_v, t_v),
-        "value": evals / t_py, "unit": "line*gridpoint evals/s", "cores": 1, "kind": "port",
-        "sample": "%d of %d lines drawn uniformly (seed 0) from the bench workload, %d evals in %.1f s; faithful "
-                  "Python/NumPy scalar restatement of pyradClasses.py:361-400 (oracle.create_cross_section_scalar) on the %s "
-                  "line list of the workload; "
+        "value": e_S / t_py, "unit": "line*gridpoint evals/s", "cores": 1, "kind": "port",
+        "sample": "%d of the workload's %d lines (fraction %.4g of every line list of every layer, seed 0), %d of %d evals; "
+                  "faithful Python/NumPy scalar restatement of pyradClasses.py:361-400 (oracle.create_cross_section_scalar) in %.1f s; "
                   "host has %d logical cores, 1 used (the reference is single-threaded)" % (
-                      n_sample, len(lines["nu"]), evals, t_py, mol["species"], os.cpu_count() or 0),
-        "c_port_value": evals_c / t_c,
-        "c_port_sample": "plain-C restatement (oracle/lbl_oracle.c, gcc -O2, 1 core): %d lines, %d evals in %.2f s" % (
-            n_c, evals_c, t_c),
+                      n_S, n_total, f, e_S, e_total, t_py, os.cpu_count() or 0),
+        "vectorised_value": e_S / t_np,
+        "vectorised_sample": "vectorised NumPy restatement (oracle.create_cross_section, 1 core) on the SAME sample: %.2f s" % t_np,
+        "c_port_value": e_S / t_c,
+        "c_port_sample": "plain-C restatement (oracle/lbl_oracle.c, gcc -O2, 1 core) on the SAME sample: %.2f s" % t_c,
+        "at_survey_extent": {
+            "what": what_B, "lines": n_B, "evals": e_B,
+            "c_port_value": e_B / tb_c, "c_port_seconds": tb_c,
+            "vectorised_value": e_B / tb_np, "vectorised_seconds": tb_np,
+            "whole_workload_seconds_c_port": e_total / (e_B / tb_c),
+            "whole_workload_seconds_python": e_total / (e_S / t_py),
+        },
     }
 
 
@@ -308,10 +334,13 @@ def steps_in_flight(requested: str, sharded: bool) -> int:
     auto: 2 for a shard; 1 for an unsharded grid, so that an N = 1 line times every kernel alone on the chip and
     agrees with its rocprofv3 summary (the profiler does not let launches of different streams overlap the
     way they do unobserved); what more steps in flight give a small unsharded cell (C2 0.066 -> 0.043 ms,
-    C1 0.0185 -> 0.0087 with three) is reported by an extra leg of the line, `in_flight_leg`."""
+    C1 0.0185 -> 0.0087 with three) is reported by an extra leg of the line, `in_flight_leg`.
+    Round 3: auto is 1 everywhere.  Two contexts sharing one communicator have only ever run with one rank
+    (no multi-GPU box is available to the build), so the default N > 1 line takes the simple path - one step in
+    flight, one collective per step - and 2 / 3 in flight stay opt-in (--in-flight 2)."""
     if requested != "auto":
         return max(1, min(3, int(requested)))
-    return 2 if sharded else 1
+    return 1
 
 
 def gather_batch(requested: str, batchable: bool, steps_per_set: int = 0) -> int:
@@ -322,12 +351,13 @@ def gather_batch(requested: str, batchable: bool, steps_per_set: int = 0) -> int
     collectives, same bytes.  Two batch buffers per set: the gather of one batch overlaps the steps that fill
     the other.  With ONE rank forced through the communicator a shard of 8 of C3 steps in 0.0626 ms with a
     collective per step and 0.0537 / 0.0528 / 0.0522 with B = 2 / 4 / 8 (kernels alone: 0.0523).
-    auto (where it applies: a communicator, the pipelined single-array gather): the B in 3..8 that leaves the
-    smallest partly filled batch at the end of the timed region (a flush sends the whole buffer), larger B
-    on a tie - 5 for the driver's 20 steps over two resident sets."""
-    if not batchable:
+    Round 3: auto is 1 (a collective per step: the path that has run, and the one whose per-step result is usable
+    as soon as its own gather is done); "fit" picks the B in 3..8 that leaves the smallest partly filled batch at
+    the end of the timed region (a flush sends the whole buffer), larger B on a tie - 5 for 20 steps over two
+    resident sets; an integer forces B."""
+    if not batchable or requested == "auto":
         return 1
-    if requested != "auto":
+    if requested != "fit":
         return max(1, min(16, int(requested)))
     if steps_per_set < 3:
         return max(1, steps_per_set)
@@ -375,7 +405,7 @@ class _Batch:
             b.free()
 
 
-def in_flight_leg(cfg, n_flight=3, steps=200):
+def in_flight_leg(cfg, n_flight=3, steps=200, chained=False):
     """Throughput of the same resident cell with n_flight independent steps in flight, each on a context (HIP
     stream) of its own, dealt round-robin: an extra leg for cells whose accumulate launch is a partial round
     of workgroups.  Same kernels, same results; not the line's `value`."""
@@ -384,6 +414,9 @@ def in_flight_leg(cfg, n_flight=3, steps=200):
     ctxs = [nat.Context(int(os.environ.get("LOCAL_RANK", "0"))) for _ in range(n_flight)]
     layers = [engine.ResidentLayer(c, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"], mols,
                                    cfg["base_resolution"], cfg.get("dynamic_resolution", True)) for c in ctxs]
+    if chained:           # software pipeline: the accumulate kernels run one after another, line prep and sweeps beside them
+        for i, c in enumerate(ctxs):
+            c.chain_accumulate(ctxs[i - 1])
 
     def run(n):
         for k in range(n):
@@ -404,9 +437,13 @@ def in_flight_leg(cfg, n_flight=3, steps=200):
         L.free()
     for c in ctxs:
         c.close()
-    return {"steps_in_flight": n_flight, "ms_per_step": best * 1e3, "evals_per_s": evals / best,
+    return {"steps_in_flight": n_flight, "ms_per_step": best * 1e3, "evals_per_s": evals / best, "chained": bool(chained),
             "what": "the same cell with %d independent steps in flight on %d HIP streams (contexts), %d steps, best of 3: "
-                    "further steps fill the SIMDs that a partial round of workgroups leaves underused" % (n_flight, n_flight, steps)}
+                    "further steps fill the SIMDs that a partial round of workgroups leaves underused%s" % (
+                        n_flight, n_flight, steps,
+                        "" if not chained else "; chained (lbl_ctx_chain_accumulate): every step's accumulate kernels wait for the "
+                        "previous step's, so they run alone on the chip, one after another, with the line prep of the next step "
+                        "and the sweep of the previous one beside them")}
 
 
 # ------------------------------------------------------------------------------------------
@@ -517,11 +554,11 @@ def main():
     ap.add_argument("--gather", default="abs_coef", choices=["abs_coef", "all"])
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-gather in stream instead of pipelined")
     ap.add_argument("--gather-batch", default="auto",
-                    help="N > 1: steps of a resident set whose shards leave in ONE all-gather (fewer, larger collectives); auto: "
-                         "3..8 by the step count for the pipelined single-array gather, 1 = a collective per step")
+                    help="N > 1: steps of a resident set whose shards leave in ONE all-gather (fewer, larger collectives); auto = 1: "
+                         "a collective per step; fit: 3..8 by the step count; or a number")
     ap.add_argument("--in-flight", default="auto", choices=["auto", "1", "2", "3"],
-                    help="independent steps in flight per rank, each on a HIP stream (context) of its own; auto: 1 for an "
-                         "unsharded grid, 2 for a shard (see steps_in_flight)")
+                    help="independent steps in flight per rank, each on a HIP stream (context) of its own; auto: 1 "
+                         "(see steps_in_flight)")
     ap.add_argument("--check", action="store_true", help="also compare one shard against the oracle (slow)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="experiment: lbl_set_option(KEY, VALUE) on every context (e.g. accum_skew=0)")
@@ -766,7 +803,44 @@ def main():
                     layers[0].enqueue_allgather(comm, gather_bufs(layers[0]))
         barrier()
         t_gather = (time.perf_counter() - t_b) / n_b
-        breakdown_local = (t_compute, t_gather)
+
+        # Like-for-like legs, whatever mode the timed region ran in: ONE step in flight on ONE resident set, ONE
+        # collective per step; first with the all-gather in stream (a step's spectrum is complete before the next
+        # step starts), then overlapped with the next step's kernels on the communicator's stream (two buffer
+        # sets when the run has them, else the same set: a slot's fence orders the reuse).
+        def plain_step(L, overlap_slot=None):
+            L.enqueue(**step_kwargs)
+            if is_column:
+                L.enqueue_allgather(comm, overlap_slot=overlap_slot)
+            else:
+                L.enqueue_allgather(comm, gather_bufs(L), overlap_slot=overlap_slot)
+
+        barrier()
+        t_b = time.perf_counter()
+        for _ in range(n_b):
+            plain_step(layers[0])
+        barrier()
+        t_instream = (time.perf_counter() - t_b) / n_b
+        t_overlap = float("nan")
+        if n_sets >= 2:                                         # (one buffer set: nothing to overlap a gather with)
+            barrier()
+            t_b = time.perf_counter()
+            for i_b in range(n_b):
+                sl = i_b % 2
+                comm.fence_dev(4 + sl)                          # the gather that used this set two steps ago
+                plain_step(layers[sl], overlap_slot=4 + sl)
+            barrier()
+            t_overlap = (time.perf_counter() - t_b) / n_b
+        # latency of ONE step: enqueue -> the gathered spectrum usable on the host side (stream drained), median of 7
+        lat = []
+        for _ in range(7):
+            barrier()
+            t_b = time.perf_counter()
+            plain_step(layers[0])
+            ctx.sync()
+            lat.append(time.perf_counter() - t_b)
+        t_latency = sorted(lat)[len(lat) // 2]
+        breakdown_local = (t_compute, t_gather, t_instream, t_overlap, t_latency)
 
     # Batched gather: one more full batch per resident set, then every slot of the gathered buffer is checked on
     # the host - this rank's own slots against its shard bit for bit, every rank's slots finite, positive over
@@ -815,9 +889,23 @@ def main():
             red.upload(np.array([v], dtype=np.float64), offset=rank)
             comm.allgather_dev(red, rank, 1, red)
             per_rank.append(red.download(world).copy())
+        n_gathered = 1 if (is_column or args.gather == "abs_coef") else 3
+        recv_bytes = (world - 1) * layer.S * 8.0 * n_gathered
+        t_ag = float(per_rank[1].max())
         breakdown = {"kernels_only_ms_per_step": float(per_rank[0].max()) * 1e3,
                      "kernels_only_ms_by_rank": [round(float(v) * 1e3, 4) for v in per_rank[0]],
-                     "allgather_alone_ms_per_step": float(per_rank[1].max()) * 1e3,
+                     "allgather_alone_ms_per_step": t_ag * 1e3,
+                     "allgather_alone_GBps_per_rank": (recv_bytes / t_ag / 1e9) if t_ag > 0 else None,
+                     "allgather_bytes_received_per_rank_per_step": recv_bytes,
+                     "like_for_like": {
+                         "in_stream_ms_per_step": float(per_rank[2].max()) * 1e3,
+                         "overlapped_ms_per_step": (float(per_rank[3].max()) * 1e3) if n_sets >= 2 else None,
+                         "step_latency_ms": float(per_rank[4].max()) * 1e3,
+                         "what": "ONE step in flight, ONE collective per step, whatever mode the timed region ran in: the "
+                                 "all-gather in stream after the step's kernels; the same with the gather overlapped with the "
+                                 "next step's kernels (communicator stream); and the latency of a single step from enqueue to "
+                                 "the gathered spectrum (stream drained, median of 7); wall clock between barriers, max over ranks. "
+                                 "Form N-GPU / 1-GPU ratios of this mode with the N = 1 line's ms_per_step (one step in flight)"},
                      "what": "two short untimed passes after the timed region, wall clock between barriers, max over "
                              "ranks: the step's kernels with no all-gather (%d step(s) in flight, as in the timed region), and "
                              "the step's all-gather(s) alone in stream (%s%s); the pipelined step overlaps the two"
@@ -829,6 +917,7 @@ def main():
 
     result = None
     if rank == 0:
+        world_scale = evals_total / max(evals_local, 1.0)       # (rank 0's pair counts scaled to the job: shards are alike)
         value = evals_total * args.steps / elapsed_max
         n_acc, ms_acc = prof["xsec_accumulate"]
         n_sw, ms_sw = prof["layer_sweep"]
@@ -886,6 +975,15 @@ def main():
                                      "overlapped with the next step (%d buffer sets)" % n_sets if not batches else
                                      "one collective per %d steps of a resident set (shards staged side by side in a batch "
                                      "buffer), overlapped with the steps that fill the set's other batch buffer" % n_batch)},
+            "pairs": dict(layer.pairs, **{
+                "what": "how the default kernel treats the step's (line, span of 256 grid points) pairs: pairs_series go through "
+                        "the 30-term far-field series about the span centre (fp64-exact: remainder below half an ulp), pairs_direct "
+                        "are evaluated point by point; evals_series = 256 per far pair, evals_direct the rest of evals_per_step. "
+                        "`value` counts every contribution the reference's loop adds (both kinds); value_direct_kernel is the "
+                        "same workload through the all-direct kernel (accum_variant 3), every pair evaluated point by point"}),
+            "evals_direct_per_s": float(layer.pairs["evals_direct"]) * world_scale * args.steps / elapsed_max,
+            "value_direct_kernel": None,
+            "direct_frac": None,
             "roofline": {"bound": "hbm", "kernel": "xsec_accumulate_lds_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_stale": (pmc["stale"] if traffic is not None else None),
@@ -912,10 +1010,15 @@ def main():
                                    "allgather": ms_ag / args.steps},
             "setup_s": t_setup,
         }
+        vb = result["valu_f64"]
+        if vb.get("direct_kernel_evals_per_s"):
+            result["value_direct_kernel"] = vb["direct_kernel_evals_per_s"]
+            result["direct_frac"] = vb.get("direct_frac")
         if breakdown is not None:
             result["sharded_step_breakdown"] = breakdown
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(cfg["layers"][0] if is_column else cfg, args.cpu_seconds)
+            raw = cfg["layers"] if is_column else [cfg]
+            result["cpu_baseline"] = cpu_baseline([dict(c, raw_molecules=c["molecules"]) for c in raw], args.workload, args.cpu_seconds)
         if args.check:
             result["check"] = oracle_check(layer, cfg)
     want_api = rank == 0 and world == 1 and not args.no_api_path and not args.shard_of
@@ -940,6 +1043,8 @@ def main():
         result["api_path"] = api_path(cfg)
         if small_cell and n_flight == 1:
             result["in_flight_leg"] = in_flight_leg(cfg)
+        elif n_flight == 1:
+            result["in_flight_leg"] = in_flight_leg(cfg, n_flight=2, steps=60)     # so that ratios can be formed in either mode
     if rank == 0:
         print(json.dumps(result))
 

@@ -92,6 +92,13 @@ const char* lbl_last_error(const lbl_ctx* ctx);
 int lbl_sync(lbl_ctx* ctx);
 /* Native hipStream_t of the context (as void*) so a host can order foreign work on it. */
 int lbl_ctx_stream(lbl_ctx* ctx, void** stream);
+/* Two contexts of one device as a software pipeline: the ACCUMULATE kernels of `ctx` wait for the accumulate
+ * kernels `predecessor` has enqueued so far (an event on its stream), everything else of `ctx` - line prep
+ * before them, the sweep after them - does not.  With A chained after B and B after A and steps dealt
+ * alternately, the fp64-bound accumulate kernels run one after another, each alone on the chip, while the
+ * line prep of the next step and the sweep of the previous one fill the cycles they leave; every step's
+ * arrays are complete in step order.  predecessor = NULL ends the chaining. */
+int lbl_ctx_chain_accumulate(lbl_ctx* ctx, lbl_ctx* predecessor);
 /* Name of the device ("gfx950..."), CU count, HBM bytes. */
 int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 
@@ -117,6 +124,11 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "accum_tile_order"       positional order only: 1 (default) natural | 0 one contiguous run of
  *                            tiles per XCD | 2 golden-ratio stride
  *   "accum_blocks_per_cu"    variant 4 only: resident workgroups per CU, 0 = ask the runtime
+ *   "accum_skew"             1 (default) line lists whose window has no far line (narrower than 640 points) go
+ *                            through the skewed-range kernel when they fill the chip | 0 the span kernel
+ *                            (all-direct instantiation) | 2 EVERY job through the skewed-range kernel (parity tests)
+ *   "accum_skew_points_per_lane"  1 | 2 | 4 (default) | 8
+ *   "debug_ablate"           timing experiments only (results are wrong): bits switch off parts of kernels
  *   "layer_step_fused"       1 (default) lbl_layer_step_dev folds the sweep of a single-line-list layer into the
  *                            accumulate kernel | 0 always accumulate launch + sweep launch (bit-identical; A/B)
  *   "debug_throw"            test hook: 1 / 2 / 3 raise std::bad_alloc / std::runtime_error /
@@ -277,8 +289,10 @@ int lbl_line_survey_dev(lbl_ctx* ctx, lbl_lines* lines, const lbl_grid* grid, lb
  * Inside a capture only kernel launches are possible: a call that would allocate, upload or
  * synchronise returns LBL_ERR_STATE (and the capture must still be ended).  The all-gather is not
  * captured (lbl_allgather_* return LBL_ERR_STATE inside a capture): enqueue it after the graph.  A graph
- * holds pointers into the context's scratch and caches; lbl_graph_launch returns LBL_ERR_STATE once
- * one of them has changed (another batch grew a buffer or took a descriptor slot): capture again. */
+ * holds pointers into the context's scratch and caches and to the buffers and line lists of the captured
+ * calls; lbl_graph_launch returns LBL_ERR_STATE once one of them may have changed (another batch grew a
+ * scratch buffer or took a descriptor slot, or ANY buffer or line list of the context was destroyed): capture
+ * again.  Page-locked host blocks (lbl_host_alloc) are never captured. */
 typedef struct lbl_graph lbl_graph;
 int lbl_capture_begin(lbl_ctx* ctx);
 int lbl_capture_end(lbl_ctx* ctx, lbl_graph** out);

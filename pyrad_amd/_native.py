@@ -57,6 +57,7 @@ SIGNATURES = {
     "lbl_last_error": (C.c_char_p, [_P]),
     "lbl_sync": (C.c_int, [_P]),
     "lbl_ctx_stream": (C.c_int, [_P, C.POINTER(_P)]),
+    "lbl_ctx_chain_accumulate": (C.c_int, [_P, _P]),
     "lbl_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "lbl_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "lbl_profile_enable": (C.c_int, [_P, C.c_int]),
@@ -216,6 +217,11 @@ class Context:
         hbm = C.c_int64()
         self.check(self.lib.lbl_device_info(self.h, name, 256, C.byref(ncu), C.byref(hbm)))
         return dict(name=name.value.decode(), n_cu=ncu.value, hbm_bytes=hbm.value)
+
+    def chain_accumulate(self, predecessor):
+        """This context's accumulate kernels start after those ``predecessor`` has enqueued (lbl_ctx_chain_accumulate);
+        None ends the chaining."""
+        self.check(self.lib.lbl_ctx_chain_accumulate(self.h, predecessor.h if predecessor is not None else None))
 
     def set_option(self, key: str, value: int):
         self.check(self.lib.lbl_set_option(self.h, key.encode(), int(value)))

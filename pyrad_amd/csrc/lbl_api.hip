@@ -16,6 +16,10 @@
 
 
 using namespace lbl;
+namespace lbl {
+void comm_quiesce(lbl_ctx* ctx);      // lbl_comm.hip: wait for unfenced collectives on buffers of ctx
+void comm_forget(lbl_ctx* ctx);       // lbl_comm.hip: ctx is being destroyed
+}
 
 // ----------------------------------------------------------------------------------------
 // objects
@@ -86,6 +90,8 @@ struct lbl_ctx {
                              // skewed-range kernel whatever its window and the grid size (parity tests)
     int skew_R = 4;          // points per lane of the skewed-range kernel
     int ablate = 0;          // diagnostics: AccumJob.ablate
+    lbl_ctx* chain_pred = nullptr;   // lbl_ctx_chain_accumulate: accumulate kernels wait for this context's
+    hipEvent_t accum_done = nullptr; // recorded after this context's accumulate launches
     bool no_fuse = false;    // lbl_layer_step_dev as accumulate + separate sweep launch (A/B, parity tests)
     int live_objects = 0;
     // event timing (lbl_profile_*)
@@ -305,6 +311,8 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) try {
     if (ctx->live_objects != 0) return fail(ctx, LBL_ERR_STATE, "%d device objects still alive", ctx->live_objects);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    lbl::comm_forget(ctx);
+    if (ctx->accum_done) (void)hipEventDestroy(ctx->accum_done);
     for (auto& v : ctx->ev_rec) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto& sc : ctx->schedules) { if (sc.d_list) (void)hipFree(sc.d_list); if (sc.d_tabs) (void)hipFree(sc.d_tabs); }
@@ -329,6 +337,17 @@ extern "C" int lbl_sync(lbl_ctx* ctx) try {
 extern "C" int lbl_ctx_stream(lbl_ctx* ctx, void** stream) try {
     if (!ctx || !stream) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     *stream = (void*)ctx->stream;
+    return LBL_OK;
+} LBL_GUARD_END(ctx)
+
+extern "C" int lbl_ctx_chain_accumulate(lbl_ctx* ctx, lbl_ctx* predecessor) try {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (predecessor && predecessor->device != ctx->device) return fail(ctx, LBL_ERR_BAD_ARG, "contexts live on different devices");
+    if (predecessor == ctx) return fail(ctx, LBL_ERR_BAD_ARG, "a context cannot follow itself");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (lbl_ctx* c : {ctx, predecessor})
+        if (c && !c->accum_done) HIP_TRY(ctx, hipEventCreateWithFlags(&c->accum_done, hipEventDisableTiming));
+    ctx->chain_pred = predecessor;
     return LBL_OK;
 } LBL_GUARD_END(ctx)
 
@@ -458,7 +477,9 @@ extern "C" int lbl_buffer_destroy(lbl_buffer* buf) try {
     if (!buf) return LBL_OK;
     lbl_ctx* ctx = buf->ctx;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    lbl::comm_quiesce(ctx);           // an overlapped all-gather may still read or write it on the communicator's stream
     HIP_TRY(ctx, hipFree(buf->d));
+    ctx->epoch++;                     // a captured graph may hold its address (lbl_graph_launch then refuses)
     ctx->live_objects--;
     delete buf;
     return LBL_OK;
@@ -576,6 +597,7 @@ extern "C" int lbl_lines_destroy(lbl_lines* lines) try {
     lbl_ctx* ctx = lines->ctx;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipFree(lines->d));
+    ctx->epoch++;                     // a captured graph may hold its address (lbl_graph_launch then refuses)
     ctx->live_objects--;
     delete lines;
     return LBL_OK;
@@ -1064,6 +1086,9 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     HIP_TRY(ctx, hipGetLastError());
     ctx->last_jobs = n_jobs;
     if (prep_only) return LBL_OK;
+    // software pipeline of two contexts (lbl_ctx_chain_accumulate): this step's accumulate kernels start after the
+    // predecessor's; its line prep (above) did not wait
+    if (ctx->chain_pred && !ctx->capturing) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->chain_pred->accum_done, 0));
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const Group& g = groups[gi];
         ev = prof_begin(ctx, PROF_ACCUM);
@@ -1085,6 +1110,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         prof_end(ctx, PROF_ACCUM, ev);
         HIP_TRY(ctx, hipGetLastError());
     }
+    if (ctx->accum_done && !ctx->capturing) HIP_TRY(ctx, hipEventRecord(ctx->accum_done, ctx->stream));
     for (int j = 0; j < n_jobs; ++j) {
         if (!needs_regrid(grid[j])) continue;
         ev = prof_begin(ctx, PROF_REGRID);

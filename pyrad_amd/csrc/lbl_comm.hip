@@ -11,6 +11,8 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <vector>
+#include <mutex>
 
 // private views of the objects defined in lbl_api.hip
 extern "C" int lbl_ctx_stream(lbl_ctx* ctx, void** stream);
@@ -53,6 +55,35 @@ struct lbl_comm {
 
 static_assert(sizeof(ncclUniqueId) <= LBL_UNIQUE_ID_BYTES, "unique id does not fit");
 
+// Live communicators, so that freeing a buffer or a context can wait for collectives that still use them:
+// an overlapped all-gather runs on the communicator's own stream, which a context's stream knows nothing
+// about until the slot's fence.
+static std::mutex g_comms_mutex;
+static std::vector<lbl_comm*> g_comms;
+
+namespace lbl {
+// Before memory of `ctx` is released: collectives issued on its buffers and not fenced yet must have finished.
+void comm_quiesce(lbl_ctx* ctx) {
+    std::lock_guard<std::mutex> lock(g_comms_mutex);
+    for (lbl_comm* cm : g_comms)
+        for (int i = 0; i < kSlots; ++i)
+            if (cm->pending[i] && cm->owner[i] == ctx) { (void)hipStreamSynchronize(cm->cstream); break; }
+}
+// `ctx` is going away: its slots are finished and no fence may touch its stream any more.
+void comm_forget(lbl_ctx* ctx) {
+    std::lock_guard<std::mutex> lock(g_comms_mutex);
+    for (lbl_comm* cm : g_comms) {
+        bool synced = false;
+        for (int i = 0; i < kSlots; ++i) {
+            if (cm->owner[i] != ctx || cm->ctx == ctx) continue;      // (a communicator dies with its own context's objects)
+            if (cm->pending[i] && !synced) { (void)hipStreamSynchronize(cm->cstream); synced = true; }
+            cm->pending[i] = false;
+            cm->owner[i] = cm->ctx;
+        }
+    }
+}
+}  // namespace lbl
+
 extern "C" int lbl_comm_unique_id(char id[LBL_UNIQUE_ID_BYTES]) try {
     if (!id) return lbl::comm_fail(nullptr, LBL_ERR_BAD_ARG, "id is NULL");
     ncclUniqueId u;
@@ -89,12 +120,21 @@ extern "C" int lbl_comm_create(lbl_ctx* ctx, const char id[LBL_UNIQUE_ID_BYTES],
         delete cm;
         return lbl::comm_fail(ctx, LBL_ERR_HIP, "communicator stream/event creation failed");
     }
+    {
+        std::lock_guard<std::mutex> lock(g_comms_mutex);
+        g_comms.push_back(cm);
+    }
     *out = cm;
     return LBL_OK;
 } LBL_GUARD_END(ctx)
 
 extern "C" int lbl_comm_destroy(lbl_comm* comm) try {
     if (!comm) return LBL_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_comms_mutex);
+        for (size_t i = 0; i < g_comms.size(); ++i)
+            if (g_comms[i] == comm) { g_comms.erase(g_comms.begin() + (long)i); break; }
+    }
     void* s = nullptr;
     lbl_ctx_stream(comm->ctx, &s);
     (void)hipStreamSynchronize((hipStream_t)s);

@@ -84,6 +84,13 @@ __device__ __forceinline__ double linspace_at(long long j, long long n, double s
 // quotient; by Markstein's theorem one more correction with an exact residual gives RN(x/c) for every
 // x whenever rc is the correctly rounded reciprocal of a c whose significand is not all ones.  The host
 // passes rc = 0 for such a c (or a subnormal / non-finite one) and the plain divide is taken instead.
+// Range: the proof needs the residual x - q c to be exact, i.e. not to fall below the subnormal grid:
+// |x| >= 2^-969 (about 1e-292) for the divisors used here; below that the quotient can be off by one ulp
+// of a number that is itself below 1e-270, and x = +-inf gives NaN (inf - inf) where IEEE gives +-inf.
+// Cross sections times volume fractions times pressures are many orders of magnitude inside the range
+// (the smallest non-zero cross section a line list produces here is ~1e-200: Gaussian tails underflow to
+// exact zeros first, and 0 is handled exactly); a guard per call would cost the sweeps 6 % of their
+// instructions.  tests/test_gpu_abi.py::test_sweep_divisions_are_ieee_exact covers 1e-270 .. 1e+250 and 0.
 __device__ __forceinline__ double div_uniform(double x, double c, double rc) {
     if (rc == 0.0) return x / c;
     double q = x * rc;
@@ -219,17 +226,24 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
             const double u2_under = 745.2;           // exp(-745.2) == 0 in fp64
             double u2 = u2_under;
             if (KL != 0.0) {
-                // ratio Gauss/Lorentz at offset u = d/a:  C (1+u^2) exp(-u^2);  solve = 2^-54
+                // ratio Gauss/Lorentz at offset u = d/a:  C (1+u^2) exp(-u^2);  solve = 2^-54 for u^2 = v + 1,
+                // v = ln C + ln(1 + v).  The cut-off only has to err on the far side, so single precision
+                // with a margin does: ln C from the exponent and a hardware log2 of the mantissa, three
+                // fixed-point steps (each contracts by 1/(1+v)), +0.01 for the float roundings and the
+                // remaining contraction (4 double-precision logs were a fifth of this kernel's instructions).
                 const double C = fabs(KG / (r.KL * rc.b)) * 18014398509481984.0;
                 if (C <= 1.0) {
                     u2 = 0.0;
                 } else {
-                    double v = log(C);
-                    for (int it = 0; it < 3; ++it) v = log(C * (1.0 + v));   // contracts by 1/(1+v) per step
-                    u2 = fmin(v + 1.0, u2_under);
+                    int ex;
+                    const float mant = (float)frexp(C, &ex);                               // C = mant 2^ex, mant in [0.5, 1)
+                    const float lnC = ((float)ex + __log2f(mant)) * 0.69314718f;
+                    float v = lnC;
+                    for (int it = 0; it < 3; ++it) v = lnC + __log2f(1.0f + v) * 0.69314718f;
+                    u2 = fmin((double)(v * 1.00001f + 1.01f), u2_under);
                 }
             }
-            dg = (u2 > 0.0) ? sqrt(u2) * a + 2.0 : 0.0;
+            dg = (u2 > 0.0) ? (double)(__fsqrt_rn((float)u2) * 1.000001f) * a + 2.0 : 0.0;
         }
         r.dgi = (dg < 2.0e9) ? (int32_t)dg : 2000000000;
         // Gaussian recurrence along a lane's consecutive points: only for b <= 4 (see gauss_term);

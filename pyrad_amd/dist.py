@@ -172,6 +172,47 @@ def span_costs(centre_index, H: int, n: int, has_gaussian=None) -> np.ndarray:
     return near * (5.0 * 4) + gauss * 15.0 + (reach - near) * 1.6 + 600.0
 
 
+FAR_HALF_SPANS = 4           # lbl_kernels.hip FF_FAR: a line is "far" from a span when its centre is >= 4 half-spans from the span centre
+
+
+def pair_split(centre_index, H: int, n: int, first: int = 0, count: int | None = None) -> dict:
+    """How the default accumulate kernel treats the (line, span) pairs of one line list on grid points
+    [first, first + count): the same classes lbl_api.hip's group_schedule tabulates per span of 256 points
+    (edge: the line's support ends inside the span; near: every point inside the support, centre within
+    4 half-spans of the span centre; far: the rest, evaluated through the 30-term series about the span centre).
+    Windows too narrow for any far line (H < 640) run all-direct kernels: everything is direct there.
+    Returns the pair counts and the (line, grid point) evaluations behind them:
+    evals_series = 256 per far pair (a far line covers the whole span), evals_direct = the rest of the exact
+    eval count.  Host bookkeeping for bench.py; never used for results."""
+    c = np.asarray(centre_index, dtype=np.int64)
+    count = int(n) - int(first) if count is None else int(count)
+    H = int(H)
+    n_spans = -(-count // SPAN)
+    lo = int(first) + np.arange(n_spans, dtype=np.int64) * SPAN
+    hi = np.minimum(lo + SPAN, int(first) + count) - 1
+    iA = np.searchsorted(c, lo - H, "left")
+    iB = np.searchsorted(c, hi - H, "left")
+    iC = np.searchsorted(c, lo + H + 1, "left")
+    iD = np.searchsorted(c, hi + H + 1, "left")
+    none = hi - H >= lo + H + 1                      # span wider than the support: no interior line
+    iB = np.where(none, iD, iB)
+    iC = np.where(none, iD, iC)
+    pairs = int((iD - iA).sum())
+    lo_c = np.maximum(c - H, int(first))
+    hi_c = np.minimum(c + H, int(first) + count - 1)
+    evals = int(np.maximum(hi_c - lo_c + 1, 0).sum())
+    if H < (SPAN // 2) * (FAR_HALF_SPANS + 1):
+        return dict(pairs=pairs, pairs_series=0, pairs_direct=pairs, evals=evals, evals_series=0, evals_direct=evals)
+    reach = FAR_HALF_SPANS * (SPAN // 2)
+    iF1 = np.minimum(np.maximum(np.searchsorted(c, lo + SPAN // 2 - reach, "left"), iB), iC)
+    iF2 = np.minimum(np.maximum(np.searchsorted(c, lo + SPAN // 2 + reach, "left"), iF1), iC)
+    far = int(((iF1 - iB) + (iC - iF2)).sum())
+    full = (hi - lo + 1 == SPAN)
+    far_evals = int((((iF1 - iB) + (iC - iF2)) * (hi - lo + 1)).sum())
+    return dict(pairs=pairs, pairs_series=far, pairs_direct=pairs - far, evals=evals, evals_series=far_evals,
+                evals_direct=evals - far_evals)
+
+
 def gaussian_part(lines: dict, T, P, conc, molmass) -> np.ndarray:
     """Which lines carry a Gaussian term (regime select of cls:378-387: not 'Lorentz only'), from the
     reference's own half-width expressions (cls:252-263) - a host estimate for the shard cost model

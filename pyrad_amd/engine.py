@@ -209,6 +209,7 @@ class ResidentLayer:
         self.iso_mol, self.conc = [], []
         self.evals = 0
         self.n_lines = 0
+        self.pairs = dict(pairs=0, pairs_series=0, pairs_direct=0, evals=0, evals_series=0, evals_direct=0)
         self._keep = []
         sh = None if plan is None else (self.first, self.count)
         self.grid_native = native_grid(g, sh)
@@ -229,6 +230,11 @@ class ResidentLayer:
                 self.n_lines += dev_lines.n
                 if not self.empty:
                     self.evals += eval_count(lines["nu"], g["range_min"], g["resolution"], g["W"], g["n_work"], sh)
+                    from .dist import pair_split
+                    idx = np.sort(((np.asarray(lines["nu"], dtype=np.float64) - g["range_min"]) / g["resolution"]).astype(np.int64))
+                    ps = pair_split(idx, max(int(g["W"]) - 2, 0), g["n_work"], *((0, None) if sh is None else sh))
+                    for k_ in self.pairs:
+                        self.pairs[k_] += ps[k_]
                 if keep_host_lines:
                     self._keep.append(lines)
         self.abs_coef = ctx.buffer(max(self.padded_n, 1))
@@ -359,6 +365,7 @@ class ResidentColumn:
         self.jobs = [j for L in self.layers for j in L.jobs]
         self.evals = sum(L.evals for L in self.layers)
         self.n_lines = sum(L.n_lines for L in self.layers)
+        self.pairs = {k: sum(L.pairs[k] for L in self.layers) for k in self.layers[0].pairs}
 
     def enqueue(self, layer_arrays=True, fused=True):
         """One column step.  ``fused``: a single pass over all cross sections (lbl_column_step_dev)

@@ -847,20 +847,26 @@ class Molecule(_OpticalMixin, list):
         if self.exotic:
             return
         self._ensure_swept()
+        self._mark_sum_ready(force=True)          # the reference re-sums on every call (cls:566-571)
 
-    def _mark_sum_ready(self):
-        if self.exotic or self.progressCrossSection:
+    def _mark_sum_ready(self, force=False):
+        """Defer ``crossSection`` = zeros + sum of the isotopologue cross sections to the first read.  A sum that
+        is already deferred or loaded is kept only while the isotopologue cross sections it was made from are
+        still the current ones (``_xs_version``: bumped by every recomputation and by an assigned host array);
+        the loader always adds the device copies that are current when it runs."""
+        if self.exotic:
             return
-        n = int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION)
         isos = list(self)
         versions = [i._xs_version for i in isos]
+        if self.progressCrossSection and not force and self.__dict__.get("_sum_versions") == versions:
+            return
+        n = int((self.rangeMax - self.rangeMin) / utils.BASE_RESOLUTION)
 
         def load():
             ctx = _ctx()
-            if [i._xs_version for i in isos] != versions:
-                raise RuntimeError("isotopologue cross sections changed before the molecule sum was read")
             return _sum_on_device(ctx, [i._device_xsec_current(ctx, n) for i in isos], n)
         Molecule.crossSection.defer(self, load)
+        self.__dict__["_sum_versions"] = versions
         self.progressCrossSection = True
 
     def _members_ready(self):
@@ -1143,7 +1149,9 @@ class Atmosphere(list):
 
 
 # ----------------------------------------------------------------------------------------
-# plot-type dispatch (cls:824-839).  The matplotlib figures themselves are out of scope.
+# plot-type dispatch (cls:824-839), plot (cls:849-873) and plotSpectrum (cls:876-944).  What the
+# figures show is computed on the device path (getters, transmission, band integrals); drawing it is
+# matplotlib's job, imported when a figure is asked for.
 # ----------------------------------------------------------------------------------------
 def returnPlot(obj, propertyToPlot):
     if propertyToPlot == "transmittance":
@@ -1159,3 +1167,151 @@ def returnPlot(obj, propertyToPlot):
     if propertyToPlot == 'line survey':
         return obj.lineSurvey, 0
     return False
+
+
+def _pyplot():
+    try:
+        import matplotlib.pyplot as plt
+    except ImportError as e:            # the numbers do not need it: returnPlot / spectrumCurves
+        raise ImportError("pyrad_amd.plot / plotSpectrum draw with matplotlib, which is not installed; the curves and legend "
+                          "texts themselves are available without it from returnPlot() and spectrumCurves()") from e
+    return plt
+
+
+def _dark_axes(plt, title):
+    plt.figure(figsize=(10, 6), dpi=80)
+    plt.subplot(111, facecolor='xkcd:dark grey')
+    plt.margins(0.01)
+    plt.subplots_adjust(left=.07, bottom=.08, right=.97, top=.90)
+    plt.title('%s' % title)
+
+
+def _white_legend(plt, handles):
+    legend = plt.legend(handles=handles, frameon=False)
+    plt.setp(legend.get_texts(), color='w')
+
+
+def plot(propertyToPlot, title, plotList, fill=False):
+    """cls:849-873: one curve per object of ``plotList`` for a plot-type string of returnPlot (ui:407-413)."""
+    plt = _pyplot()
+    _dark_axes(plt, title)
+    plt.xlabel('wavenumber cm-1')
+    plt.ylabel(propertyToPlot)
+    if propertyToPlot == 'line survey':
+        plt.yscale('log')
+    plt.grid('grey', linewidth=.5, linestyle=':')
+    handles = []
+    style = dict(linewidth=1.2, alpha=.7)
+    for singlePlot, color in zip(plotList, COLOR_LIST):
+        yAxis, fillAxis = returnPlot(singlePlot, propertyToPlot)
+        xAxis = singlePlot.xAxis
+        curve, = plt.plot(xAxis, yAxis, color=color, label='%s' % singlePlot.name, **style)
+        handles.append(curve)
+        plt.fill_between(xAxis, fillAxis, yAxis, color=color, alpha=.3 * fill)
+        style = dict(linewidth=.7, alpha=.5)
+    _white_legend(plt, handles)
+    plt.show()
+
+
+def _planck_axis(planckType, rangeMin, rangeMax):
+    """abscissa and Planck function of a plotSpectrum type (cls:888-903); None for an unknown type"""
+    if planckType == 'wavenumber':
+        n = int((rangeMax - rangeMin) / utils.BASE_RESOLUTION)
+        return ('wavenumber cm-1', 'Radiance Wm-2sr-1(cm-1)-1',
+                np.linspace(rangeMin, rangeMax, n), lambda T: _planck_wavenumber_axis(rangeMin, rangeMax, n, T))
+    if planckType == 'Hz':
+        x = np.linspace(rangeMin, rangeMax, 1000)
+        return 'Hertz', 'Radiance Wm-2sr-1Hz-1', x, lambda T: planckHz(x, T)
+    if planckType == 'wavelength':
+        x = np.linspace(rangeMin, rangeMax, int((rangeMax - rangeMin) / utils.BASE_RESOLUTION))
+        return 'wavelength um', 'Radiance Wm-2sr-1um-1', x, lambda T: planckWavelength(x, T)
+    return None
+
+
+def _planck_wavenumber_axis(rangeMin, rangeMax, n, temperature):
+    """pyradPlanck.planckWavenumber on linspace(rangeMin, rangeMax, n) (pl:38-44), on the device (lbl_planck_dev)."""
+    ctx = _ctx()
+    out = ctx.buffer(max(n, 1))
+    try:
+        ctx.planck_dev(rangeMin, rangeMax, n, float(temperature), out)
+        return out.download(n)
+    finally:
+        out.free()
+
+
+def planckHz(Hz, temp):
+    """pyradPlanck.py:18-26 (Wm-2sr-1Hz-1; plot-only, host NumPy)"""
+    with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+        a = 2 * h * Hz**3 / c**2
+        b = h * Hz / k / temp
+        return a / (np.exp(b) - 1)
+
+
+def planckWavelength(lam, temp):
+    """pyradPlanck.py:29-35 (wavelength in um, Wm-2sr-1um-1; plot-only, host NumPy)"""
+    with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+        a = 2.0E24 * h * c ** 2 / (lam ** 5)
+        b = 10 ** 6 * h * c / lam / k / temp
+        return a / (np.exp(b) - 1)
+
+
+def spectrumCurves(layer=None, title=None, rangeMin=None, rangeMax=None, objList=None, surfaceSpectrum=None,
+                   planckTemperatureList=None, planckType='wavenumber'):
+    """Everything plotSpectrum draws (cls:876-944), without drawing it: axis labels, title, and the curves in
+    the reference's order - one Planck curve per temperature, labelled '<T>K : <band integral>Wm-2' with
+    integrateSpectrum(y, res=(rangeMax - rangeMin) / len(y)) (cls:914), then for every object of ``objList`` its
+    ``transmission(surfaceSpectrum)`` labelled '<name> : <integrateSpectrum(y, pi)>Wm-2' (cls:933-937).  Transmission,
+    Planck curves on the layer axis and the integrals run on the device."""
+    if layer:
+        rangeMin, rangeMax, title = layer.rangeMin, layer.rangeMax, layer.title
+    axis = _planck_axis(planckType, rangeMin, rangeMax)
+    if axis is None:
+        raise UnboundLocalError("local variable 'xAxis' referenced before assignment")     # what cls:906-912 ends in
+    xlabel, ylabel, xAxis, planckFunction = axis
+    if not rangeMax:
+        xAxis = layer.xAxis                                                                # cls:910-911
+    curves = []
+    for temperature in planckTemperatureList:
+        yAxis = planckFunction(float(temperature))
+        power = integrateSpectrum(yAxis, res=(rangeMax - rangeMin) / len(yAxis))
+        curves.append(dict(kind='planck', x=xAxis, y=yAxis, power=power, label='%sK : %sWm-2' % (temperature, round(power, 2))))
+    surfacePower = None
+    if objList:
+        surfacePower = integrateSpectrum(surfaceSpectrum, pi)                              # cls:933
+        for obj in objList:
+            yAxis = obj.transmission(surfaceSpectrum)
+            power = integrateSpectrum(yAxis, pi)
+            curves.append(dict(kind='object', x=layer.xAxis, y=yAxis, power=power, label='%s : %sWm-2' % (obj.name, round(power, 2))))
+    return dict(title=title, xlabel=xlabel, ylabel=ylabel, curves=curves, surfacePower=surfacePower)
+
+
+def plotSpectrum(layer=None, title=None, rangeMin=None, rangeMax=None, objList=None, surfaceSpectrum=None,
+                 planckTemperatureList=None, planckType='wavenumber', fill=False):
+    """cls:876-944 (ui:373 Planck curves, ui:399 transmission through a layer): the figure of spectrumCurves()."""
+    plt = _pyplot()
+    spec = spectrumCurves(layer, title, rangeMin, rangeMax, objList, surfaceSpectrum, planckTemperatureList, planckType)
+    _dark_axes(plt, spec['title'])
+    plt.xlabel(spec['xlabel'])
+    plt.ylabel(spec['ylabel'])
+    handles = []
+    rgb = [1.0, .6, .3]                       # the Planck curves walk through the colours like cls:904-931
+    step = [-.15, .15, .15]
+    objects = iter(zip(COLOR_LIST, [dict(alpha=.7, linewidth=1.2)] + [dict(alpha=.5, linewidth=1)] * len(COLOR_LIST)))
+    for c in spec['curves']:
+        if c['kind'] == 'planck':
+            curve, = plt.plot(c['x'], c['y'], linewidth=.75, color=tuple(rgb), linestyle=':', label=c['label'])
+            for i in range(3):
+                if not 0 <= rgb[i] + step[i] <= 1:
+                    step[i] = -step[i]
+                rgb[i] += step[i]
+            if rgb[0] < .3 and rgb[1] < .3 and rgb[2] < .3:
+                rgb[1] += .5
+                rgb[2] += .2
+            if rgb[0] < .3 and rgb[1] < .3:
+                rgb[1] += .4
+        else:
+            color, style = next(objects)
+            curve, = plt.plot(c['x'], c['y'], color=color, label=c['label'], **style)
+        handles.append(curve)
+    _white_legend(plt, handles)
+    plt.show()

@@ -817,9 +817,66 @@ def g10():
     save("G10_line_survey", **arrays)
 
 
+# ----------------------------------------------------------------------------
+# G11: the reference's own plot() and plotSpectrum() (cls:849-944) under the Agg backend: the
+# curves they draw and the legend texts (band integrals rounded to 2 digits) read back from the figure
+# ----------------------------------------------------------------------------
+def g11():
+    import json
+    import matplotlib.pyplot as plt
+    cfg = dict(synthetic.config_c1(n_lines=600), T=270, surface_T=288)
+
+    def figure_curves():
+        ax = plt.gcf().axes[0]
+        lines = ax.get_lines()
+        out = dict(labels=[ln.get_label() for ln in lines], x=[np.array(ln.get_xdata(), dtype=np.float64) for ln in lines],
+                   y=[np.array(ln.get_ydata(), dtype=np.float64) for ln in lines],
+                   xlabel=ax.get_xlabel(), ylabel=ax.get_ylabel(), title=ax.get_title(), yscale=ax.get_yscale())
+        plt.close("all")
+        return out
+
+    _, layer = run_reference_layer(cfg)
+    UT.BASE_RESOLUTION = cfg["base_resolution"]
+    arrays = dict(cfg_scalars(cfg))
+    arrays.update(pack_lines("lines", cfg["molecules"][0]["lines"]))
+    arrays["conc_ppm"] = np.float64(400)
+    meta = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        # createTransmission (ui:390-402): surface spectrum at the first temperature, the layer's own temperature appended
+        temps = [288, layer.T]
+        surface = PL.planckWavenumber(layer.xAxis, temps[0])
+        CLS.plotSpectrum(layer, objList=[layer, layer[0]], surfaceSpectrum=surface, planckTemperatureList=temps)
+        c = figure_curves()
+        meta["transmission"] = {k: c[k] for k in ("labels", "xlabel", "ylabel", "title")}
+        for i, y in enumerate(c["y"]):
+            arrays["transmission.y%d" % i] = y
+        arrays["transmission.x"] = c["x"][-1]
+        arrays["surface"] = np.array(surface)
+        # createPlanckCurves (ui:376-380): Planck curves only, the three abscissa types
+        for kind, lo, hi in (("wavenumber", 600, 680), ("Hz", 1e12, 9e13), ("wavelength", 8, 40)):
+            CLS.plotSpectrum(title="Planck spectrums", rangeMin=lo, rangeMax=hi, planckTemperatureList=[250, "300"], planckType=kind)
+            c = figure_curves()
+            meta["planck." + kind] = {k: c[k] for k in ("labels", "xlabel", "ylabel", "title")}
+            meta["planck." + kind]["range"] = [lo, hi]
+            for i, y in enumerate(c["y"]):
+                arrays["planck.%s.y%d" % (kind, i)] = y
+            arrays["planck.%s.x" % kind] = c["x"][0]
+        # createPlot (ui:79-83): every plot type of the menu (ui:407-413) for the layer and its molecule
+        for kind in ("transmittance", "absorption coefficient", "cross section", "absorbance", "optical depth", "line survey"):
+            CLS.plot(kind, "golden %s" % kind, [layer, layer[0]])
+            c = figure_curves()
+            meta["plot." + kind] = {k: c[k] for k in ("labels", "xlabel", "ylabel", "title", "yscale")}
+            for i, y in enumerate(c["y"]):
+                if kind in ("transmittance", "line survey") or (kind == "optical depth" and i == 1):      # (the rest: G1 holds them)
+                    arrays["plot.%s.y%d" % (kind, i)] = y
+    UT.BASE_RESOLUTION = .01
+    arrays["meta_json"] = np.array(json.dumps(meta))
+    save("G11_plots", **arrays)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REFERENCE):
         sys.exit("needs /root/reference (build container only)")
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for name in which:
         globals()[name]()

@@ -96,22 +96,24 @@ def test_shard_plans_tile_the_grid():
 
 
 def test_steps_in_flight_rule():
-    """An unsharded grid is left alone on the chip (an N = 1 line times every kernel by itself); a shard keeps 2
-    steps in flight; small unsharded cells (partial round of workgroups) get the extra in-flight leg."""
+    """One step in flight by default, sharded or not (the simple path is the one that has run with a communicator);
+    more are opt-in; small unsharded cells (partial round of workgroups) get the extra in-flight leg."""
     f = bench.steps_in_flight
-    assert f("auto", False) == 1 and f("auto", True) == 2
+    assert f("auto", False) == 1 and f("auto", True) == 1
     assert f("2", False) == 2 and f("3", True) == 3 and f("1", True) == 1
     assert bench.partial_round(4e5) and bench.partial_round(1e4) and bench.partial_round(0.9e6)      # C2, C1, C3 / 8
     assert not bench.partial_round(7.2e6) and not bench.partial_round(1.8e6)
 
 
 def test_gather_batch_rule():
-    """Batches of 3..8 steps per collective, sized so that the timed region ends on a full batch where it can."""
+    """A collective per step by default; "fit": batches of 3..8 steps per collective, sized so that the timed region
+    ends on a full batch where it can."""
     f = bench.gather_batch
     assert f("auto", False, 10) == 1 and f("4", False, 10) == 1          # in-stream or multi-array gathers: a collective per step
-    assert f("auto", True, 10) == 5                                      # the driver's 20 steps over two resident sets
-    assert f("auto", True, 32) == 8 and f("auto", True, 25) == 5 and f("auto", True, 3) == 3 and f("auto", True, 2) == 2
-    assert f("auto", True, 7) == 7 and f("auto", True, 11) in (4, 6)     # 11 = 2 * 6 - 1 = 3 * 4 - 1
+    assert f("auto", True, 10) == 1 and f("auto", True, 32) == 1         # default: one collective per step
+    assert f("fit", True, 10) == 5                                       # 20 steps over two resident sets
+    assert f("fit", True, 32) == 8 and f("fit", True, 25) == 5 and f("fit", True, 3) == 3 and f("fit", True, 2) == 2
+    assert f("fit", True, 7) == 7 and f("fit", True, 11) in (4, 6)       # 11 = 2 * 6 - 1 = 3 * 4 - 1
     assert f("6", True, 10) == 6 and f("1", True, 10) == 1
 
 

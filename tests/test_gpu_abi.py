@@ -121,6 +121,11 @@ def test_graph_capture_replays_the_step_bit_for_bit(ctx):
     g2 = L.capture_step(surface_T=288.0)
     g2.launch()
     assert all(np.array_equal(L.results()[k], ref[k]) for k in ref)
+    # freeing ANY buffer or line list of the context makes its graphs stale too: a captured kernel node may hold the address
+    ctx.buffer(16).free()
+    with pytest.raises(nat.LblError) as e:
+        g2.launch()
+    assert e.value.code == -6 and "stale" in str(e.value)
     for x in (graph, g1, gc, g2):
         x.free()
     for o in others + [L, one, col]:
@@ -158,12 +163,16 @@ def test_sweep_divisions_are_ieee_exact(ctx):
     """The sweeps divide by launch-uniform constants (1E4, k, T) with a 5-instruction sequence instead of
     the general divide; it must return the IEEE quotient bit for bit, as NumPy's crossSection *
     concentration * P / 1E4 / k / T does (pyradClasses.py:583): random cross sections over 25 decades,
-    zeros, integer and non-integer temperatures, three molecules with one or two isotopologues."""
+    zeros, integer and non-integer temperatures, three molecules with one or two isotopologues; one pass over
+    520 decades (1e-270 .. 1e+250)."""
     k_B = 1.38064852E-23
     rng = np.random.default_rng(77)
     n = 200_000
-    for T, P in ((296, 1013.25), (217, 10.0), (287.65, 843.21), (1.0, 1e-3), (3000, 2e5), (255.99999999999997, 500.0)):
-        xs = [10.0 ** rng.uniform(-42, -16, n) for _ in range(4)]
+    cases = [(296, 1013.25, -42, -16), (217, 10.0, -42, -16), (287.65, 843.21, -42, -16), (1.0, 1e-3, -42, -16),
+             (3000, 2e5, -42, -16), (255.99999999999997, 500.0, -42, -16),
+             (296, 1013.25, -270, 250)]          # the whole range the 5-instruction form is stated for (lbl_kernels.hip div_uniform)
+    for T, P, lo, hi in cases:
+        xs = [10.0 ** rng.uniform(lo, hi, n) for _ in range(4)]
         for a in xs:
             a[rng.integers(0, n, 500)] = 0.0
         conc = [float(c) for c in (4e-4, 0.0123456789, 1.8e-6)]
@@ -202,3 +211,36 @@ def test_plain_c_host_reproduces_the_reference_peak(tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "0/0/1" in p.stdout and "[4502..5498]" in p.stdout
+
+
+def test_chained_contexts_give_the_same_arrays():
+    """lbl_ctx_chain_accumulate: two contexts as a software pipeline (the accumulate kernels of one wait for the
+    other's; line prep and sweeps do not).  Steps dealt alternately to the two contexts reproduce the arrays of a
+    lone context bit for bit, with and without the chaining, and unchaining works."""
+    from pyrad_amd import _native as nat, engine
+    g = engine.layer_grid(1013.25, 640, 700, .001, False)
+    mols = []
+    for s_, seed, conc in (("co2", 71, 4e-4), ("h2o", 72, 1e-2)):
+        sp = synthetic.SPECIES[s_]
+        mols.append(dict(conc=conc, isotopologues=[dict(lines=synthetic.make_lines(seed, 3000, g["eff_min"], g["eff_max"]),
+                                                        molmass=sp["molmass"], q_T=synthetic.q_value(s_, 280), q296=sp["q296"])]))
+    a, b = nat.Context(0), nat.Context(0)
+    try:
+        La, Lb = (engine.ResidentLayer(c, 10.0, 280, 1013.25, 640, 700, mols, .001, False) for c in (a, b))
+        La.enqueue(surface_T=288.0)
+        ref = La.results()
+        a.chain_accumulate(b)
+        b.chain_accumulate(a)
+        for k in range(6):
+            (La, Lb)[k % 2].enqueue(surface_T=288.0)
+        ra, rb = La.results(), Lb.results()
+        assert all(np.array_equal(ra[k], ref[k]) and np.array_equal(rb[k], ref[k]) for k in ref)
+        with pytest.raises(nat.LblError):
+            a.chain_accumulate(a)
+        a.chain_accumulate(None)
+        b.chain_accumulate(None)
+        La.enqueue(surface_T=288.0)
+        assert all(np.array_equal(La.results()[k], ref[k]) for k in ref)
+        La.free(); Lb.free()
+    finally:
+        a.close(); b.close()

@@ -50,14 +50,31 @@ def test_default_contract():
     sw = d["roofline_sweep"]
     assert sw["kernel"] == "layer_sweep_kernel" and sw["algorithmic_bytes_per_launch"] == 8.0 * 2400000 * 6 and sw["frac"] > 0.2
     assert "api_path" in d and d["api_path"]["ms_per_call"] > 0
+    # the headline cannot be read as 1e13 evaluated profiles per second: the direct / series split travels with it
+    pr = d["pairs"]
+    assert pr["pairs_direct"] + pr["pairs_series"] == pr["pairs"] and pr["evals_direct"] + pr["evals_series"] == pr["evals"]
+    assert pr["evals"] == d["config"]["evals_per_step"] and 0.8 < pr["evals_series"] / pr["evals"] < 0.95
+    assert d["value_direct_kernel"] > 1e12 and 0.2 < d["direct_frac"] < 1.0 and 0 < d["evals_direct_per_s"] < d["value"]
+    assert d["in_flight_leg"]["steps_in_flight"] == 2 and d["in_flight_leg"]["evals_per_s"] > 1e12       # N = 1: the other mode, for ratios
+    c = d["cpu_baseline"]
+    assert "SAME sample" in c["c_port_sample"] and "SAME sample" in c["vectorised_sample"]
+    assert "1/16" in c["at_survey_extent"]["what"] and c["at_survey_extent"]["c_port_value"] > 1e7
 
 
 def test_forced_single_rank_communicator_pipeline():
-    d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--workload", "C1"], {"PYRAD_FORCE_COMM": "1"})
+    # the default N > 1 path: one step in flight, one collective per step, overlapped with the next step (two buffer sets)
+    d0 = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--workload", "C1"], {"PYRAD_FORCE_COMM": "1"})
+    assert d0["config"]["steps_in_flight"] == 1 and d0["config"]["gather_batch"] == 1 and "2 buffer sets" in d0["config"]["allgather"]
+    bd = d0["sharded_step_breakdown"]       # what an N > 1 line carries: kernels without the gather, the gather alone, like-for-like legs
+    assert bd["kernels_only_ms_per_step"] > 0 and bd["allgather_alone_ms_per_step"] > 0 and len(bd["kernels_only_ms_by_rank"]) == 1
+    assert "allgather_alone_GBps_per_rank" in bd and bd["allgather_bytes_received_per_rank_per_step"] == 0.0      # one rank: nothing to receive
+    ll = bd["like_for_like"]
+    assert ll["in_stream_ms_per_step"] > 0 and ll["overlapped_ms_per_step"] > 0 and ll["step_latency_ms"] > 0
+    # opt-in: the gathers of 3 steps batched into one collective
+    d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--workload", "C1", "--gather-batch", "fit"],
+                  {"PYRAD_FORCE_COMM": "1"})
     assert d["config"]["allgather"].startswith("one collective per 3 steps") and d["value"] > 0       # 6 steps, two sets
     assert d["config"]["gather_batch"] == 3 and d["config"]["gather_verified"] is True
-    bd = d["sharded_step_breakdown"]       # what an N > 1 line carries: kernels without the gather, the gather alone
-    assert bd["kernels_only_ms_per_step"] > 0 and bd["allgather_alone_ms_per_step"] > 0 and len(bd["kernels_only_ms_by_rank"]) == 1
     d2 = run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--workload", "C1", "--no-overlap"],
                    {"PYRAD_FORCE_COMM": "1"})
     assert d2["config"]["allgather"] == "in-stream" and d2["kernel_ms_per_step"]["allgather"] > 0
@@ -86,7 +103,7 @@ def test_sharded_step_with_the_communicator_pipeline(shards):
     collective moves this rank's slot only).  Catches host-side mistakes in the N > 1 branch that the
     gloo tests (no HIP) and the --shard-of runs (no communicator) do not reach."""
     d = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-api-path", "--shard-of", "8,3",
-                   "--shards", shards], {"PYRAD_FORCE_COMM": "1"})
+                   "--shards", shards, "--in-flight", "2", "--gather-batch", "fit"], {"PYRAD_FORCE_COMM": "1"})
     assert d["config"]["allgather"].startswith("one collective per 3 steps") and d["value"] > 1e12
     assert d["config"]["gather_verified"] is True
     b = d["config"]["shard_bounds"]
@@ -96,14 +113,16 @@ def test_sharded_step_with_the_communicator_pipeline(shards):
     d2 = run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-api-path", "--shard-of", "8,3",
                     "--shards", shards, "--no-overlap", "--gather", "all"], {"PYRAD_FORCE_COMM": "1"})
     assert d2["config"]["allgather"] == "in-stream" and d2["kernel_ms_per_step"]["allgather"] > 0
-    assert d["config"]["steps_in_flight"] == 2 and d["config"]["gather_batch"] == 3      # a shard: two steps in flight, gathers batched
+    assert d["config"]["steps_in_flight"] == 2 and d["config"]["gather_batch"] == 3      # opt-in: two steps in flight, gathers batched
     d1 = run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-api-path", "--shard-of", "8,3",
-                    "--shards", shards, "--in-flight", "1", "--gather-batch", "1"], {"PYRAD_FORCE_COMM": "1"})
+                    "--shards", shards], {"PYRAD_FORCE_COMM": "1"})           # the default: one in flight, a collective per step
     assert d1["config"]["steps_in_flight"] == 1 and "2 buffer sets" in d1["config"]["allgather"] and d1["config"]["gather_batch"] == 1
     assert d1["config"]["evals_per_step"] == d["config"]["evals_per_step"]
+    ll = d1["sharded_step_breakdown"]["like_for_like"]
+    assert 0.03 < ll["in_stream_ms_per_step"] < 0.3 and 0.03 < ll["overlapped_ms_per_step"] < 0.3 and ll["step_latency_ms"] > 0.03
     # the column takes the same route
     d3 = run_bench(["--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--workload", "C5", "--shard-of", "8,3",
-                    "--shards", shards], {"PYRAD_FORCE_COMM": "1"})
+                    "--shards", shards, "--gather-batch", "fit"], {"PYRAD_FORCE_COMM": "1"})
     assert d3["value"] > 1e11 and "column" in d3["config"]["workload"] and d3["config"]["gather_verified"] is True
 
 

@@ -306,3 +306,89 @@ def test_lazy_protocol_random_sequences(pyrad, seed):
         k, t = pyrad.getAbsCoef(layer), pyrad.getTransmittance(layer)
         kf, tf = fresh(state)
         assert np.array_equal(k, kf) and np.array_equal(t, tf), (seed, step, op, state)
+
+
+def test_molecule_sum_is_refreshed_after_an_isotopologue_changes(pyrad):
+    """Molecule.createCrossSection re-sums its isotopologues on every call (cls:566-571): after an isotopologue
+    has been recomputed, or has had a host array assigned, the molecule's (and then the layer's) cross section
+    must be the sum of the CURRENT isotopologue cross sections, not a cached earlier one."""
+    z = load_golden("G6_composition")
+    source(co2=unpack_lines(z, "co2.lines"), co2_636=unpack_lines(z, "co2_636.lines"))
+    layer = pyrad.Layer(float(z["depth"]), int(z["T"]), float(z["P"]), 1000, 1040)
+    co2 = layer.addMolecule('co2', isotopeDepth=2, ppm=400)
+    first = np.array(pyrad.getCrossSection(co2))
+    assert rel_err(first, z["co2.xsec"]) <= RTOL
+    # recompute one isotopologue, then the molecule again: same physics, the sum must still be right
+    co2[1].createCrossSection()
+    co2.createCrossSection()
+    assert np.array_equal(np.array(co2.crossSection), first)
+    # a host array assigned to an isotopologue: the next molecule sum carries it
+    doubled = 2.0 * np.array(co2[1].crossSection)
+    co2[1].crossSection = doubled
+    co2.createCrossSection()
+    want = np.zeros_like(first) + np.array(co2[0].crossSection) + doubled
+    assert np.array_equal(np.array(co2.crossSection), want)
+    # ... and so does the layer's cross section, through the molecule's
+    layer.createCrossSection()
+    assert np.array_equal(np.array(layer.crossSection), np.zeros_like(first) + want)
+    # a user-assigned molecule cross section survives getters that do not recreate it
+    co2.crossSection = first
+    pyrad.getAbsCoef(layer)
+    assert co2.crossSection is first
+
+
+def test_g11_plot_and_plot_spectrum_like_the_reference(pyrad):
+    """pyrad.plot (cls:849-873) and pyrad.plotSpectrum (cls:876-944) as pyradInteractive calls them (ui:83, 373, 399):
+    curves, axis labels, titles and legend texts (band integrals rounded to two digits) against what the
+    reference's own functions drew under the Agg backend (G11)."""
+    import json
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    z = load_golden("G11_plots")
+    meta = json.loads(str(z["meta_json"]))
+    source(co2=unpack_lines(z, "lines"))
+    layer = pyrad.Layer(float(z["depth"]), int(z["T"]), float(z["P"]), float(z["range_min"]), float(z["range_max"]), name="C1")
+    co2 = layer.addMolecule('co2', ppm=int(z["conc_ppm"]))
+
+    def drawn():
+        ax = plt.gcf().axes[0]
+        out = dict(labels=[ln.get_label() for ln in ax.get_lines()], y=[np.asarray(ln.get_ydata()) for ln in ax.get_lines()],
+                   x=[np.asarray(ln.get_xdata()) for ln in ax.get_lines()],
+                   xlabel=ax.get_xlabel(), ylabel=ax.get_ylabel(), title=ax.get_title(), yscale=ax.get_yscale())
+        plt.close("all")
+        return out
+
+    # createTransmission (ui:390-402)
+    temps = [288, layer.T]
+    surface = layer.planck(temps[0])
+    assert rel_err(surface, z["surface"]) <= RTOL
+    pyrad.plotSpectrum(layer, objList=[layer, co2], surfaceSpectrum=surface, planckTemperatureList=temps)
+    got, want = drawn(), meta["transmission"]
+    assert (got["labels"], got["xlabel"], got["ylabel"], got["title"]) == (want["labels"], want["xlabel"], want["ylabel"], want["title"])
+    for i in range(4):
+        assert rel_err(got["y"][i], z["transmission.y%d" % i]) <= RTOL, i
+    assert np.array_equal(got["x"][-1], z["transmission.x"])
+    # the same numbers without a figure
+    spec = pyrad.spectrumCurves(layer, objList=[layer, co2], surfaceSpectrum=surface, planckTemperatureList=temps)
+    assert [c["label"] for c in spec["curves"]] == want["labels"] and spec["surfacePower"] > 0
+    # createPlanckCurves (ui:376-380)
+    for kind in ("wavenumber", "Hz", "wavelength"):
+        want = meta["planck." + kind]
+        lo, hi = want["range"]
+        pyrad.plotSpectrum(title="Planck spectrums", rangeMin=lo, rangeMax=hi, planckTemperatureList=[250, "300"], planckType=kind)
+        got = drawn()
+        assert (got["labels"], got["xlabel"], got["ylabel"], got["title"]) == (want["labels"], want["xlabel"], want["ylabel"], want["title"]), kind
+        for i in range(2):
+            assert rel_err(got["y"][i], z["planck.%s.y%d" % (kind, i)]) <= RTOL, (kind, i)
+        assert np.array_equal(got["x"][0], z["planck.%s.x" % kind])
+    # createPlot (ui:79-83): every plot type of the menu
+    for kind in ("transmittance", "absorption coefficient", "cross section", "absorbance", "optical depth", "line survey"):
+        want = meta["plot." + kind]
+        pyrad.plot(kind, "golden %s" % kind, [layer, co2])
+        got = drawn()
+        assert all(got[k] == want[k] for k in ("labels", "xlabel", "ylabel", "title", "yscale")), kind
+        for i in range(2):
+            key = "plot.%s.y%d" % (kind, i)
+            if key in z.files:
+                assert rel_err(got["y"][i], z[key]) <= (0.0 if kind == "line survey" else RTOL), key

@@ -113,3 +113,32 @@ def test_shard_bounds_cover_grid():
                 assert first == min(r * s, n) and 0 <= count <= s
                 covered += count
             assert covered == n and S * world >= n
+
+
+def test_pair_split_matches_a_brute_force_classification():
+    """dist.pair_split (bench.py's direct / series bookkeeping): classes of (line, span of 256 points) pairs as
+    lbl_api.hip's group_schedule tabulates them, against a loop over spans and lines; evals add up to eval_count."""
+    import numpy as np
+    from pyrad_amd import dist
+    rng = np.random.default_rng(5)
+    for H, n, first, count in ((4998, 9000, 0, None), (700, 5000, 1024, 2048), (300, 4000, 0, None), (1500, 3000, 256, 1500)):
+        c = np.sort(rng.integers(-H - 50, n + H + 50, 400))
+        got = dist.pair_split(c, H, n, first, count)
+        cnt = n - first if count is None else count
+        pairs = far = far_evals = evals = 0
+        for lo in range(first, first + cnt, 256):
+            hi = min(lo + 256, first + cnt) - 1
+            xc2 = 2 * lo + 255                                  # twice the span centre lo + 127.5
+            for ci in c:
+                if ci + H < lo or ci - H > hi:
+                    continue
+                pairs += 1
+                covers = ci - H <= lo and ci + H >= hi
+                # far: centre index <= lo + 127 - 512 or >= lo + 128 + 512 (lbl_kernels.hip: FF_FAR half-spans of 128)
+                if H >= 640 and covers and (ci <= lo + 127 - 512 or ci >= lo + 128 + 512):
+                    far += 1
+                    far_evals += hi - lo + 1
+        for ci in c:
+            evals += max(min(ci + H, first + cnt - 1) - max(ci - H, first) + 1, 0)
+        assert got["pairs"] == pairs and got["pairs_series"] == far and got["pairs_direct"] == pairs - far, (H, n)
+        assert got["evals"] == evals and got["evals_series"] == far_evals and got["evals_direct"] == evals - far_evals
