@@ -127,7 +127,7 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "accum_skew"             1 (default) line lists whose window has no far line (narrower than 640 points) go
  *                            through the skewed-range kernel when they fill the chip | 0 the span kernel
  *                            (all-direct instantiation) | 2 EVERY job through the skewed-range kernel (parity tests)
- *   "accum_skew_points_per_lane"  1 | 2 | 4 (default) | 8
+ *   "accum_skew_points_per_lane"  1 | 2 | 4 | 8 (default)
  *   "debug_ablate"           timing experiments only (results are wrong): bits switch off parts of kernels
  *   "layer_step_fused"       1 (default) lbl_layer_step_dev folds the sweep of a single-line-list layer into the
  *                            accumulate kernel | 0 always accumulate launch + sweep launch (bit-identical; A/B)

@@ -124,6 +124,7 @@ struct SweepArgs {
     double term_conc[kMaxIso];      // volume fraction of the term's molecule
     int32_t term_flags[kMaxIso];
     int32_t n_iso, n_mol;
+    int32_t variant, pad;           // 1: streaming (non-temporal) loads and stores (0 with lbl_set_option debug_ablate bit 64, for A/B)
     double P, T, depth;
     double rT, r_surface_T;         // RN(1/T), RN(1/surface_T) for div_uniform (0: plain divide)
     double start, stop, step;       // xAxis = linspace(start, stop, n)

@@ -805,7 +805,7 @@ def test_skew_kernel_random_cells(ctx, orc, seed):
             assert np.array_equal(xs, xs2)                       # bit-identical rerun
     finally:
         ctx.set_option("accum_skew", 1)
-        ctx.set_option("accum_skew_points_per_lane", 4)
+        ctx.set_option("accum_skew_points_per_lane", 8)
 
 
 def test_skew_kernel_resident_column_matches_span_kernel(ctx, orc):
