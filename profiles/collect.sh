@@ -6,7 +6,7 @@
 # Counters are collected in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass,
 # MI355X_MICROARCH.md "rocprofv3 PMC slots") and never together with the trace domains.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 WORKLOAD=${2:-C3}
 SHARD=$3          # optional "G,r": shard r of a G-way sharding (what a rank of a G-GPU run computes); label <workload>s<G>
 R=$GRAFT_REPO_ROOT

@@ -1456,7 +1456,7 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
     void* d_args = nullptr;
     if ((rc = device_args(ctx, a, sizeof(ColumnStepArgs), &d_args))) return rc;
     hipEvent_t ev = prof_begin(ctx, PROF_COLUMN);
-    launch_column_step((const ColumnStepArgs*)d_args, count, ctx->stream);
+    launch_column_step((const ColumnStepArgs*)d_args, first, count, ctx->stream);
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;

@@ -1864,61 +1864,82 @@ __global__ __launch_bounds__(256) void column_sweep_kernel(const ColumnArgs* __r
 // term of a molecule and of a layer).  NB terms are loaded at once, independent of one another; everything
 // that depends on the grid point only (2E8 h c^2 n^3 and 100 h c n / k of pyradPlanck.py:41-42) is computed
 // once per point, not once per layer.
-__global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* __restrict__ Ap) {
+template <int NP>
+__global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* __restrict__ Ap, long long first, long long count) {
 #pragma clang fp contract(off)
+    // NP grid points per thread (2: 16-byte loads; the host gives this instantiation an even first point and an even count)
     constexpr int NB = 6;
+    typedef double vec __attribute__((ext_vector_type(NP)));
+    typedef const vec __attribute__((address_space(1)))* GlobalVec;
     const ColumnStepArgs& A = *Ap;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    const long long jend = A.first + A.count;
+    const long long stride = (long long)gridDim.x * blockDim.x * NP;
+    const long long jend = first + count;
     const int n_terms = A.n_terms;
     const int n_full = n_terms - n_terms % NB;
     const bool layer_arrays = A.layer_arrays != 0;          // (streaming / non-temporal loads measured 18 % SLOWER here: 536 vs 455 us)
-    for (long long j = A.first + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < jend; j += stride) {
-        const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
-        double pa_n, pb_n;
-        planck_point(nu, A.pa, A.pb, pa_n, pb_n);
-        double I = A.I_in ? A.I_in[j] : planck_at(pa_n, pb_n, A.surface_T, A.r_surface_T);
-        double kk = 0.0, xs = 0.0;
+    auto load = [&](const double* p, long long j) {
+        vec v;
+        if (NP == 1) v[0] = load_global_f64(p, j);
+        else v = *(GlobalVec)(unsigned long long)(p + j);
+        return v;
+    };
+    for (long long j = first + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * NP; j < jend; j += stride) {
+        double pa_n[NP], pb_n[NP], I[NP], kk[NP], xs[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const double nu = linspace_at(j + p, A.n, A.start, A.stop, A.step);
+            planck_point(nu, A.pa, A.pb, pa_n[p], pb_n[p]);
+            I[p] = A.I_in ? A.I_in[j + p] : planck_at(pa_n[p], pb_n[p], A.surface_T, A.r_surface_T);
+            kk[p] = 0.0; xs[p] = 0.0;
+        }
         int l = 0;
-        auto term = [&](int t, double v) {
+        auto term = [&](int t, vec v) {
             const int f = A.term_flags[t];
-            xs += v;
-            if (A.ablate & 16) { I += v; return; }                 // (diagnostics: memory traffic only)
-            if (f & TERM_LAST_MOL) { kk += abs_coef_term(xs, A.term_conc[t], A.term_P[t], A.term_T[t], A.term_rT[t]); xs = 0.0; }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) xs[p] += v[p];
+            if (A.ablate & 16) { I[0] += v[0]; return; }           // (diagnostics: memory traffic only)
+            if (f & TERM_LAST_MOL) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { kk[p] += abs_coef_term(xs[p], A.term_conc[t], A.term_P[t], A.term_T[t], A.term_rT[t]); xs[p] = 0.0; }
+            }
             if (f & TERM_LAST_LAYER) {
-                const double tr = exp(-kk * A.term_depth[t]);
-                if (layer_arrays) {
-                    if (A.abs_coef[l]) A.abs_coef[l][j] = kk;
-                    if (A.trans[l]) A.trans[l][j] = tr;
-                    ++l;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const double tr = exp(-kk[p] * A.term_depth[t]);
+                    if (layer_arrays) {
+                        if (A.abs_coef[l]) A.abs_coef[l][j + p] = kk[p];
+                        if (A.trans[l]) A.trans[l][j + p] = tr;
+                    }
+                    const double B = planck_at(pa_n[p], pb_n[p], A.term_T[t], A.term_rT[t]);
+                    const double transmitted = tr * I[p];
+                    const double emitted = (1.0 - tr) * B;
+                    I[p] = transmitted + emitted;
+                    kk[p] = 0.0;
                 }
-                const double B = planck_at(pa_n, pb_n, A.term_T[t], A.term_rT[t]);
-                const double transmitted = tr * I;
-                const double emitted = (1.0 - tr) * B;
-                I = transmitted + emitted;
-                kk = 0.0;
+                if (layer_arrays) ++l;
             }
         };
         // two batches of NB loads in flight: the next batch is requested before the current one is consumed
-        double cur[NB], nxt[NB];
+        vec cur[NB], nxt[NB];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) { cur[u] = 0.0; nxt[u] = 0.0; }
+        for (int u = 0; u < NB; ++u) { cur[u] = (vec)(0.0); nxt[u] = (vec)(0.0); }
         if (n_full > 0) {
 #pragma unroll
-            for (int u = 0; u < NB; ++u) cur[u] = (A.ablate & 32) ? 1e-22 * (double)(j & 7) : load_global_f64(A.xsec[u], j);
+            for (int u = 0; u < NB; ++u) cur[u] = (A.ablate & 32) ? (vec)(1e-22 * (double)(j & 7)) : load(A.xsec[u], j);
         }
         for (int t0 = 0; t0 < n_full; t0 += NB) {
             if (t0 + NB < n_full) {
 #pragma unroll
-                for (int u = 0; u < NB; ++u) nxt[u] = (A.ablate & 32) ? 1e-22 * (double)(j & 7) : load_global_f64(A.xsec[t0 + NB + u], j);
+                for (int u = 0; u < NB; ++u) nxt[u] = (A.ablate & 32) ? (vec)(1e-22 * (double)(j & 7)) : load(A.xsec[t0 + NB + u], j);
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u) term(t0 + u, cur[u]);
 #pragma unroll
             for (int u = 0; u < NB; ++u) cur[u] = nxt[u];
         }
-        for (int t = n_full; t < n_terms; ++t) term(t, load_global_f64(A.xsec[t], j));
-        A.I_out[j] = I;
+        for (int t = n_full; t < n_terms; ++t) term(t, load(A.xsec[t], j));
+#pragma unroll
+        for (int p = 0; p < NP; ++p) A.I_out[j + p] = I[p];
     }
 }
 
@@ -2102,9 +2123,16 @@ void launch_layer_sweep(const SweepArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL(layer_sweep_kernel<false>, dim3(sweep_blocks(a.count)), dim3(256), 0, s, a);
 }
 
-void launch_column_step(const ColumnStepArgs* d_args, long long count, hipStream_t s) {
+void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(column_step_kernel, dim3(sweep_blocks(count)), dim3(256), 0, s, d_args);
+    static const bool pairs = !getenv("LBL_DIAG_COLUMN_NP1");
+    if (pairs && (first & 1) == 0 && count >= 2) {     // two points per thread with 16-byte loads; an odd last point by itself
+        const long long even = count & ~1LL;
+        hipLaunchKernelGGL(column_step_kernel<2>, dim3(sweep_blocks(even / 2)), dim3(256), 0, s, d_args, first, even);
+        if (count & 1) hipLaunchKernelGGL(column_step_kernel<1>, dim3(1), dim3(64), 0, s, d_args, first + even, 1LL);
+        return;
+    }
+    hipLaunchKernelGGL(column_step_kernel<1>, dim3(sweep_blocks(count)), dim3(256), 0, s, d_args, first, count);
 }
 
 void launch_column_sweep(const ColumnArgs* d_args, long long count, hipStream_t s) {

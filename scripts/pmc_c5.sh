@@ -9,7 +9,7 @@ for opts in "$@"; do
   i=$((i+1))
   SET=""
   for o in $opts; do SET="$SET --set $o"; done
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/bench.py --workload ${WORKLOAD:-C5} --steps 3 --warmup 1 --precondition-seconds 0 --no-cpu-baseline --no-api-path --no-direct-pass $SET > $OUT/p$i.json 2> $OUT/p$i.err || exit 1
+  rm -rf $OUT/p$i; rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/bench.py --workload ${WORKLOAD:-C5} --steps 3 --warmup 1 --precondition-seconds 0 --no-cpu-baseline --no-api-path --no-direct-pass $SET > $OUT/p$i.json 2> $OUT/p$i.err || exit 1
   echo "== $opts"
   python3 - $OUT/p$i <<'PY'
 import csv, glob, sys, collections

@@ -9,7 +9,7 @@ for opts in "$@"; do
   i=$((i+1))
   SET=""
   for o in $opts; do SET="$SET --set $o"; done
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t$i -- python3 $R/bench.py --workload ${WORKLOAD:-C5} --steps 10 --warmup 2 --no-cpu-baseline --no-api-path --no-direct-pass $SET > $OUT/t$i.json 2> $OUT/t$i.err || exit 1
+  rm -rf $OUT/t$i; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t$i -- python3 $R/bench.py --workload ${WORKLOAD:-C5} --steps 10 --warmup 2 --no-cpu-baseline --no-api-path --no-direct-pass $SET > $OUT/t$i.json 2> $OUT/t$i.err || exit 1
   echo "== $opts"
   python3 - $OUT/t$i <<'PY'
 import csv, glob, sys
