@@ -1004,7 +1004,12 @@ def main():
                                "frac": (balg_sw / t_sw / 1e9 / HBM_PEAK_GBS) if t_sw > 0 else 0.0,
                                "traffic": pmc["hbm"].get(sweep_kernel),
                                "traffic_stale": (pmc["stale"] if pmc["hbm"].get(sweep_kernel) is not None else None),
-                               "algorithmic_bytes_per_launch": balg_sw, "avg_launch_ms": t_sw * 1e3, "launches": n_sw},
+                               "algorithmic_bytes_per_launch": balg_sw, "avg_launch_ms": t_sw * 1e3, "launches": n_sw,
+                               # a pair of HIP event records costs the stream a few microseconds, which shows on a 25 us
+                               # kernel: the committed rocprofv3 kernel trace of this very command is the cleaner clock
+                               "avg_launch_ms_rocprofv3": (pmc["avg_us"].get(sweep_kernel) or 0.0) / 1e3 or None,
+                               "frac_rocprofv3": (balg_sw / (pmc["avg_us"][sweep_kernel] * 1e-6) / 1e9 / HBM_PEAK_GBS)
+                                                 if pmc["avg_us"].get(sweep_kernel) else None},
             "kernel_ms_per_step": {"line_prep": ms_prep / args.steps, "xsec_accumulate": ms_acc / max(n_sampled, 1),
                                    ("column_step" if is_column else "layer_sweep"): ms_sw / args.steps,
                                    "allgather": ms_ag / args.steps},

@@ -3,7 +3,9 @@
 
 Tolerances: the reference is fp64 and so is the device path.  north_star asks for <= 1e-6
 relative on the absorption coefficient; the device differs from NumPy only by summation
-association and libm-vs-ocml last-bit effects, so these tests hold it to RTOL = 1e-11.
+association and libm-vs-ocml last-bit effects.  Whole-spectrum comparisons against the oracle use the
+per-point bound of conftest.point_tolerance (2e-12 + the nu -> 0 amplification of the stimulated-emission
+factor, stated in ulps); golden comparisons of cells away from 0 cm^-1 keep the global RTOL = 1e-11.
 Centre indices (integer work) must be bit-exact.
 """
 import numpy as np
@@ -516,7 +518,13 @@ def test_random_cells_against_oracle(ctx, orc, seed):
                                        synthetic.q_value(species, T), sp["q296"], g)
     assert tuple(counts) == tuple(rc)
     assert xs.shape == ref.shape
-    check(xs, ref)
+    # per-point bound: 2e-12 + the nu -> 0 amplification of the stimulated-emission factor (conftest.point_tolerance),
+    # not a global figure that a cell starting at 0 cm^-1 can exceed
+    from conftest import point_tolerance, rel_err_points
+    tol = point_tolerance(orc.x_axis(rmin, rmax, base), T, g["dfc"])
+    floor = float(np.max(np.abs(ref))) * FLOOR_REL if ref.size else 0.0
+    e = rel_err_points(xs, ref, floor)
+    assert np.all(e <= tol), (float(e.max()), int(np.argmax(e / tol)))
 
 
 def test_far_field_series_cases(ctx, orc):
