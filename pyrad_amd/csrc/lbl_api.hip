@@ -89,6 +89,7 @@ struct lbl_ctx {
                              // skewed-range kernel when they fill the chip; 0 the all-direct span kernel; 2 EVERY job through the
                              // skewed-range kernel whatever its window and the grid size (parity tests)
     int skew_R = 8;          // points per lane of the skewed-range kernel (8: 118 VGPRs, 4 waves per SIMD; measured 7 % faster than 4 on the column)
+    int far_min_H = 0;       // windows below this many points go to the skewed-range kernel even if they have far lines (0: the far-field kernel's own limit, 640)
     int ablate = 0;          // diagnostics: AccumJob.ablate
     lbl_ctx* chain_pred = nullptr;   // lbl_ctx_chain_accumulate: accumulate kernels wait for this context's
     hipEvent_t accum_done = nullptr; // recorded after this context's accumulate launches
@@ -440,6 +441,9 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) try {
         if (!(value == 1 || value == 2 || value == 4 || value == 8))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_skew_points_per_lane must be 1, 2, 4 or 8");
         ctx->skew_R = value;
+    } else if (!strcmp(key, "accum_far_min_window")) {
+        if (value < 0) return fail(ctx, LBL_ERR_BAD_ARG, "accum_far_min_window must be >= 0");
+        ctx->far_min_H = value;
     } else if (!strcmp(key, "debug_ablate")) {
         ctx->ablate = value;        // timing experiments only: results are wrong when non-zero
     } else if (!strcmp(key, "layer_step_fused")) {
@@ -926,6 +930,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         if (ctx->accum_variant != 5) return 0;
         const long long H = std::max<long long>(grid[j].window - 2, 0);
         const long long r = ctx->accum_R ? ctx->accum_R : r_cap(j);
+        if (ctx->skew && H < ctx->far_min_H) return 0;
         return H >= 32 * r * (far_half_spans + 1) ? 1 : 0;
     };
     // Narrow windows (no far line on any span) go to the skewed-range kernel, all in ONE group whatever their
