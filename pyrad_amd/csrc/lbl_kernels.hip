@@ -24,7 +24,11 @@
 //   3    xsec_accumulate_lds_kernel  records streamed through wave-private LDS, every pair direct
 //   4    ..._balanced_kernel         3 with an exactly balanced partition of (span, line) pairs
 //   5    xsec_accumulate_lds_kernel<.., FF = true>  (default) 3 + far-field series for distant
-//        Lorentz lines; optionally the layer sweep of a single-line-list layer in the output stage
+//        Lorentz lines; optionally the layer sweep of a single-line-list layer in the output stage;
+//        round 3: its edge lines (support ends inside the span) take the skewed walk (skew_edges), and
+//        line lists whose window is too narrow for any far line (< 640 points: the upper layers of a
+//        column) run xsec_accumulate_skew_kernel, in which every LANE walks the lines that reach its
+//        own points (lbl_set_option "accum_skew")
 //
 // K2 is fp64-VALU bound, not HBM bound: its compulsory traffic is 56 B per line and 8 B per grid
 // point against 5 fp64 instructions per directly evaluated (line, grid point) pair.
