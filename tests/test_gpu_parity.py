@@ -842,6 +842,16 @@ def test_skew_kernel_resident_column_matches_span_kernel(ctx, orc):
             col.free()
         finally:
             ctx.set_option("accum_skew", 1)
+    # the routing threshold between the two kernels moved up: the 738-point window takes the walk as well
+    ctx.set_option("accum_far_min_window", 1000)
+    try:
+        col = engine.ResidentColumn(ctx, cfgs, 288.0)
+        col.enqueue(layer_arrays=True)
+        moved = col.results()
+        col.free()
+    finally:
+        ctx.set_option("accum_far_min_window", 0)
+    assert rel_err(moved["toa"], res[0]["toa"]) <= 1e-13 and not np.array_equal(moved["transmittance"][2], res[1]["transmittance"][2])
     assert rel_err(res[1]["toa"], res[0]["toa"]) <= 1e-13
     for a, b in zip(res[1]["transmittance"], res[0]["transmittance"]):
         # transmittance = exp(-k depth): a relative difference e of k is a relative difference e * (-ln tr) of tr
