@@ -1790,50 +1790,70 @@ __device__ __forceinline__ double load_global_f64(const double* p, long long j) 
     return ((GlobalF64)(unsigned long long)p)[j];
 }
 
-template <bool NT>
+template <bool NT, int NP>
 __global__ __launch_bounds__(256) void layer_sweep_kernel(const SweepArgs A) {
 #pragma clang fp contract(off)
+    // NP grid points per thread (2: 16-byte accesses; the host gives this instantiation an even first point and count)
     constexpr int NB = 4;
-    auto ld = [&](const double* p, long long j) { return NT ? __builtin_nontemporal_load(p + j) : load_global_f64(p, j); };
-    auto st = [&](double* p, long long j, double v) { if (NT) __builtin_nontemporal_store(v, p + j); else p[j] = v; };
-    const long long stride = (long long)gridDim.x * blockDim.x;
+    typedef double vec __attribute__((ext_vector_type(NP)));
+    auto ld = [&](const double* p, long long j) {
+        vec v;
+        if (NP == 1) v[0] = NT ? __builtin_nontemporal_load(p + j) : load_global_f64(p, j);
+        else v = NT ? __builtin_nontemporal_load(reinterpret_cast<const vec*>(p + j)) : *reinterpret_cast<const vec*>(p + j);
+        return v;
+    };
+    auto st = [&](double* p, long long j, vec v) {
+        if (NP == 1) { if (NT) __builtin_nontemporal_store(v[0], p + j); else p[j] = v[0]; }
+        else { if (NT) __builtin_nontemporal_store(v, reinterpret_cast<vec*>(p + j)); else *reinterpret_cast<vec*>(p + j) = v; }
+    };
+    const long long stride = (long long)gridDim.x * blockDim.x * NP;
     const long long jend = A.first + A.count;
     const int n_full = A.n_iso - A.n_iso % NB;
-    for (long long j = A.first + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < jend; j += stride) {
+    for (long long j = A.first + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * NP; j < jend; j += stride) {
         // Layer.absCoef (pyradClasses.py:707-712): zeros + sum over molecules of
         // Molecule.absCoef = crossSection * concentration * P / 1E4 / k / T (pyradClasses.py:583),
         // Molecule.crossSection = zeros + sum over isotopologues (pyradClasses.py:566-571)
-        double kk = 0.0, xs = 0.0;
-        auto term = [&](int t, double v) {
+        vec kk = (vec)(0.0), xs = (vec)(0.0);
+        auto term = [&](int t, vec v) {
             xs += v;
-            if (A.term_flags[t] & TERM_LAST_MOL) { kk += abs_coef_term(xs, A.term_conc[t], A.P, A.T, A.rT); xs = 0.0; }
+            if (A.term_flags[t] & TERM_LAST_MOL) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { kk[p] += abs_coef_term(xs[p], A.term_conc[t], A.P, A.T, A.rT); xs[p] = 0.0; }
+            }
         };
         for (int t0 = 0; t0 < n_full; t0 += NB) {
-            double v[NB];
+            vec v[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) v[u] = ld(A.xsec[t0 + u], j);
 #pragma unroll
             for (int u = 0; u < NB; ++u) term(t0 + u, v[u]);
         }
         {
-            double v[NB];
+            vec v[NB];
 #pragma unroll
-            for (int u = 0; u < NB - 1; ++u) v[u] = n_full + u < A.n_iso ? ld(A.xsec[n_full + u], j) : 0.0;
+            for (int u = 0; u < NB - 1; ++u) v[u] = n_full + u < A.n_iso ? ld(A.xsec[n_full + u], j) : (vec)(0.0);
 #pragma unroll
             for (int u = 0; u < NB - 1; ++u) if (n_full + u < A.n_iso) term(n_full + u, v[u]);
         }
         if (A.abs_coef) st(A.abs_coef, j, kk);
-        const double tr = exp(-kk * A.depth);                               // pyradClasses.py:716
+        vec tr;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) tr[p] = exp(-kk[p] * A.depth);            // pyradClasses.py:716
         if (A.trans) st(A.trans, j, tr);
         if (A.I_out) {
-            const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
-            double pa_n, pb_n;
-            planck_point(nu, A.pa, A.pb, pa_n, pb_n);
-            const double B = planck_at(pa_n, pb_n, A.T, A.rT);                  // Layer.planck(self.T)
-            const double Iin = A.I_in ? A.I_in[j] : planck_at(pa_n, pb_n, A.surface_T, A.r_surface_T);
-            const double transmitted = tr * Iin;                            // pyradClasses.py:785
-            const double emitted = (1.0 - tr) * B;                          // pyradClasses.py:786
-            st(A.I_out, j, transmitted + emitted);
+            vec out;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const double nu = linspace_at(j + p, A.n, A.start, A.stop, A.step);
+                double pa_n, pb_n;
+                planck_point(nu, A.pa, A.pb, pa_n, pb_n);
+                const double B = planck_at(pa_n, pb_n, A.T, A.rT);              // Layer.planck(self.T)
+                const double Iin = A.I_in ? A.I_in[j + p] : planck_at(pa_n, pb_n, A.surface_T, A.r_surface_T);
+                const double transmitted = tr[p] * Iin;                     // pyradClasses.py:785
+                const double emitted = (1.0 - tr[p]) * B;                   // pyradClasses.py:786
+                out[p] = transmitted + emitted;
+            }
+            st(A.I_out, j, out);
         }
     }
 }
@@ -2121,10 +2141,27 @@ static int sweep_blocks(long long n) {       // (one point per thread on a large
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+template <bool NT>
+static void launch_layer_sweep_nt(const SweepArgs& a, hipStream_t s) {
+    static const bool pairs = !getenv("LBL_DIAG_SWEEP_NP1");
+    if (pairs && (a.first & 1) == 0 && a.count >= 2) {      // two points per thread with 16-byte accesses; an odd last point by itself
+        SweepArgs m = a;
+        m.count = a.count & ~1LL;
+        hipLaunchKernelGGL((layer_sweep_kernel<NT, 2>), dim3(sweep_blocks(m.count / 2)), dim3(256), 0, s, m);
+        if (a.count & 1) {
+            SweepArgs t = a;
+            t.first = a.first + m.count; t.count = 1;
+            hipLaunchKernelGGL((layer_sweep_kernel<NT, 1>), dim3(1), dim3(64), 0, s, t);
+        }
+        return;
+    }
+    hipLaunchKernelGGL((layer_sweep_kernel<NT, 1>), dim3(sweep_blocks(a.count)), dim3(256), 0, s, a);
+}
+
 void launch_layer_sweep(const SweepArgs& a, hipStream_t s) {
     if (a.count <= 0) return;
-    if (a.variant) hipLaunchKernelGGL(layer_sweep_kernel<true>, dim3(sweep_blocks(a.count)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(layer_sweep_kernel<false>, dim3(sweep_blocks(a.count)), dim3(256), 0, s, a);
+    if (a.variant) launch_layer_sweep_nt<true>(a, s);
+    else launch_layer_sweep_nt<false>(a, s);
 }
 
 void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s) {
