@@ -205,3 +205,20 @@ def test_batched_gather_layout_two_simulated_ranks():
         assert ev[0] == ("fence", 4) and [e for e in ev if e[0] == "gather"] == [("gather", 4), ("gather", 5), ("gather", 4)]
         assert [e for e in ev if e[0] == "fence"] == [("fence", 4), ("fence", 5), ("fence", 4)]
     assert not net.calls                                              # every collective was matched by every rank
+
+
+def test_cpu_baseline_legs_share_one_sample():
+    """bench.cpu_baseline: the Python, vectorised and C legs are timed on the same seeded lines; C1 also at
+    the whole workload, a multi-list cell at a seeded 1/16 of every list; eval counts are exact."""
+    from pyrad_amd import synthetic
+    cfg = synthetic.config_c1(n_lines=600)
+    r = bench.cpu_baseline([dict(cfg, raw_molecules=cfg["molecules"])], "C1", seconds_target=0.3)
+    assert r["kind"] == "port" and r["cores"] == 1 and r["value"] > 1e5
+    assert "SAME sample" in r["c_port_sample"] and "SAME sample" in r["vectorised_sample"]
+    ext = r["at_survey_extent"]
+    assert ext["what"] == "the WHOLE workload" and ext["lines"] == 600 and ext["c_port_value"] > r["value"]
+    # a three-list cell: the 1/16 extent
+    c3 = synthetic.config_c3(n_lines=1600, range_min=600, range_max=640)
+    r3 = bench.cpu_baseline([dict(c3, raw_molecules=c3["molecules"])], "C3", seconds_target=0.3)
+    assert "1/16" in r3["at_survey_extent"]["what"] and r3["at_survey_extent"]["lines"] == 3 * 100
+    assert r3["at_survey_extent"]["whole_workload_seconds_c_port"] > 0
