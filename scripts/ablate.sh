@@ -27,11 +27,9 @@ elif what == "nofar":
 elif what == "noedge":
     s = s.replace(anchor, "        iA = iB; iD = iC;\n" + anchor)
 elif what == "nonear":
-    s = s.replace(anchor, anchor + "\n        const int keepF1 = iF1; iF2 = keepF1;  /* near lines dropped (far-right range starts later: unchanged count) */")
-    s = s.replace("const int keepF1 = iF1; iF2 = keepF1;", "const int nearF2 = iF2; (void)nearF2;")
-    line = "            accumulate_lines<R, true>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);"
-    assert line in s
-    s = s.replace(line, "            /* near lines dropped */")
+    line = "accumulate_lines<R, 1>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);"
+    assert s.count(line) == 2
+    s = s.replace(line, "/* near lines dropped */;")
 open(p, "w").write(s)
 PY
   make -C $T/pyrad_amd/csrc -j4 > $T/build.log 2>&1 || { grep -E "error" $T/build.log; exit 1; }
