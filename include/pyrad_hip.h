@@ -128,6 +128,8 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *                            through the skewed-range kernel when they fill the chip | 0 the span kernel
  *                            (all-direct instantiation) | 2 EVERY job through the skewed-range kernel (parity tests)
  *   "accum_skew_points_per_lane"  1 | 2 | 4 | 8 (default)
+ *   "accum_far_min_window"   windows below this many points take the skewed-range kernel even where the far-field
+ *                            kernel could run them (0, the default: its own limit, 640; measured flat up to 1000)
  *   "debug_ablate"           timing experiments only (results are wrong): bits switch off parts of kernels
  *   "layer_step_fused"       1 (default) lbl_layer_step_dev folds the sweep of a single-line-list layer into the
  *                            accumulate kernel | 0 always accumulate launch + sweep launch (bit-identical; A/B)
