@@ -172,6 +172,12 @@ int lbl_buffer_devptr(lbl_buffer* buf, void** devptr);                 /* for RC
 int lbl_lines_create(lbl_ctx* ctx, const double* nu, const double* sw, const double* elower,
                      const double* gamma_air, const double* gamma_self, const double* n_air,
                      const double* delta_air, int64_t n_lines, lbl_lines** out);
+/* A view of `count` consecutive lines of a resident list, starting at line `first` (nu is sorted, so a wavenumber
+ * window of a list - Layer.effectiveRangeMin/Max of pyradClasses.py:656-657, or the halo of a grid shard - is such a
+ * range): no copy, the view shares the parent's device arrays.  A 30-layer column keeps ONE copy of every molecule's
+ * lines and 30 views of it, and the line-prep kernels of all layers read the same addresses (they stay in cache).
+ * A view is destroyed with lbl_lines_destroy; a list with live views cannot be destroyed (LBL_ERR_STATE). */
+int lbl_lines_view(lbl_lines* parent, int64_t first, int64_t count, lbl_lines** out);
 int lbl_lines_destroy(lbl_lines* lines);
 int lbl_lines_count(const lbl_lines* lines, int64_t* n);
 

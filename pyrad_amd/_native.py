@@ -58,6 +58,7 @@ SIGNATURES = {
     "lbl_sync": (C.c_int, [_P]),
     "lbl_ctx_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "lbl_ctx_chain_accumulate": (C.c_int, [_P, _P]),
+    "lbl_lines_view": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(_P)]),
     "lbl_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "lbl_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "lbl_profile_enable": (C.c_int, [_P, C.c_int]),
@@ -529,6 +530,17 @@ class Lines:
         ctx.check(ctx.lib.lbl_lines_create(ctx.h, *[_ptr(a) for a in arrs], self.n, C.byref(h)))
         self.h = h
         ctx._children.append(self)
+
+    def view(self, first: int, count: int) -> "Lines":
+        """``count`` consecutive lines from line ``first`` on (sorted order), sharing this list's device arrays
+        (lbl_lines_view).  Free the views before the list."""
+        v = Lines.__new__(Lines)
+        v.ctx, v.n = self.ctx, int(count)
+        h = _P()
+        self.ctx.check(self.ctx.lib.lbl_lines_view(self.h, int(first), int(count), C.byref(h)))
+        v.h = h
+        self.ctx._children.append(v)
+        return v
 
     def free(self):
         if self.h:

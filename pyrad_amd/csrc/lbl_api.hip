@@ -109,11 +109,14 @@ struct lbl_buffer {
 
 struct lbl_lines {
     lbl_ctx* ctx;
-    double* d;        // 7 arrays of n: nu, sw, elower, gamma_air, gamma_self, n_air, delta_air
+    double* d;        // 7 arrays of `stride` doubles: nu, sw, elower, gamma_air, gamma_self, n_air, delta_air (a view: offset into its root's)
     int64_t n;
     std::vector<double> host_nu;   // for scheduling only: longest-first tile order (never used for results)
     uint64_t serial;               // identity for the schedule cache
-    const double* field(int k) const { return d + (size_t)k * (size_t)n; }
+    int64_t stride = 0;            // distance between the field arrays: the OWNING list's line count
+    lbl_lines* root = nullptr;     // a view (lbl_lines_view): the list that owns the device arrays
+    int views = 0;                 // live views of this (owning) list
+    const double* field(int k) const { return d + (size_t)k * (size_t)stride; }
 };
 
 static thread_local std::string g_err;
@@ -577,6 +580,7 @@ extern "C" int lbl_lines_create(lbl_ctx* ctx, const double* nu, const double* sw
     lbl_lines* L = new (std::nothrow) lbl_lines{ctx, nullptr, n_lines, {}, 0};
     if (!L) return fail(ctx, LBL_ERR_OOM, "host allocation failed");
     L->host_nu.swap(host_nu);
+    L->stride = n_lines;
     double* d = nullptr;
     {
         hipError_t em = hipMalloc((void**)&d, (size_t)std::max<int64_t>(n_lines, 1) * 7 * sizeof(double));
@@ -596,10 +600,37 @@ extern "C" int lbl_lines_create(lbl_ctx* ctx, const double* nu, const double* sw
     return LBL_OK;
 } LBL_GUARD_END(ctx)
 
+extern "C" int lbl_lines_view(lbl_lines* parent, int64_t first, int64_t count, lbl_lines** out) try {
+    if (!parent || !out) return fail(parent ? parent->ctx : nullptr, LBL_ERR_BAD_ARG, "NULL argument");
+    lbl_ctx* ctx = parent->ctx;
+    *out = nullptr;
+    if (first < 0 || count < 0 || first + count > parent->n) return fail(ctx, LBL_ERR_BAD_ARG, "view outside the line list");
+    lbl_lines* root = parent->root ? parent->root : parent;
+    std::vector<double> host_nu(parent->host_nu.begin() + first, parent->host_nu.begin() + first + count);
+    lbl_lines* V = new (std::nothrow) lbl_lines{ctx, parent->d + first, count, {}, 0};
+    if (!V) return fail(ctx, LBL_ERR_OOM, "host allocation failed");
+    V->host_nu.swap(host_nu);
+    V->stride = root->stride;
+    V->root = root;
+    V->serial = ++ctx->lines_serial;
+    root->views++;
+    ctx->live_objects++;
+    *out = V;
+    return LBL_OK;
+} LBL_GUARD_END(parent ? parent->ctx : nullptr)
+
 extern "C" int lbl_lines_destroy(lbl_lines* lines) try {
     if (!lines) return LBL_OK;
     lbl_ctx* ctx = lines->ctx;
+    if (lines->views > 0) return fail(ctx, LBL_ERR_STATE, "%d views of this line list are still alive", lines->views);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (lines->root) {                 // a view: the arrays belong to its root
+        lines->root->views--;
+        ctx->epoch++;
+        ctx->live_objects--;
+        delete lines;
+        return LBL_OK;
+    }
     HIP_TRY(ctx, hipFree(lines->d));
     ctx->epoch++;                     // a captured graph may hold its address (lbl_graph_launch then refuses)
     ctx->live_objects--;

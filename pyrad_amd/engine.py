@@ -180,7 +180,7 @@ class ResidentLayer:
     """
 
     def __init__(self, ctx: nat.Context, depth, T, P, range_min, range_max, molecules,
-                 base_resolution=None, dynamic_resolution=True, shard=None, keep_host_lines=False):
+                 base_resolution=None, dynamic_resolution=True, shard=None, keep_host_lines=False, line_pool=None):
         self.ctx = ctx
         self.depth, self.T, self.P = depth, T, P
         self.range_min, self.range_max = range_min, range_max
@@ -220,7 +220,18 @@ class ResidentLayer:
                 lines = select_window(iso["lines"], g["eff_min"], g["eff_max"])
                 if plan is not None:
                     lines = self._halo_select(lines)
-                dev_lines = ctx.lines(lines)
+                dev_lines = None
+                if line_pool is not None:
+                    # the window (and the shard's halo) is a wavenumber range: a VIEW of the column's one resident
+                    # copy of this line list (lbl_lines_view), not another upload
+                    lo, hi = g["eff_min"], g["eff_max"]
+                    if plan is not None:
+                        H = max(int(g["W"]) - 2, 0)
+                        lo = max(lo, g["range_min"] + (self.first - H - 2) * g["resolution"])
+                        hi = min(hi, g["range_min"] + (self.first + self.count + H + 2) * g["resolution"])
+                    dev_lines = line_pool.view(iso["lines"], lo, hi, expect=len(lines["nu"]))
+                if dev_lines is None:
+                    dev_lines = ctx.lines(lines)
                 out = ctx.buffer(max(self.padded_n, 1))
                 out.fill(0.0)
                 ip = nat.IsoParams(float(T), float(P), float(mol["conc"]), float(iso["molmass"]),
@@ -336,6 +347,35 @@ class ResidentLayer:
         self.jobs = []
 
 
+class LinePool:
+    """One resident copy of every distinct line list of a column (identity of the host dict), handed out as views:
+    the 30 layers of a column select wavenumber windows of the same three lists."""
+
+    def __init__(self, ctx: nat.Context):
+        self.ctx = ctx
+        self.masters = {}
+
+    def view(self, lines: dict, lo: float, hi: float, expect: int):
+        """the lines with lo < nu < hi (ut:437-438 is strict) as a view of the resident copy; None if that is not
+        the selection the caller made (then it uploads its own)"""
+        key = id(lines["nu"])               # (layer configs are often fresh dicts around the same arrays)
+        if key not in self.masters or self.masters[key][2]["nu"] is not lines["nu"]:
+            nu = np.asarray(lines["nu"], dtype=np.float64)
+            order = np.argsort(nu, kind="stable")
+            self.masters[key] = (self.ctx.lines(lines), nu[order], lines)       # (Lines sorts the same way)
+        master, nu, _ = self.masters[key]
+        first = int(np.searchsorted(nu, lo, "right"))
+        end = int(np.searchsorted(nu, hi, "left"))
+        if max(end - first, 0) != expect:
+            return None
+        return master.view(first, max(end - first, 0))
+
+    def free(self):
+        for master, _, _ in self.masters.values():
+            master.free()
+        self.masters = {}
+
+
 class ResidentColumn:
     """A column of layers (bottom to top) resident in HBM: all layers' isotopologue jobs go
     through ONE batched K1/K2 launch sequence, every layer gets its fused sweep, and the
@@ -348,8 +388,10 @@ class ResidentColumn:
     def __init__(self, ctx: nat.Context, layer_cfgs, surface_T, shard=None):
         self.ctx = ctx
         self.surface_T = float(surface_T)
+        self.pool = LinePool(ctx)
         self.layers = [ResidentLayer(ctx, c["depth"], c["T"], c["P"], c["range_min"], c["range_max"], c["molecules"],
-                                     c.get("base_resolution"), c.get("dynamic_resolution", True), shard=shard)
+                                     c.get("base_resolution"), c.get("dynamic_resolution", True), shard=shard,
+                                     line_pool=self.pool)
                        for c in layer_cfgs]
         first = self.layers[0]
         for L in self.layers[1:]:
@@ -419,6 +461,7 @@ class ResidentColumn:
     def free(self):
         for L in self.layers:
             L.free()
+        self.pool.free()                    # after the layers' views
         self.I_toa.free()
         if self.I_gathered is not None:
             self.I_gathered.free()

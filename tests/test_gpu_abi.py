@@ -244,3 +244,38 @@ def test_chained_contexts_give_the_same_arrays():
         La.free(); Lb.free()
     finally:
         a.close(); b.close()
+
+
+def test_line_list_views_share_the_parent_arrays(ctx):
+    """lbl_lines_view: a wavenumber window of a resident list as a view (no copy) gives bit for bit the cross section
+    of the same lines uploaded on their own; a view of a view works; a list with live views cannot be destroyed."""
+    from pyrad_amd import _native as nat, engine
+    g = engine.layer_grid(300.0, 640, 700, .001, False)
+    base = synthetic.make_lines(81, 6000, 600.0, 740.0)
+    sp = synthetic.SPECIES["co2"]
+    iso = nat.IsoParams(250.0, 300.0, 4e-4, sp["molmass"], synthetic.q_value("co2", 250), sp["q296"])
+    grid = engine.native_grid(g)
+    nu = base["nu"]
+    first, end = int(np.searchsorted(nu, g["eff_min"], "right")), int(np.searchsorted(nu, g["eff_max"], "left"))
+    sub = {k: v[first:end] for k, v in base.items()}
+    own = ctx.lines(sub)
+    master = ctx.lines(base)
+    view = master.view(first, end - first)
+    inner = master.view(first - 10, end - first + 30).view(10, end - first)
+    outs = [ctx.buffer(g["n_base"]) for _ in range(3)]
+    ctx.xsec_accumulate_dev([(own, iso, grid, outs[0]), (view, iso, grid, outs[1]), (inner, iso, grid, outs[2])])
+    a, b, c = (o.download(g["n_base"]) for o in outs)
+    assert np.array_equal(a, b) and np.array_equal(a, c) and np.all(a > 0)
+    with pytest.raises(nat.LblError) as e:
+        master.free()
+    assert e.value.code == -6 and "views" in str(e.value)
+    with pytest.raises(nat.LblError):
+        master.view(5990, 20)                          # outside the list
+    for x in (view, inner, own):
+        x.free()
+    intermediate = [c_ for c_ in ctx._children if isinstance(c_, nat.Lines) and c_ is not master]
+    for x in intermediate:                                # the intermediate view of `inner`
+        x.free()
+    master.free()
+    for o in outs:
+        o.free()
