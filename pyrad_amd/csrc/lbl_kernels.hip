@@ -1234,7 +1234,9 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         else wave_line_ranges_far(J.cidx, J.n_lines, wlo, whi, H, fl, fr, lane, iA, iB, iC, iD, iF1, iF2);
         const bool any_far = (iF1 - iB) + (iC - iF2) > 0;
         // edge lines first (skewed walk), while neither the series coefficients nor the Gaussian run sums are live
-        const bool edges_done = EDGE_SKEW && any_far && !(J.ablate & 8);
+        // (also on spans without any far line - windows just above the kernel's limit, grid ends: their interior lines
+        // are all near, [iF1, iF2) = [iB, iC))
+        const bool edges_done = EDGE_SKEW && !(J.ablate & 8);
         if (edges_done)
             skew_edges<R>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, lh, lc, s_ecnt[EDGE_SKEW ? wave : 0][0],
                           s_ecnt[EDGE_SKEW ? wave : 0][1], lane, S);
