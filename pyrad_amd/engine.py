@@ -383,7 +383,8 @@ class ResidentColumn:
     I <- T_i I + (1 - T_i) B(nu, T_i), I_0 = B(nu, surface_T).  All layers share one wavenumber
     range and base grid.  With ``shard=(world, rank)`` every rank keeps ALL layers for its own
     contiguous grid range (the fold is independent per grid point), so one all-gather of the
-    outgoing spectrum suffices."""
+    outgoing spectrum suffices.  Line lists that several layers share (the same host arrays) are uploaded
+    once; every layer works on a view of its wavenumber window (LinePool)."""
 
     def __init__(self, ctx: nat.Context, layer_cfgs, surface_T, shard=None):
         self.ctx = ctx
