@@ -97,7 +97,11 @@ int lbl_ctx_stream(lbl_ctx* ctx, void** stream);
  * before them, the sweep after them - does not.  With A chained after B and B after A and steps dealt
  * alternately, the fp64-bound accumulate kernels run one after another, each alone on the chip, while the
  * line prep of the next step and the sweep of the previous one fill the cycles they leave; every step's
- * arrays are complete in step order.  predecessor = NULL ends the chaining. */
+ * arrays are complete in step order.  predecessor = NULL ends the chaining.
+ * Destroying a predecessor unlinks it: its successors simply stop waiting (any destroy order is safe).
+ * A chained context (either end of a link) cannot capture a graph - the cross-context event waits do not
+ * live in a captured sequence: lbl_capture_begin returns LBL_ERR_STATE on it, and a capturing context
+ * cannot be chained. */
 int lbl_ctx_chain_accumulate(lbl_ctx* ctx, lbl_ctx* predecessor);
 /* Name of the device ("gfx950..."), CU count, HBM bytes. */
 int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
@@ -130,7 +134,9 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "accum_skew_points_per_lane"  1 | 2 | 4 | 8 (default)
  *   "accum_far_min_window"   windows below this many points take the skewed-range kernel even where the far-field
  *                            kernel could run them (0, the default: its own limit, 640; measured flat up to 1000)
- *   "debug_ablate"           timing experiments only (results are wrong): bits switch off parts of kernels
+ *   "debug_ablate"           ONLY in diagnostic builds of the library (make EXTRA=-DLBL_DIAG): timing experiments,
+ *                            bits switch off parts of kernels, results are wrong.  The production library has no
+ *                            such code in its kernels and answers LBL_ERR_BAD_ARG (unknown option)
  *   "layer_step_fused"       1 (default) lbl_layer_step_dev folds the sweep of a single-line-list layer into the
  *                            accumulate kernel | 0 always accumulate launch + sweep launch (bit-identical; A/B)
  *   "debug_throw"            test hook: 1 / 2 / 3 raise std::bad_alloc / std::runtime_error /
@@ -203,9 +209,12 @@ int lbl_xsec_accumulate_dev(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
 /* Regime counters of the most recent lbl_xsec_accumulate_dev (drains the stream):
  * counts[3*j + {0,1,2}] = {gaussian, lorentz, voigt} of job j. */
 int lbl_last_regime_counts(lbl_ctx* ctx, int n_jobs, int64_t* counts);
-/* Debug / parity aid: per-line centre index (pyradClasses.py:390), Lorentz and Doppler
- * half-widths (pyradClasses.py:256-263) and corrected intensity (pyradIntensity.py:30-32)
- * as the device computed them.  Any output may be NULL. */
+/* Parity aid: runs the real line preparation (K1) of this one job and reports, per line, the centre index
+ * K1 wrote (pyradClasses.py:390; the very value the accumulate kernel works from, clamped to +-2e9), and the
+ * Lorentz and Doppler half-widths (pyradClasses.py:256-263), the corrected intensity (pyradIntensity.py:30-32)
+ * and the regime (0 Gaussian, 1 Lorentz, 2 pseudo-Voigt; pyradClasses.py:379-387) from the same device
+ * expressions K1 evaluates (a separate reporting kernel: the timed kernels carry no debug stores).
+ * Any output may be NULL. */
 int lbl_line_quantities(lbl_ctx* ctx, lbl_lines* lines, const lbl_iso_params* iso,
                         const lbl_grid* grid, int64_t* index, double* lorentz_hw,
                         double* gauss_hw, double* intensity, int32_t* regime);

@@ -184,7 +184,12 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            for child in list(self._children):
+            # views before the line lists they window (lbl_lines_destroy refuses a list with live views), then
+            # everything else newest first
+            for child in reversed(list(self._children)):
+                if isinstance(child, Lines) and child._parent is not None:
+                    child.free()
+            for child in reversed(list(self._children)):
                 child.free()
             for blocks in self.__dict__.pop("_pinned_pool", {}).values():      # idle blocks; a block a caller still
                 for ptr in blocks:                                              # holds an array in is freed with that array
@@ -526,6 +531,7 @@ class Lines:
             lines = {k: np.asarray(lines[k])[order] for k in self.ORDER}
         arrs = [_as_f64(lines[k]) for k in self.ORDER]
         self.n = int(arrs[0].size)
+        self._parent = None
         h = _P()
         ctx.check(ctx.lib.lbl_lines_create(ctx.h, *[_ptr(a) for a in arrs], self.n, C.byref(h)))
         self.h = h
@@ -536,6 +542,7 @@ class Lines:
         (lbl_lines_view).  Free the views before the list."""
         v = Lines.__new__(Lines)
         v.ctx, v.n = self.ctx, int(count)
+        v._parent = self                       # the view keeps its list alive (a collected list could not free itself)
         h = _P()
         self.ctx.check(self.ctx.lib.lbl_lines_view(self.h, int(first), int(count), C.byref(h)))
         v.h = h
@@ -546,6 +553,7 @@ class Lines:
         if self.h:
             self.ctx.check(self.ctx.lib.lbl_lines_destroy(self.h))
             self.h = None
+            self._parent = None
             if self in self.ctx._children:
                 self.ctx._children.remove(self)
 

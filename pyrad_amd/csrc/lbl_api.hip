@@ -4,11 +4,13 @@
 #include "lbl_device.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -90,7 +92,8 @@ struct lbl_ctx {
                              // skewed-range kernel whatever its window and the grid size (parity tests)
     int skew_R = 8;          // points per lane of the skewed-range kernel (8: 118 VGPRs, 4 waves per SIMD; measured 7 % faster than 4 on the column)
     int far_min_H = 0;       // windows below this many points go to the skewed-range kernel even if they have far lines (0: the far-field kernel's own limit, 640)
-    int ablate = 0;          // diagnostics: AccumJob.ablate
+    int ablate = 0;          // LBL_DIAG builds: AccumJob.ablate (always 0 in the production library)
+    const PrepJob* last_prep_desc = nullptr;   // device copy of the last batch's PrepJob[] (lbl_line_quantities reads job 0)
     lbl_ctx* chain_pred = nullptr;   // lbl_ctx_chain_accumulate: accumulate kernels wait for this context's
     hipEvent_t accum_done = nullptr; // recorded after this context's accumulate launches
     bool no_fuse = false;    // lbl_layer_step_dev as accumulate + separate sweep launch (A/B, parity tests)
@@ -120,6 +123,21 @@ struct lbl_lines {
 };
 
 static thread_local std::string g_err;
+// every live context of the process: lbl_ctx_destroy unlinks the dying one from contexts chained to it
+static std::mutex g_ctx_mutex;
+static std::vector<lbl_ctx*> g_contexts;
+
+// LBL_TRACE=1: host-side phase timings on stderr (setup paths only: allocation, upload, schedule build)
+static const bool g_trace = getenv("LBL_TRACE") != nullptr;
+struct TraceScope {
+    const char* what; long long n; std::chrono::steady_clock::time_point t0;
+    TraceScope(const char* w, long long n_ = 0) : what(w), n(n_) { if (g_trace) t0 = std::chrono::steady_clock::now(); }
+    ~TraceScope() {
+        if (g_trace)
+            fprintf(stderr, "[lbl trace] %-28s %10.1f us  (%lld)\n", what,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), n);
+    }
+};
 
 static int fail(lbl_ctx* ctx, int code, const char* fmt, ...) noexcept {
     char buf[512];
@@ -161,6 +179,7 @@ static int capture_refuses(lbl_ctx* ctx, const char* what) {
 static int arena_reserve(lbl_ctx* ctx, DeviceArena& a, size_t bytes) {
     if (bytes <= a.cap) return LBL_OK;
     if (ctx->capturing) return capture_refuses(ctx, "growing a scratch buffer");
+    TraceScope tr("arena grow", (long long)bytes);
     ctx->epoch++;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (a.ptr) HIP_TRY(ctx, hipFree(a.ptr));
@@ -306,6 +325,7 @@ extern "C" int lbl_ctx_create(int device, lbl_ctx** out) try {
     if (e != hipSuccess) { int rc = fail(nullptr, LBL_ERR_HIP, "context setup: %s", hipGetErrorString(e)); delete ctx; return rc; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    { std::lock_guard<std::mutex> lock(g_ctx_mutex); g_contexts.push_back(ctx); }
     *out = ctx;
     return LBL_OK;
 } LBL_GUARD_END(nullptr)
@@ -315,6 +335,11 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) try {
     if (ctx->live_objects != 0) return fail(ctx, LBL_ERR_STATE, "%d device objects still alive", ctx->live_objects);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    {   // a successor chained to this context (lbl_ctx_chain_accumulate) must not wait on its event any more
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), ctx), g_contexts.end());
+        for (lbl_ctx* c : g_contexts) if (c->chain_pred == ctx) c->chain_pred = nullptr;
+    }
     lbl::comm_forget(ctx);
     if (ctx->accum_done) (void)hipEventDestroy(ctx->accum_done);
     for (auto& v : ctx->ev_rec) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -348,6 +373,7 @@ extern "C" int lbl_ctx_chain_accumulate(lbl_ctx* ctx, lbl_ctx* predecessor) try 
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (predecessor && predecessor->device != ctx->device) return fail(ctx, LBL_ERR_BAD_ARG, "contexts live on different devices");
     if (predecessor == ctx) return fail(ctx, LBL_ERR_BAD_ARG, "a context cannot follow itself");
+    if (ctx->capturing || (predecessor && predecessor->capturing)) return fail(ctx, LBL_ERR_STATE, "cannot chain a context while it is capturing a graph");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (lbl_ctx* c : {ctx, predecessor})
         if (c && !c->accum_done) HIP_TRY(ctx, hipEventCreateWithFlags(&c->accum_done, hipEventDisableTiming));
@@ -447,8 +473,10 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) try {
     } else if (!strcmp(key, "accum_far_min_window")) {
         if (value < 0) return fail(ctx, LBL_ERR_BAD_ARG, "accum_far_min_window must be >= 0");
         ctx->far_min_H = value;
+#ifdef LBL_DIAG
     } else if (!strcmp(key, "debug_ablate")) {
-        ctx->ablate = value;        // timing experiments only: results are wrong when non-zero
+        ctx->ablate = value;        // diagnostic builds only, timing experiments: results are wrong when non-zero
+#endif
     } else if (!strcmp(key, "layer_step_fused")) {
         if (value < 0 || value > 1) return fail(ctx, LBL_ERR_BAD_ARG, "layer_step_fused must be 0 or 1");
         ctx->no_fuse = value == 0;
@@ -471,6 +499,7 @@ extern "C" int lbl_buffer_create(lbl_ctx* ctx, int64_t n, lbl_buffer** out) try 
     *out = nullptr;
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative length");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    TraceScope tr("buffer_create", (long long)n);
     double* d = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d, (size_t)std::max<int64_t>(n, 1) * sizeof(double)));
     lbl_buffer* b = new (std::nothrow) lbl_buffer{ctx, d, n};
@@ -575,6 +604,7 @@ extern "C" int lbl_lines_create(lbl_ctx* ctx, const double* nu, const double* sw
     for (int64_t i = 1; i < n_lines; ++i)
         if (!(nu[i] >= nu[i - 1])) return fail(ctx, LBL_ERR_BAD_ARG, "nu must be non-decreasing (line %lld)", (long long)i);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    TraceScope tr("lines_create", (long long)n_lines);
     // host-side allocations first: if they throw, nothing on the device has to be released
     std::vector<double> host_nu(nu, nu + n_lines);
     lbl_lines* L = new (std::nothrow) lbl_lines{ctx, nullptr, n_lines, {}, 0};
@@ -604,7 +634,7 @@ extern "C" int lbl_lines_view(lbl_lines* parent, int64_t first, int64_t count, l
     if (!parent || !out) return fail(parent ? parent->ctx : nullptr, LBL_ERR_BAD_ARG, "NULL argument");
     lbl_ctx* ctx = parent->ctx;
     *out = nullptr;
-    if (first < 0 || count < 0 || first + count > parent->n) return fail(ctx, LBL_ERR_BAD_ARG, "view outside the line list");
+    if (first < 0 || count < 0 || first > parent->n || count > parent->n - first) return fail(ctx, LBL_ERR_BAD_ARG, "view outside the line list");
     lbl_lines* root = parent->root ? parent->root : parent;
     std::vector<double> host_nu(parent->host_nu.begin() + first, parent->host_nu.begin() + first + count);
     lbl_lines* V = new (std::nothrow) lbl_lines{ctx, parent->d + first, count, {}, 0};
@@ -749,6 +779,7 @@ static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const 
             return &ctx->schedules.back();
         }
     if (ctx->capturing) { (void)capture_refuses(ctx, "building a dispatch schedule"); return nullptr; }
+    TraceScope tr("group_schedule", (long long)jobs_in_group.size());
     struct Item { int count, job, tile; };
     std::vector<Item> items;
     std::vector<long long> idx;
@@ -900,10 +931,8 @@ static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const 
     return &ctx->schedules.back();
 }
 
-struct DbgOut { long long* index; double* lhw; double* ghw; double* inten; int32_t* regime; };
-
 static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines, const lbl_iso_params* iso,
-                              const lbl_grid* grid, double* const* out_dev, const DbgOut* dbg, bool prep_only,
+                              const lbl_grid* grid, double* const* out_dev, bool prep_only,
                               const FusedSweep* fuse = nullptr, double fuse_conc = 0.0) {
     // fuse != NULL (n_jobs == 1): the layer sweep runs in the output stage of the one job
     if (n_jobs <= 0) return LBL_OK;
@@ -1024,7 +1053,6 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         p.cold = (ColdRec*)ctx->cold.ptr + line_off[j];
         p.cidx = (int32_t*)ctx->cidx.ptr + line_off[j];
         p.block_counts = d_counts + (size_t)j * blocks_per_job * 3;
-        if (dbg) { p.dbg_index = dbg->index; p.dbg_lhw = dbg->lhw; p.dbg_ghw = dbg->ghw; p.dbg_intensity = dbg->inten; p.dbg_regime = dbg->regime; }
         p.T = iso[j].T; p.P = iso[j].P; p.q_frac = iso[j].q_frac; p.molmass = iso[j].molmass;
         p.Q_T = iso[j].Q_T; p.Q_296 = iso[j].Q_296;
         p.range_min = grid[j].range_min; p.resolution = grid[j].resolution;
@@ -1121,6 +1149,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     prof_end(ctx, PROF_PREP, ev);
     HIP_TRY(ctx, hipGetLastError());
     ctx->last_jobs = n_jobs;
+    ctx->last_prep_desc = dp;
     if (prep_only) return LBL_OK;
     // software pipeline of two contexts (lbl_ctx_chain_accumulate): this step's accumulate kernels start after the
     // predecessor's; its line prep (above) did not wait
@@ -1171,7 +1200,7 @@ extern "C" int lbl_xsec_accumulate_dev(lbl_ctx* ctx, int n_jobs, lbl_lines* cons
         if (out[j]->n < grid[j].n_base) return fail(ctx, LBL_ERR_BAD_ARG, "job %d: output buffer shorter than n_base", j);
         outs[j] = out[j]->d;
     }
-    return enqueue_accumulate(ctx, n_jobs, lines, iso, grid, outs.data(), nullptr, false);
+    return enqueue_accumulate(ctx, n_jobs, lines, iso, grid, outs.data(), false);
 } LBL_GUARD_END(ctx)
 
 extern "C" int lbl_last_regime_counts(lbl_ctx* ctx, int n_jobs, int64_t* counts) try {
@@ -1230,21 +1259,23 @@ extern "C" int lbl_line_quantities(lbl_ctx* ctx, lbl_lines* lines, const lbl_iso
     char* d = nullptr;
     const size_t bytes = n * (8 + 8 + 8 + 8 + 4);
     HIP_TRY(ctx, hipMalloc((void**)&d, bytes));
-    DbgOut dbg;
-    dbg.index = (long long*)d;
-    dbg.lhw = (double*)(d + 8 * n);
-    dbg.ghw = (double*)(d + 16 * n);
-    dbg.inten = (double*)(d + 24 * n);
-    dbg.regime = (int32_t*)(d + 32 * n);
+    long long* d_index = (long long*)d;
+    double* d_lhw = (double*)(d + 8 * n);
+    double* d_ghw = (double*)(d + 16 * n);
+    double* d_inten = (double*)(d + 24 * n);
+    int32_t* d_regime = (int32_t*)(d + 32 * n);
     double* no_out = nullptr;
-    int rc = enqueue_accumulate(ctx, 1, &lines, iso, grid, &no_out, &dbg, true);
+    // the real line prep (K1) of this one job, then a reporting kernel: the centre indices are the ones K1 wrote
+    int rc = enqueue_accumulate(ctx, 1, &lines, iso, grid, &no_out, true);
     hipError_t e = hipSuccess;
     if (!rc) {
-        if (index) e = hipMemcpyAsync(index, dbg.index, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess && lorentz_hw) e = hipMemcpyAsync(lorentz_hw, dbg.lhw, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess && gauss_hw) e = hipMemcpyAsync(gauss_hw, dbg.ghw, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess && intensity) e = hipMemcpyAsync(intensity, dbg.inten, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess && regime) e = hipMemcpyAsync(regime, dbg.regime, 4 * n, hipMemcpyDeviceToHost, ctx->stream);
+        launch_line_quantities(ctx->last_prep_desc, (int)n, d_index, d_lhw, d_ghw, d_inten, d_regime, ctx->stream);
+        e = hipGetLastError();
+        if (e == hipSuccess && index) e = hipMemcpyAsync(index, d_index, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && lorentz_hw) e = hipMemcpyAsync(lorentz_hw, d_lhw, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && gauss_hw) e = hipMemcpyAsync(gauss_hw, d_ghw, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && intensity) e = hipMemcpyAsync(intensity, d_inten, 8 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && regime) e = hipMemcpyAsync(regime, d_regime, 4 * n, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     } else {
         (void)hipStreamSynchronize(ctx->stream);
@@ -1373,11 +1404,11 @@ extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lin
         f.trans = trans ? trans->d : nullptr;
         f.I_out = I_out ? I_out->d : nullptr;
         f.n = n; f.on = 1;
-        return enqueue_accumulate(ctx, 1, lines, iso, grids.data(), outs.data(), nullptr, false, &f, conc[iso_mol[0]]);
+        return enqueue_accumulate(ctx, 1, lines, iso, grids.data(), outs.data(), false, &f, conc[iso_mol[0]]);
     }
     // several line lists, a work grid that needs the regrid kernel, or a kernel variant without the fused
     // stage: the accumulate launch and the sweep launch
-    if ((rc = enqueue_accumulate(ctx, n_iso, lines, iso, grids.data(), outs.data(), nullptr, false))) return rc;
+    if ((rc = enqueue_accumulate(ctx, n_iso, lines, iso, grids.data(), outs.data(), false))) return rc;
     long long sf, sc;
     shard_range(*grid, &sf, &sc);
     const bool whole = sc == grid->n_work;
@@ -1615,6 +1646,14 @@ struct lbl_graph {
 extern "C" int lbl_capture_begin(lbl_ctx* ctx) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (ctx->capturing) return fail(ctx, LBL_ERR_STATE, "already capturing");
+    bool chained = ctx->chain_pred != nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        for (lbl_ctx* c : g_contexts) chained = chained || c->chain_pred == ctx;
+    }
+    if (chained)
+        return fail(ctx, LBL_ERR_STATE, "this context is part of an accumulate chain (lbl_ctx_chain_accumulate): the cross-context "
+                                        "event waits cannot live in a captured graph; capture on an unchained context");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     ctx->capturing = true;

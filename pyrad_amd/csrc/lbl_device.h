@@ -83,7 +83,7 @@ struct AccumJob {
     // Fused layer step of a single-line-list layer (lbl_layer_step_dev): the sweep of a point runs in
     // this job's output stage with the molecule's volume fraction `conc`.
     int32_t chain_flags;
-    int32_t ablate;        // diagnostics (lbl_set_option debug_ablate): timing-only builds of the skewed-range kernel skip parts of its work
+    int32_t ablate;        // LBL_DIAG builds only (lbl_set_option debug_ablate): timing-only runs skip parts of the kernel; else 0 and never read
     double conc;
     FusedSweep fuse;       // fuse.on: sweep every point right after its cross section is final
 };
@@ -98,8 +98,6 @@ struct PrepJob {
     const double* gamma_self; const double* n_air; const double* delta_air;
     HotRec* hot; ColdRec* cold; int32_t* cidx;
     unsigned int* block_counts;           // [blocks of 256 lines][3]: per-block regime counts, no atomics
-    // optional debug outputs
-    long long* dbg_index; double* dbg_lhw; double* dbg_ghw; double* dbg_intensity; int32_t* dbg_regime;
     double T, P, q_frac, molmass, Q_T, Q_296;
     double range_min, resolution;
     double log_t0_over_T;   // ln(296/T), computed once per job on the host
@@ -124,7 +122,7 @@ struct SweepArgs {
     double term_conc[kMaxIso];      // volume fraction of the term's molecule
     int32_t term_flags[kMaxIso];
     int32_t n_iso, n_mol;
-    int32_t variant, pad;           // 1: streaming (non-temporal) loads and stores (0 with lbl_set_option debug_ablate bit 64, for A/B)
+    int32_t variant, pad;           // 1: streaming (non-temporal) loads and stores (0 in LBL_DIAG builds with debug_ablate bit 64, for A/B)
     double P, T, depth;
     double rT, r_surface_T;         // RN(1/T), RN(1/surface_T) for div_uniform (0: plain divide)
     double start, stop, step;       // xAxis = linspace(start, stop, n)
@@ -147,7 +145,7 @@ struct ColumnStepArgs {
     double term_P[kMaxColumnIso], term_T[kMaxColumnIso], term_rT[kMaxColumnIso], term_depth[kMaxColumnIso];   // rT = RN(1/T) (0: plain divide)
     int32_t term_flags[kMaxColumnIso];
     int32_t n_terms, n_layers;
-    int32_t ablate;                     // diagnostics (lbl_set_option debug_ablate): timing-only variants
+    int32_t ablate;                     // LBL_DIAG builds only (lbl_set_option debug_ablate): timing-only variants; else 0 and never read
     int32_t layer_arrays;               // any of trans[] / abs_coef[] set
     double r_surface_T;
     double* trans[kMaxLayers];          // optional per-layer transmittance outputs
@@ -171,6 +169,8 @@ struct ColumnArgs {
 
 // ---- launchers (lbl_kernels.hip) ---------------------------------------------------------
 void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStream_t s);
+void launch_line_quantities(const PrepJob* d_job, int n_lines, long long* index, double* lhw, double* ghw, double* intensity,
+                            int32_t* regime, hipStream_t s);
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
                        const int2* worklist, int total_tiles, hipStream_t s);
 // narrow windows: every lane walks the lines that reach its own R points (skewed ranges); tiles of 256 R points

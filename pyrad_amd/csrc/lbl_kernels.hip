@@ -37,6 +37,14 @@
 
 namespace lbl {
 
+// Timing-only ablations (parts of a kernel switched off: WRONG results) exist in diagnostic builds only
+// (make EXTRA=-DLBL_DIAG, scripts/make_diag_lib.sh); the production library carries none of them.
+#ifdef LBL_DIAG
+#define LBL_ABLATE(obj, bit) (((obj).ablate & (bit)) != 0)
+#else
+#define LBL_ABLATE(obj, bit) false
+#endif
+
 // ----------------------------------------------------------------------------------------
 // small helpers
 // ----------------------------------------------------------------------------------------
@@ -154,36 +162,51 @@ __device__ __forceinline__ double abs_coef_term(double xs, double conc, double P
 // ----------------------------------------------------------------------------------------
 // K1: per-line preparation
 // ----------------------------------------------------------------------------------------
+// What the reference computes per line before it touches the grid (pyradClasses.py:252-263, 378, 388-390;
+// pyradIntensity.py:16-32): shared by K1 and by the kernel behind lbl_line_quantities, which only reports them.
+struct LinePhysics {
+    double broadened, lhw, ghw, ratio, A, fidx;
+};
+__device__ __forceinline__ LinePhysics line_physics(const PrepJob& J, int i) {
+    LinePhysics L;
+    const double nu = J.nu[i];
+    const double q = J.q_frac;
+    const double Pp0 = J.P_over_p0;                                   // P / p0, evaluated on the host
+    // Line.broadenedLine (pyradClasses.py:252-254)
+    L.broadened = nu + J.delta_air[i] * J.P / p0;
+    // Line.lorentzHW (pyradClasses.py:256-259)
+    // (t0/T)**n evaluated as exp(n ln(t0/T)) with the logarithm hoisted to the host (one per job)
+    L.lhw = ((1.0 - q) * J.gamma_air[i] + q * J.gamma_self[i]) * Pp0 * exp(J.n_air[i] * J.log_t0_over_T);
+    // Isotope.molMass (pyradClasses.py:294-296), Line.gaussianHW (pyradClasses.py:261-263): the
+    // square root depends on the job only (host)
+    L.ghw = L.broadened * J.ghw_factor;
+    L.ratio = L.lhw / L.ghw;                                          // pyradClasses.py:378
+    // pyradIntensity.intensityFactor (pyradIntensity.py:16-32) at the SHIFTED wavenumber
+    // (pyradClasses.py:388).  Divisions by the per-job T and t0 are multiplications by their
+    // reciprocals: at most one ulp in an exponent of order 1-50.
+    const double c2 = cLight * hPlanck * 100.0 / kB;                  // pyradIntensity.py:13
+    const double E = J.elower[i];
+    const double stim = (1.0 - exp(-c2 * L.broadened * J.inv_T)) / (1.0 - exp(-c2 * L.broadened * (1.0 / t0)));
+    // exp(-c2 E/T) / exp(-c2 E/t0) as one exponential of the difference (exactly 1 at T = t0,
+    // like the quotient; elsewhere within |c2 E (1/T - 1/t0)| ulps of it, < 1e-14 relative)
+    const double boltz = exp(c2 * E * (1.0 / t0) - c2 * E * J.inv_T);
+    L.A = J.sw[i] * J.q_ratio * stim * boltz;
+    // centre index from the UNSHIFTED wavenumber, truncation toward zero (pyradClasses.py:390)
+    L.fidx = (nu - J.range_min) / J.resolution;
+    return L;
+}
+__device__ __forceinline__ int line_regime(double ratio) {          // pyradClasses.py:379-387
+    return ratio < .01 ? 0 : (ratio > 100.0 ? 1 : 2);
+}
+
 __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restrict__ jobs) {
     const PrepJob& J = jobs[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int regime = -1;
     if (i < J.n_lines) {
-        const double nu = J.nu[i];
-        const double q = J.q_frac;
-        const double Pp0 = J.P_over_p0;                                   // P / p0, evaluated on the host
-        // Line.broadenedLine (pyradClasses.py:252-254)
-        const double broadened = nu + J.delta_air[i] * J.P / p0;
-        // Line.lorentzHW (pyradClasses.py:256-259)
-        // (t0/T)**n evaluated as exp(n ln(t0/T)) with the logarithm hoisted to the host (one per job)
-        const double lhw = ((1.0 - q) * J.gamma_air[i] + q * J.gamma_self[i]) * Pp0 * exp(J.n_air[i] * J.log_t0_over_T);
-        // Isotope.molMass (pyradClasses.py:294-296), Line.gaussianHW (pyradClasses.py:261-263): the
-        // square root depends on the job only (host)
-        const double ghw = broadened * J.ghw_factor;
-        const double ratio = lhw / ghw;                                   // pyradClasses.py:378
-        // pyradIntensity.intensityFactor (pyradIntensity.py:16-32) at the SHIFTED wavenumber
-        // (pyradClasses.py:388).  Divisions by the per-job T and t0 are multiplications by their
-        // reciprocals: at most one ulp in an exponent of order 1-50.
-        const double c2 = cLight * hPlanck * 100.0 / kB;                  // pyradIntensity.py:13
-        const double E = J.elower[i];
-        const double stim = (1.0 - exp(-c2 * broadened * J.inv_T)) / (1.0 - exp(-c2 * broadened * (1.0 / t0)));
-        // exp(-c2 E/T) / exp(-c2 E/t0) as one exponential of the difference (exactly 1 at T = t0,
-        // like the quotient; elsewhere within |c2 E (1/T - 1/t0)| ulps of it, < 1e-14 relative)
-        const double boltz = exp(c2 * E * (1.0 / t0) - c2 * E * J.inv_T);
-        const double A = J.sw[i] * J.q_ratio * stim * boltz;
-        // centre index from the UNSHIFTED wavenumber, truncation toward zero (pyradClasses.py:390)
-        const double fidx = (nu - J.range_min) / J.resolution;
-        long long idx = (long long)fidx;
+        const LinePhysics L = line_physics(J, i);
+        const double lhw = L.lhw, ghw = L.ghw, ratio = L.ratio, A = L.A;
+        long long idx = (long long)L.fidx;
         if (idx > 2000000000LL) idx = 2000000000LL;
         if (idx < -2000000000LL) idx = -2000000000LL;
 
@@ -267,11 +290,6 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
         J.hot[i] = r;
         J.cold[i] = rc;
         J.cidx[i] = (int32_t)idx;
-        if (J.dbg_index) J.dbg_index[i] = (long long)fidx;
-        if (J.dbg_lhw) J.dbg_lhw[i] = lhw;
-        if (J.dbg_ghw) J.dbg_ghw[i] = ghw;
-        if (J.dbg_intensity) J.dbg_intensity[i] = A;
-        if (J.dbg_regime) J.dbg_regime[i] = regime;
     }
     // regime counters (pyradClasses.py:368-370, 406).  One plain store per block: thousands of
     // atomics on one cache line cost ~12 ns each and made this kernel 3x longer than its arithmetic.
@@ -285,6 +303,21 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
     if (threadIdx.x < 3)
         J.block_counts[blockIdx.x * 3 + threadIdx.x] =
             s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+}
+
+// lbl_line_quantities: the per-line numbers of the reference (Line.lorentzHW / gaussianHW, the corrected intensity,
+// the regime) from the same expressions K1 evaluates, and the centre index K1 itself wrote (the one K2 works
+// from; K1 clamps it to +-2e9).  Never part of a step.
+__global__ __launch_bounds__(256) void line_quantities_kernel(const PrepJob* __restrict__ jobs, long long* __restrict__ index,
+                                                              double* __restrict__ lhw, double* __restrict__ ghw,
+                                                              double* __restrict__ intensity, int32_t* __restrict__ regime) {
+    const PrepJob& J = jobs[0];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= J.n_lines) return;
+    const LinePhysics L = line_physics(J, i);
+    index[i] = (long long)J.cidx[i];
+    lhw[i] = L.lhw; ghw[i] = L.ghw; intensity[i] = L.A;
+    regime[i] = line_regime(L.ratio);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1236,7 +1269,7 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         // edge lines first (skewed walk), while neither the series coefficients nor the Gaussian run sums are live
         // (also on spans without any far line - windows just above the kernel's limit, grid ends: their interior lines
         // are all near, [iF1, iF2) = [iB, iC))
-        const bool edges_done = EDGE_SKEW && !(J.ablate & 8);
+        const bool edges_done = EDGE_SKEW && !LBL_ABLATE(J, 8);
         if (edges_done)
             skew_edges<R>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, lh, lc, s_ecnt[EDGE_SKEW ? wave : 0][0],
                           s_ecnt[EDGE_SKEW ? wave : 0][1], lane, S);
@@ -1395,7 +1428,6 @@ __global__ __launch_bounds__(256, 4) void xsec_accumulate_skew_kernel(const Accu
     };
     // every centre of [iA, iD) lies in [wlo - H, whi + H], so these differences fit an int
     auto slot = [&](int c, int base) { const int i = c - base + 1; return i < 0 ? 0 : (i > 64 * R + 1 ? 64 * R + 1 : i); };
-    const int ablate = J.ablate;
     int it = 0;
     if (lane == 0) {                                      // the sentinel: centre at the span start, a2 = 1, K = 0, no Gaussian reach
         lh[SKEW_CH * 4] = (double)wlo; lh[SKEW_CH * 4 + 1] = 1.0; lh[SKEW_CH * 4 + 2] = 0.0; lh[SKEW_CH * 4 + 3] = 0.0;
@@ -1448,7 +1480,7 @@ __global__ __launch_bounds__(256, 4) void xsec_accumulate_skew_kernel(const Accu
         // Gaussian ranges from the largest reach of the chunk: records with centre in [p0 - g, p0 + R-1 + g], g = reach - 1
         int g_lo = 0, g_hi = 0;
         const int gmax = wave_max_i32(reach);
-        if (gmax > 0 && !(ablate & 1)) {
+        if (gmax > 0 && !LBL_ABLATE(J, 1)) {
             const int g = gmax - 1;
             zero_counters();
 #pragma unroll
@@ -1465,8 +1497,8 @@ __global__ __launch_bounds__(256, 4) void xsec_accumulate_skew_kernel(const Accu
             skew_counts<R>(cntR, lane, unused, g_hi);
             g_lo = max(g_lo, a_part); g_hi = min(g_hi, b_part);             // only lines whose support reaches the lane's points
         }
-        if (!(ablate & 2)) skew_lorentz<R, true, true>(lh, SKEW_CH, a_part, a_full - a_part, b_full, b_part - b_full, x0, Hf, S, it);
-        if (!(ablate & 4)) skew_lorentz<R, false, false>(lh, SKEW_CH, a_full, b_full - a_full, 0, 0, x0, Hf, S, it);
+        if (!LBL_ABLATE(J, 2)) skew_lorentz<R, true, true>(lh, SKEW_CH, a_part, a_full - a_part, b_full, b_part - b_full, x0, Hf, S, it);
+        if (!LBL_ABLATE(J, 4)) skew_lorentz<R, false, false>(lh, SKEW_CH, a_full, b_full - a_full, 0, 0, x0, Hf, S, it);
         // a record within reach g of a lane's block has |d| <= g + R - 1 at every point of the lane
         if (gmax + R - 2 <= H) skew_gauss<R, false>(lh, COLD, SKEW_CH, g_lo, g_hi, x0, Hf, S);
         else skew_gauss<R, true>(lh, COLD, SKEW_CH, g_lo, g_hi, x0, Hf, S);
@@ -1923,7 +1955,7 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
             const int f = A.term_flags[t];
 #pragma unroll
             for (int p = 0; p < NP; ++p) xs[p] += v[p];
-            if (A.ablate & 16) { I[0] += v[0]; return; }           // (diagnostics: memory traffic only)
+            if (LBL_ABLATE(A, 16)) { I[0] += v[0]; return; }       // (diagnostic builds: memory traffic only)
             if (f & TERM_LAST_MOL) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) { kk[p] += abs_coef_term(xs[p], A.term_conc[t], A.term_P[t], A.term_T[t], A.term_rT[t]); xs[p] = 0.0; }
@@ -1951,12 +1983,12 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
         for (int u = 0; u < NB; ++u) { cur[u] = (vec)(0.0); nxt[u] = (vec)(0.0); }
         if (n_full > 0) {
 #pragma unroll
-            for (int u = 0; u < NB; ++u) cur[u] = (A.ablate & 32) ? (vec)(1e-22 * (double)(j & 7)) : load(A.xsec[u], j);
+            for (int u = 0; u < NB; ++u) cur[u] = LBL_ABLATE(A, 32) ? (vec)(1e-22 * (double)(j & 7)) : load(A.xsec[u], j);
         }
         for (int t0 = 0; t0 < n_full; t0 += NB) {
             if (t0 + NB < n_full) {
 #pragma unroll
-                for (int u = 0; u < NB; ++u) nxt[u] = (A.ablate & 32) ? (vec)(1e-22 * (double)(j & 7)) : load(A.xsec[t0 + NB + u], j);
+                for (int u = 0; u < NB; ++u) nxt[u] = LBL_ABLATE(A, 32) ? (vec)(1e-22 * (double)(j & 7)) : load(A.xsec[t0 + NB + u], j);
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u) term(t0 + u, cur[u]);
@@ -2043,6 +2075,12 @@ void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStrea
     hipLaunchKernelGGL(line_prep_kernel, grid, dim3(256), 0, s, d_jobs);
 }
 
+void launch_line_quantities(const PrepJob* d_job, int n_lines, long long* index, double* lhw, double* ghw, double* intensity,
+                            int32_t* regime, hipStream_t s) {
+    if (n_lines <= 0) return;
+    hipLaunchKernelGGL(line_quantities_kernel, dim3((n_lines + 255) / 256), dim3(256), 0, s, d_job, index, lhw, ghw, intensity, regime);
+}
+
 template <int R>
 static void launch_accum_scalar(const AccumJob* d_jobs, int n_jobs, int max_tiles, int variant, hipStream_t s) {
     dim3 grid(((max_tiles + 7) / 8) * 8, n_jobs);
@@ -2061,8 +2099,11 @@ static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, 
         if (total_tiles <= 0) return;
         grid = dim3(total_tiles, 1);
     }
-    // diagnostics only (scripts/cost_fit.py): unused dynamic LDS to limit the workgroups resident per CU
+#ifdef LBL_DIAG        // (scripts/cost_fit.py): unused dynamic LDS to limit the workgroups resident per CU
     static const int pad = getenv("LBL_DIAG_LDS_PAD") ? atoi(getenv("LBL_DIAG_LDS_PAD")) : 0;
+#else
+    constexpr int pad = 0;
+#endif
     switch (LS) {
         case 8: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 8, FF>), grid, dim3(512), pad, s, d_jobs, worklist); break;
         case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
@@ -2138,14 +2179,22 @@ void launch_regrid(const double* work, long long n_work, double* out, long long 
 }
 
 static int sweep_blocks(long long n) {       // (one point per thread on a larger grid measured no faster: 442 vs 433 us for the column)
+#ifdef LBL_DIAG
     static const long long cap = getenv("LBL_DIAG_SWEEP_BLOCKS") ? atoll(getenv("LBL_DIAG_SWEEP_BLOCKS")) : 4096;
+#else
+    constexpr long long cap = 4096;
+#endif
     long long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 template <bool NT>
 static void launch_layer_sweep_nt(const SweepArgs& a, hipStream_t s) {
+#ifdef LBL_DIAG
     static const bool pairs = !getenv("LBL_DIAG_SWEEP_NP1");
+#else
+    constexpr bool pairs = true;
+#endif
     if (pairs && (a.first & 1) == 0 && a.count >= 2) {      // two points per thread with 16-byte accesses; an odd last point by itself
         SweepArgs m = a;
         m.count = a.count & ~1LL;
@@ -2168,7 +2217,11 @@ void launch_layer_sweep(const SweepArgs& a, hipStream_t s) {
 
 void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s) {
     if (count <= 0) return;
+#ifdef LBL_DIAG
     static const bool pairs = !getenv("LBL_DIAG_COLUMN_NP1");
+#else
+    constexpr bool pairs = true;
+#endif
     if (pairs && (first & 1) == 0 && count >= 2) {     // two points per thread with 16-byte loads; an odd last point by itself
         const long long even = count & ~1LL;
         hipLaunchKernelGGL(column_step_kernel<2>, dim3(sweep_blocks(even / 2)), dim3(256), 0, s, d_args, first, even);

@@ -170,6 +170,36 @@ def as_plan(shard, n_work):
     return equal_plan(n_work, world, rank) if world > 1 else None
 
 
+class StepGraph:
+    """A resident step as one hipGraph launch, captured again by itself when the library reports the graph
+    stale (LBL_ERR_STATE: a scratch buffer grew, a descriptor slot was rewritten, or ANY buffer or line list of
+    the context was destroyed since the capture - e.g. a temporary of pyrad_amd.model sharing the context).
+    The stale launch is not lost: the step is enqueued kernel by kernel once, which also re-creates whatever the
+    capture needs, and recorded for the launches that follow."""
+
+    def __init__(self, owner, enqueue_kwargs):
+        self.owner, self.kwargs = owner, dict(enqueue_kwargs)
+        self.recaptures = 0
+        owner.enqueue(**self.kwargs)               # scratch, schedules and descriptors exist before the capture
+        self.g = owner.ctx.capture(lambda: owner.enqueue(**self.kwargs))
+
+    def launch(self):
+        try:
+            self.g.launch()
+        except nat.LblError as e:
+            if e.code != -6:
+                raise
+            self.g.free()
+            self.owner.enqueue(**self.kwargs)      # this step, kernel by kernel
+            self.g = self.owner.ctx.capture(lambda: self.owner.enqueue(**self.kwargs))
+            self.recaptures += 1
+
+    def free(self):
+        if self.g is not None:
+            self.g.free()
+            self.g = None
+
+
 class ResidentLayer:
     """One layer (gas cell) whose line lists, cross sections and spectra live in HBM.
 
@@ -289,14 +319,13 @@ class ResidentLayer:
         self.enqueue_xsec()
         self.enqueue_sweep(I_in=I_in, surface_T=surface_T)
 
-    def capture_step(self, **enqueue_kwargs) -> nat.Graph:
+    def capture_step(self, **enqueue_kwargs) -> StepGraph:
         """Capture this layer's step (``enqueue(**enqueue_kwargs)``) into a graph: run once so that scratch,
         schedule and descriptors exist, then record.  ``graph.launch()`` replays line prep, accumulate
         and sweep with one host call."""
         if self.empty:
             return None
-        self.enqueue(**enqueue_kwargs)
-        return self.ctx.capture(lambda: self.enqueue(**enqueue_kwargs))
+        return StepGraph(self, enqueue_kwargs)
 
     def send_range(self):
         """(offset, S): the S doubles of a spectrum buffer this rank contributes to the all-gather"""
@@ -431,12 +460,11 @@ class ResidentColumn:
                                   self.layers[0].range_min, self.layers[0].range_max, self.n, self.I_toa,
                                   surface_T=self.surface_T, first=first, count=count)
 
-    def capture_step(self, **enqueue_kwargs) -> nat.Graph:
+    def capture_step(self, **enqueue_kwargs) -> StepGraph:
         """The column step (all layers' line prep + accumulate launches + the column fold) as one graph."""
         if self.empty:
             return None
-        self.enqueue(**enqueue_kwargs)
-        return self.ctx.capture(lambda: self.enqueue(**enqueue_kwargs))
+        return StepGraph(self, enqueue_kwargs)
 
     def send_range(self):
         """(offset, S): the S doubles of the outgoing spectrum this rank contributes to the all-gather"""

@@ -11,13 +11,19 @@ ctx = nat.Context(0)
 for k in ("R", "LS"):
     if os.environ.get(k):
         ctx.set_option({"R": "accum_points_per_lane", "LS": "accum_line_split"}[k], int(os.environ[k]))
-cfg, _ = bench.build_workload("C2", scale)
+workload = os.environ.get("WORKLOAD", "C2")        # WORKLOAD=C3 SHARD=8,4: one shard of 8 of the mixed cell
+cfg, _ = bench.build_workload(workload, scale)
+shard = None
+if os.environ.get("SHARD"):
+    G, r = (int(v) for v in os.environ["SHARD"].split(","))
+    shard = (G, r)
 L = engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"], bench.molecules_of(cfg),
-                         cfg["base_resolution"], False)
+                         cfg["base_resolution"], False, shard=shard)
 for _ in range(3):
     L.enqueue_xsec()
 ctx.sync()
-nb = 8 * ((L.n // (64 * int(os.environ.get("R", "4")) * (4 // int(os.environ.get("LS", "2")))) + 8) // 8)
+pts = L.count * len(L.jobs)
+nb = 8 * ((pts // (64 * int(os.environ.get("R", "4")) * (4 // int(os.environ.get("LS", "1" if workload != "C2" else "2")))) + 8) // 8)
 n = nb * 4 * 3
 buf = (C.c_uint64 * n)()
 ctx.lib.lbl_debug_times.restype = C.c_int
