@@ -203,8 +203,30 @@ def api_path(cfg, reps=5):
             spec = layer.transmission(surf)
             t_trans.append(time.perf_counter() - t0)
         ms_call = 1e3 * float(np.median(t_call))
+        # re-windowing (pyradClasses.py:734-752 -> resetData, cls:45-56): the mutator re-reads the lines of the new window,
+        # the next getter computes on it - new line selection (a view of the resident list), a new dispatch schedule
+        # (built on the device, in stream), line prep, accumulate, sweep, one download
+        t_mut_p, t_get_p, t_mut_r, t_get_r = [], [], [], []
+        P0, r0 = cfg["P"], (cfg["range_min"], cfg["range_max"])
+        width = r0[1] - r0[0]
+        for i in range(reps):
+            P_new = P0 * (0.9 - 0.02 * i)
+            t0 = time.perf_counter(); layer.changePressure(P_new); t_mut_p.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); k2 = model.getAbsCoef(layer); t_get_p.append(time.perf_counter() - t0)
+        layer.changePressure(P0)
+        for i in range(reps):
+            a, b = r0[0] + width * 0.02 * (i + 1), r0[1] - width * 0.02 * (i + 1)
+            t0 = time.perf_counter(); layer.changeRange(a, b); t_mut_r.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); k2 = model.getAbsCoef(layer); t_get_r.append(time.perf_counter() - t0)
+        layer.changeRange(*r0)
+        med = lambda v: 1e3 * float(np.median(v))
         return {"ms_per_call": ms_call, "evals_per_s": evals / (ms_call * 1e-3),
                 "ms_transmission": 1e3 * float(np.median(t_trans)),
+                "ms_change_pressure": med(t_get_p), "ms_change_pressure_mutator": med(t_mut_p),
+                "ms_change_range": med(t_get_r), "ms_change_range_mutator": med(t_mut_r),
+                "rewindow_what": "getAbsCoef AFTER layer.changePressure / layer.changeRange (each to a window not seen before: new "
+                                 "line selection, new dispatch schedule, recompute, one download; finite %s); *_mutator = the "
+                                 "changePressure / changeRange call itself (host: re-reading the window's lines)" % bool(np.isfinite(k2).all()),
                 "ms_build_layer": 1e3 * t_build, "ms_first_call": 1e3 * t_first, "bytes_downloaded_per_call": 8 * int(k.size),
                 "what": "model.getAbsCoef(layer) after layer.changeTemperature (recompute on resident line lists + download "
                         "of the absorption coefficient); ms_transmission = layer.transmission(host spectrum): upload, fold "
@@ -250,7 +272,21 @@ def api_path_column(cfg, reps=3):
             spec = atm.transmission(surfaceTemperature=cfg["surface_T"])
             t_call.append(time.perf_counter() - t0)
         ms_call = 1e3 * float(np.median(t_call))
+        # re-windowing every layer of the column (pyradClasses.py:745-752): 1 % lower pressures, then back
+        t_mut, t_get = [], []
+        for f in (0.99, 1.0):
+            t0 = time.perf_counter()
+            for L, c in zip(atm, cfg["layers"]):
+                L.changePressure(c["P"] * f)
+            t_mut.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            spec = atm.transmission(surfaceTemperature=cfg["surface_T"])
+            t_get.append(time.perf_counter() - t0)
         return {"ms_per_call": ms_call, "evals_per_s": evals / (ms_call * 1e-3), "ms_build_atmosphere": 1e3 * t_build,
+                "ms_change_pressure": 1e3 * float(np.median(t_get)), "ms_change_pressure_mutator": 1e3 * float(np.median(t_mut)),
+                "rewindow_what": "Atmosphere.transmission AFTER changePressure on every layer (new windows: new line selections, "
+                                 "new dispatch schedules built on the device, recompute, one download); *_mutator = the %d "
+                                 "changePressure calls themselves" % len(cfg["layers"]),
                 "ms_first_call": 1e3 * t_first, "bytes_downloaded_per_call": 8 * int(spec.size),
                 "what": "model.Atmosphere.transmission(surfaceTemperature) after changeTemperature on all %d layers "
                         "(recompute on resident line lists, column step, download of the outgoing spectrum); median of %d; "
@@ -559,6 +595,9 @@ def main():
     ap.add_argument("--in-flight", default="auto", choices=["auto", "1", "2", "3"],
                     help="independent steps in flight per rank, each on a HIP stream (context) of its own; auto: 1 "
                          "(see steps_in_flight)")
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="the steady state is timed in this many blocks of --steps steps: block 0 is the timed region "
+                         "(ms_per_step, value); the others only feed ms_per_step_blocks (median, spread)")
     ap.add_argument("--check", action="store_true", help="also compare one shard against the oracle (slow)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="experiment: lbl_set_option(KEY, VALUE) on every context (e.g. accum_skew=0)")
@@ -629,7 +668,8 @@ def main():
         ctx.set_option("accum_longest_first", args.longest_first)
     for kv in args.set:
         key, _, val = kv.partition("=")
-        ctx.set_option(key, int(val))
+        ctx.set_option(key, int(val))          # ("debug_*" keys exist in diagnostic builds of the library only)
+    ablated = any(kv.partition("=")[0].startswith("debug_") and int(kv.partition("=")[2]) != 0 for kv in args.set)
 
     comm = None
     rdzv = None
@@ -749,6 +789,16 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
     prof = ctx.profile_read()
+    # Steady state once more in blocks of `steps` (no timing events inside, barrier on both sides of each): the timed
+    # region above is the driver-checked figure, these say how much a block of that length scatters on this box
+    block_ms = [elapsed / args.steps * 1e3]
+    for _ in range(max(0, args.blocks - 1)):
+        barrier()
+        t_b0 = time.perf_counter()
+        for k in range(args.steps):
+            step()
+        barrier()
+        block_ms.append((time.perf_counter() - t_b0) / args.steps * 1e3)
     ctx.profile_enable(["line_prep", "regrid", "layer_sweep", "column_sweep"] + ([] if overlap_gather else ["allgather"]))
     ctx.profile_reset()
     n_extra = max(2, min(5, args.steps))
@@ -1012,13 +1062,26 @@ def main():
                                                  if pmc["avg_us"].get(sweep_kernel) else None},
             "kernel_ms_per_step": {"line_prep": ms_prep / args.steps, "xsec_accumulate": ms_acc / max(n_sampled, 1),
                                    ("column_step" if is_column else "layer_sweep"): ms_sw / args.steps,
-                                   "allgather": ms_ag / args.steps},
+                                   "allgather": ms_ag / args.steps,
+                                   "source": "xsec_accumulate: HIP events around its launches in every %d-th step OF THE TIMED REGION "
+                                             "(%d of %d steps); line_prep, sweep%s: a SEPARATE pass of %d steps after it, every launch "
+                                             "bracketed (a pair of event records costs the stream a few microseconds, so the parts "
+                                             "can sum to more than ms_per_step)" % (every, n_sampled, args.steps,
+                                                                                   "" if overlap_gather else ", allgather", n_extra)},
+            "ms_per_step_blocks": {"blocks": [round(v, 6) for v in block_ms], "median": float(np.median(block_ms)),
+                                   "min": float(np.min(block_ms)), "max": float(np.max(block_ms)),
+                                   "spread_rel": float((np.max(block_ms) - np.min(block_ms)) / np.median(block_ms)),
+                                   "what": "max over ranks is NOT taken here (rank 0's clock between barriers); block 0 is the "
+                                           "timed region that ms_per_step and value come from"},
             "setup_s": t_setup,
         }
         vb = result["valu_f64"]
         if vb.get("direct_kernel_evals_per_s"):
             result["value_direct_kernel"] = vb["direct_kernel_evals_per_s"]
             result["direct_frac"] = vb.get("direct_frac")
+        if ablated:
+            result["ablated"] = True
+            result["invalid"] = "a debug_* option was set: parts of the kernels are switched off, results are wrong, timing experiment only"
         if breakdown is not None:
             result["sharded_step_breakdown"] = breakdown
         if not args.no_cpu_baseline and world == 1:

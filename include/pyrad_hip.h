@@ -137,6 +137,10 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "debug_ablate"           ONLY in diagnostic builds of the library (make EXTRA=-DLBL_DIAG): timing experiments,
  *                            bits switch off parts of kernels, results are wrong.  The production library has no
  *                            such code in its kernels and answers LBL_ERR_BAD_ARG (unknown option)
+ *   "schedule_build"         1 (default) span tables and dispatch order of a launch group are built on the device, in
+ *                            stream, by the first batch that uses them (no host search, no copy, no wait) | 0 on the host
+ *                            (one thread; 4 ms for the 100-2500 cm^-1 cell, 80 ms for a 30-layer column).  Same tables,
+ *                            same results; other "accum_longest_first" values than 4 always build on the host
  *   "layer_step_fused"       1 (default) lbl_layer_step_dev folds the sweep of a single-line-list layer into the
  *                            accumulate kernel | 0 always accumulate launch + sweep launch (bit-identical; A/B)
  *   "debug_throw"            test hook: 1 / 2 / 3 raise std::bad_alloc / std::runtime_error /
@@ -209,6 +213,15 @@ int lbl_xsec_accumulate_dev(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
 /* Regime counters of the most recent lbl_xsec_accumulate_dev (drains the stream):
  * counts[3*j + {0,1,2}] = {gaussian, lorentz, voigt} of job j. */
 int lbl_last_regime_counts(lbl_ctx* ctx, int n_jobs, int64_t* counts);
+/* Introspection for tests: the k-th most recently used dispatch schedule of the context (0 = the last one an
+ * accumulate batch used).  list receives 2 ints per workgroup (job of the launch group, tile of the job), tabs 8 ints
+ * per span of 64 R points {iA, iB, iC, iD, iF1, iF2, 0, 0} (the lower bounds of the span's edge / interior / far lines
+ * in the job's sorted centre indices).  Either array may be NULL; *n_items / *n_tab_ints are always set.
+ * built_on_device: 1 when the schedule came from the in-stream device build ("schedule_build" 1, the default),
+ * 0 from the host. */
+int lbl_schedule_export(lbl_ctx* ctx, int k, int32_t* list, int64_t list_cap, int32_t* tabs, int64_t tabs_cap,
+                        int64_t* n_items, int64_t* n_tab_ints, int32_t* built_on_device);
+
 /* Parity aid: runs the real line preparation (K1) of this one job and reports, per line, the centre index
  * K1 wrote (pyradClasses.py:390; the very value the accumulate kernel works from, clamped to +-2e9), and the
  * Lorentz and Doppler half-widths (pyradClasses.py:256-263), the corrected intensity (pyradIntensity.py:30-32)

@@ -81,6 +81,8 @@ SIGNATURES = {
                                       C.POINTER(Grid), _P, C.POINTER(C.c_int64)]),
     "lbl_xsec_accumulate_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(IsoParams), C.POINTER(Grid),
                                           C.POINTER(_P)]),
+    "lbl_schedule_export": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int32)]),
     "lbl_last_regime_counts": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     "lbl_line_quantities": (C.c_int, [_P, _P, C.POINTER(IsoParams), C.POINTER(Grid), _P, _P, _P, _P, _P]),
     "lbl_layer_sweep_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int, _D,
@@ -347,6 +349,15 @@ class Context:
         O = (_P * n)(*[j[3].h for j in jobs])
         self.check(self.lib.lbl_xsec_accumulate_dev(self.h, n, L, I, G, O))
 
+    def schedule_export(self, k: int = 0):
+        """(list[n, 2] of (job, tile), tabs[spans, 8], built_on_device) of the k-th most recently used schedule."""
+        n = C.c_int64(); nt = C.c_int64(); dev = C.c_int32()
+        self.check(self.lib.lbl_schedule_export(self.h, int(k), None, 0, None, 0, C.byref(n), C.byref(nt), C.byref(dev)))
+        lst = np.empty((n.value, 2), np.int32); tabs = np.empty((max(nt.value, 0) // 8, 8), np.int32)
+        self.check(self.lib.lbl_schedule_export(self.h, int(k), _ptr(lst), lst.size, _ptr(tabs), tabs.size, C.byref(n),
+                                                C.byref(nt), C.byref(dev)))
+        return lst, tabs, bool(dev.value)
+
     def last_regime_counts(self, n_jobs: int):
         counts = (C.c_int64 * (3 * n_jobs))()
         self.check(self.lib.lbl_last_regime_counts(self.h, n_jobs, counts))
@@ -536,6 +547,9 @@ class Lines:
         ctx.check(ctx.lib.lbl_lines_create(ctx.h, *[_ptr(a) for a in arrs], self.n, C.byref(h)))
         self.h = h
         ctx._children.append(self)
+
+    def has_views(self) -> bool:
+        return any(isinstance(c, Lines) and c._parent is self and c.h for c in self.ctx._children)
 
     def view(self, first: int, count: int) -> "Lines":
         """``count`` consecutive lines from line ``first`` on (sorted order), sharing this list's device arrays

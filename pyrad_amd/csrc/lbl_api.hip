@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -71,8 +72,24 @@ struct lbl_ctx {
     int accum_LS = 0;        // waves sharing one span of points (line split), 0 = choose per launch
     int bal_workers[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident wavefronts of the balanced kernel per R (cached)
     // schedule cache: (job, tile) lists sorted longest first, per launch group
-    struct Schedule { std::vector<uint64_t> key; int2* d_list; int total; int32_t* d_tabs; std::vector<size_t> tab_off; };
-    std::vector<Schedule> schedules;
+    struct Schedule {
+        std::vector<uint64_t> key; int2* d_list; int total; int32_t* d_tabs; std::vector<size_t> tab_off;
+        void* d_block = nullptr;              // the one allocation d_list and d_tabs live in
+        // device build (launch_schedule_build): enqueued by the first batch that uses the schedule, right after its
+        // line prep; until then d_list / d_tabs are uninitialised
+        bool pending = false;
+        int R = 0, spans_per_tile = 0, total_spans = 0;
+        long long far_reach = 0;
+        double cost_near = 0, cost_edge = 0, cost_far = 0, cost_fixed = 0;
+        std::vector<int32_t> span_first, tile_first;
+    };
+    std::vector<std::unique_ptr<Schedule>> schedules;
+    int accuracy = 0;        // 0 exact (default): every result as close to the reference's fp64 as the arithmetic allows (1e-14);
+                             // 1 budget: <= 1e-9 relative on the absorption coefficient (north_star asks 1e-6), still fp64:
+                             // 18 instead of 30 far-field terms, Gaussian cut-off at 2^-34 instead of 2^-54 of the line's
+                             // Lorentz term, one-factor absorption coefficient and cheaper Planck / exp in the sweeps
+    int sched_build = 1;     // 1 (default): span tables and dispatch order built on the device, in stream; 0: on the host
+    DeviceArena sched;       // scratch of the device build
     uint64_t lines_serial = 0;
     int lpt = 4;             // longest-first worklist: 4 (default) = 3 + XCD-partitioned when the launch has several rounds; 3 bin-packed per CU when the launch is one round; 2 snake; 1 plain; 0 positional
     int tile_order = 1;      // 1: natural order (default; measured 8 % faster on the clustered C2 grid:
@@ -344,10 +361,10 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) try {
     if (ctx->accum_done) (void)hipEventDestroy(ctx->accum_done);
     for (auto& v : ctx->ev_rec) for (auto& p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    for (auto& sc : ctx->schedules) { if (sc.d_list) (void)hipFree(sc.d_list); if (sc.d_tabs) (void)hipFree(sc.d_tabs); }
+    for (auto& sc : ctx->schedules) if (sc->d_block) (void)hipFree(sc->d_block);
     for (auto& e : ctx->desc_cache) if (e.dptr) (void)hipFree(e.dptr);
     for (auto& e : ctx->arg_cache) if (e.dptr) (void)hipFree(e.dptr);
-    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->bal, &ctx->red, &ctx->zeros};
+    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->bal, &ctx->red, &ctx->zeros, &ctx->sched};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     (void)hipStreamDestroy(ctx->stream);
@@ -477,6 +494,12 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) try {
     } else if (!strcmp(key, "debug_ablate")) {
         ctx->ablate = value;        // diagnostic builds only, timing experiments: results are wrong when non-zero
 #endif
+    } else if (!strcmp(key, "accuracy")) {
+        if (value < 0 || value > 1) return fail(ctx, LBL_ERR_BAD_ARG, "accuracy must be 0 (exact) or 1 (budget: 1e-9)");
+        ctx->accuracy = value;
+    } else if (!strcmp(key, "schedule_build")) {
+        if (value < 0 || value > 1) return fail(ctx, LBL_ERR_BAD_ARG, "schedule_build must be 0 (host) or 1 (device)");
+        ctx->sched_build = value;
     } else if (!strcmp(key, "layer_step_fused")) {
         if (value < 0 || value > 1) return fail(ctx, LBL_ERR_BAD_ARG, "layer_step_fused must be 0 or 1");
         ctx->no_fuse = value == 0;
@@ -755,14 +778,14 @@ static void choose_shape(const lbl_ctx* ctx, int variant, long long total_points
 #ifndef LBL_COST_GAUSS
 #define LBL_COST_GAUSS 15.0      // wave-instructions a near line's Gaussian passes add per span (0.6 passes of ~25; 29 before the 16-point runs)
 #endif
-static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::vector<int>& jobs_in_group,
-                                               lbl_lines* const* lines, const lbl_grid* grid, int R, int LS, long long tile_pts) {
+static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::vector<int>& jobs_in_group,
+                                         lbl_lines* const* lines, const lbl_grid* grid, int R, int LS, long long tile_pts) {
     std::vector<uint64_t> key;
     const bool far_field = variant == 5;
     int far_half_spans = 0;
     double far_cost = 1.0;
     if (far_field) accumulate_far_field_params(R, &far_half_spans, &far_cost);
-    key.push_back((uint64_t)R << 32 | (uint64_t)LS << 8 | (uint64_t)ctx->lpt << 1 | (uint64_t)far_field);
+    key.push_back((uint64_t)R << 32 | (uint64_t)LS << 8 | (uint64_t)ctx->sched_build << 4 | (uint64_t)ctx->lpt << 1 | (uint64_t)far_field);
     for (int j : jobs_in_group) {
         long long sf, sc;
         shard_range(grid[j], &sf, &sc);
@@ -773,13 +796,65 @@ static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const 
         key.push_back((uint64_t)sf); key.push_back((uint64_t)sc); key.push_back((uint64_t)grid[j].window);
     }
     for (size_t i = 0; i < ctx->schedules.size(); ++i)
-        if (ctx->schedules[i].key == key) {
+        if (ctx->schedules[i]->key == key) {
             // least recently used at the front: an entry handed out in this call is never the next to go
             std::rotate(ctx->schedules.begin() + i, ctx->schedules.begin() + i + 1, ctx->schedules.end());
-            return &ctx->schedules.back();
+            return ctx->schedules.back().get();
         }
     if (ctx->capturing) { (void)capture_refuses(ctx, "building a dispatch schedule"); return nullptr; }
     TraceScope tr("group_schedule", (long long)jobs_in_group.size());
+    auto evict_oldest = [&]() {
+        if (ctx->schedules.size() >= 16) {                    // small cache: drop the oldest entry
+            ctx->epoch++;
+            (void)hipStreamSynchronize(ctx->stream);
+            if (ctx->schedules.front()->d_block) (void)hipFree(ctx->schedules.front()->d_block);
+            ctx->schedules.erase(ctx->schedules.begin());
+        }
+    };
+    auto one_block = [&](size_t n_items, size_t n_tab_ints, int2** d_list, int32_t** d_tabs) -> void* {
+        const size_t list_bytes = (std::max<size_t>(n_items, 1) * sizeof(int2) + 255) & ~(size_t)255;
+        void* blk = nullptr;
+        if (hipMalloc(&blk, list_bytes + std::max<size_t>(n_tab_ints, 8) * sizeof(int32_t)) != hipSuccess) return nullptr;
+        *d_list = (int2*)blk;
+        *d_tabs = (int32_t*)((char*)blk + list_bytes);
+        return blk;
+    };
+    {
+        // Device build: only the sizes are worked out here; the tables and the order are produced in stream by the first
+        // batch that uses the schedule (enqueue_accumulate, after its line prep has written the centre indices).
+        long long n_items = 0, n_spans_all = 0;
+        for (int j : jobs_in_group) {
+            long long sf, sc;
+            shard_range(grid[j], &sf, &sc);
+            n_items += (sc + tile_pts - 1) / tile_pts;
+            n_spans_all += (sc + 64LL * R - 1) / (64LL * R);
+        }
+        const int n_cu_i = ctx->n_cu > 0 ? ctx->n_cu : 256;
+        if (ctx->sched_build == 1 && ctx->lpt == 4 && n_items > 0 && n_spans_all < (1LL << 27) &&
+            sched_device_supported((int)n_items, n_cu_i)) {
+            std::unique_ptr<lbl_ctx::Schedule> S(new lbl_ctx::Schedule());
+            S->key = key;
+            S->R = R; S->spans_per_tile = (int)(tile_pts / (64LL * R));
+            S->far_reach = far_field ? (long long)far_half_spans * 32 * R : 0;
+            S->cost_near = 5.0 * R + LBL_COST_GAUSS; S->cost_edge = 8.0 * R; S->cost_far = far_cost * 5.0 * R; S->cost_fixed = 600.0;
+            int32_t span_run = 0, tile_run = 0;
+            for (int j : jobs_in_group) {
+                long long sf, sc;
+                shard_range(grid[j], &sf, &sc);
+                S->tab_off.push_back((size_t)span_run * 8);
+                S->span_first.push_back(span_run); S->tile_first.push_back(tile_run);
+                span_run += (int32_t)((sc + 64LL * R - 1) / (64LL * R));
+                tile_run += (int32_t)((sc + tile_pts - 1) / tile_pts);
+            }
+            S->total_spans = span_run; S->total = tile_run;
+            S->d_block = one_block((size_t)tile_run, (size_t)span_run * 8, &S->d_list, &S->d_tabs);
+            if (!S->d_block) return nullptr;
+            S->pending = true;
+            evict_oldest();
+            ctx->schedules.push_back(std::move(S));
+            return ctx->schedules.back().get();
+        }
+    }
     struct Item { int count, job, tile; };
     std::vector<Item> items;
     std::vector<long long> idx;
@@ -913,22 +988,19 @@ static const lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const 
     for (size_t i = 0; i < items.size(); ++i) { host[i].x = items[i].job; host[i].y = items[i].tile; }
     int2* d_list = nullptr;
     int32_t* d_tabs = nullptr;
-    if (hipMalloc((void**)&d_list, std::max<size_t>(host.size(), 1) * sizeof(int2)) != hipSuccess) return nullptr;
-    if (hipMalloc((void**)&d_tabs, std::max<size_t>(tabs.size(), 8) * sizeof(int32_t)) != hipSuccess) { (void)hipFree(d_list); return nullptr; }
+    void* blk = one_block(host.size(), tabs.size(), &d_list, &d_tabs);
+    if (!blk) return nullptr;
     if ((!host.empty() && hipMemcpy(d_list, host.data(), host.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) ||
         (!tabs.empty() && hipMemcpy(d_tabs, tabs.data(), tabs.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)) {
-        (void)hipFree(d_list); (void)hipFree(d_tabs);
+        (void)hipFree(blk);
         return nullptr;
     }
-    if (ctx->schedules.size() >= 16) {                    // small cache: drop the oldest entry
-        ctx->epoch++;
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(ctx->schedules.front().d_list);
-        (void)hipFree(ctx->schedules.front().d_tabs);
-        ctx->schedules.erase(ctx->schedules.begin());
-    }
-    ctx->schedules.push_back({key, d_list, (int)host.size(), d_tabs, tab_off});
-    return &ctx->schedules.back();
+    evict_oldest();
+    std::unique_ptr<lbl_ctx::Schedule> S(new lbl_ctx::Schedule());
+    S->key = key; S->d_list = d_list; S->total = (int)host.size(); S->d_tabs = d_tabs; S->tab_off = tab_off; S->d_block = blk;
+    S->total_spans = -(int)(tabs.size() / 8);          // (negative: built on the host; lbl_schedule_export)
+    ctx->schedules.push_back(std::move(S));
+    return ctx->schedules.back().get();
 }
 
 static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines, const lbl_iso_params* iso,
@@ -1009,7 +1081,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     std::vector<int> order(n_jobs);
     for (int j = 0; j < n_jobs; ++j) order[j] = j;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return group_key(a) > group_key(b); });
-    struct Group { int first, count, R, LS, max_tiles, variant; const int2* worklist; int total_tiles; const int32_t* tabs; std::vector<size_t> tab_off; };
+    struct Group { int first, count, R, LS, max_tiles, variant; const int2* worklist; int total_tiles; const int32_t* tabs; std::vector<size_t> tab_off; lbl_ctx::Schedule* sched; };
     std::vector<Group> groups;
     for (int k = 0; k < n_jobs;) {
         int e = k;
@@ -1022,7 +1094,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             mh = std::min(mh, H); mxh = std::max(mxh, H);
             ++e;
         }
-        Group g{k, e - k, 0, 0, 0, ctx->accum_variant, nullptr, 0, nullptr, {}};
+        Group g{k, e - k, 0, 0, 0, ctx->accum_variant, nullptr, 0, nullptr, {}, nullptr};
         if (is_skew(order[k])) {
             g.R = ctx->skew_R; g.LS = 1; g.variant = 6;
         } else {
@@ -1033,10 +1105,11 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         if ((g.variant == 3 || g.variant == 5 || g.variant == 6) && ctx->lpt) {
             // cached host schedule of this group: dispatch order + the line ranges of every span
             std::vector<int> members(order.begin() + k, order.begin() + e);
-            const lbl_ctx::Schedule* sc = group_schedule(ctx, g.variant == 6 ? 3 : g.variant, members, lines, grid, g.R, g.LS,
-                                                         accumulate_tile_points(g.R, g.LS, g.variant));
+            lbl_ctx::Schedule* sc = group_schedule(ctx, g.variant == 6 ? 3 : g.variant, members, lines, grid, g.R, g.LS,
+                                                   accumulate_tile_points(g.R, g.LS, g.variant));
             if (!sc) return ctx->capturing ? LBL_ERR_STATE : fail(ctx, LBL_ERR_OOM, "schedule allocation failed");
-            g.worklist = sc->d_list; g.total_tiles = sc->total; g.tabs = sc->d_tabs; g.tab_off = sc->tab_off;
+            if (sc->pending && ctx->capturing) return capture_refuses(ctx, "building a dispatch schedule");
+            g.worklist = sc->d_list; g.total_tiles = sc->total; g.tabs = sc->d_tabs; g.tab_off = sc->tab_off; g.sched = sc;
         }
         groups.push_back(g);
         k = e;
@@ -1061,6 +1134,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         { const double m = iso[j].molmass / 1000.0 / avo; p.ghw_factor = std::sqrt(2.0 * kB * iso[j].T / m / (cLight * cLight)); }
         p.q_ratio = iso[j].Q_296 / iso[j].Q_T;
         p.inv_T = 1.0 / iso[j].T; p.inv_res = 1.0 / grid[j].resolution; p.inv_res2 = p.inv_res * p.inv_res;
+        p.gauss_cut = ctx->accuracy ? 17179869184.0 : 18014398509481984.0;          // 2^34 : 2^54
         p.n_lines = (int32_t)L->n;
     }
     const bool balanced = ctx->accum_variant == 4;
@@ -1151,6 +1225,30 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     ctx->last_jobs = n_jobs;
     ctx->last_prep_desc = dp;
     if (prep_only) return LBL_OK;
+    // schedules that have not been built yet: span tables from the centre indices K1 has just written, tile costs and
+    // the dispatch order, all in stream ahead of the accumulate launches that read them (nothing comes back to the host)
+    for (Group& g : groups) {
+        lbl_ctx::Schedule* sc = g.sched;
+        if (!sc || !sc->pending) continue;
+        TraceScope tr("schedule build (enqueue)", (long long)sc->total);
+        const size_t jobs_bytes = ((size_t)g.count * sizeof(SchedJob) + 255) & ~(size_t)255;
+        if ((rc = arena_reserve(ctx, ctx->sched, jobs_bytes + sched_scratch_bytes(sc->total)))) return rc;
+        void* pinned = nullptr;
+        if ((rc = stage_alloc(ctx, jobs_bytes, &pinned))) return rc;
+        SchedJob* hj = (SchedJob*)pinned;
+        for (int k = g.first; k < g.first + g.count; ++k) {
+            const AccumJob& a = ha[k];
+            SchedJob& sj = hj[k - g.first];
+            sj.cidx = a.cidx; sj.n_lines = a.n_lines; sj.H = a.H; sj.p_begin = a.p_begin; sj.p_end = a.p_end;
+            sj.span_first = sc->span_first[(size_t)(k - g.first)]; sj.tile_first = sc->tile_first[(size_t)(k - g.first)];
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->sched.ptr, pinned, (size_t)g.count * sizeof(SchedJob), hipMemcpyHostToDevice, ctx->stream));
+        launch_schedule_build((const SchedJob*)ctx->sched.ptr, g.count, sc->total_spans, sc->total, sc->R, sc->spans_per_tile,
+                              sc->far_reach, sc->cost_near, sc->cost_edge, sc->cost_far, sc->cost_fixed,
+                              ctx->n_cu > 0 ? ctx->n_cu : 256, sc->d_tabs, (char*)ctx->sched.ptr + jobs_bytes, sc->d_list, ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+        sc->pending = false;
+    }
     // software pipeline of two contexts (lbl_ctx_chain_accumulate): this step's accumulate kernels start after the
     // predecessor's; its line prep (above) did not wait
     if (ctx->chain_pred && !ctx->capturing) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->chain_pred->accum_done, 0));
@@ -1170,7 +1268,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             launch_accumulate_skew(da + g.first, g.count, g.max_tiles, g.R, g.worklist, g.total_tiles, ctx->stream);
         } else {
             launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, g.variant, g.worklist, g.total_tiles,
-                              ctx->stream);
+                              ctx->stream, ctx->accuracy);
         }
         prof_end(ctx, PROF_ACCUM, ev);
         HIP_TRY(ctx, hipGetLastError());
@@ -1186,6 +1284,30 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     }
     return LBL_OK;
 }
+
+// Introspection for tests: the k-th most recently used schedule of the context (0 = the last one handed out):
+// its (job, tile) dispatch list and its span table, copied to the host after the stream has drained.
+extern "C" int lbl_schedule_export(lbl_ctx* ctx, int k, int32_t* list, int64_t list_cap, int32_t* tabs, int64_t tabs_cap,
+                                   int64_t* n_items, int64_t* n_tab_ints, int32_t* built_on_device) try {
+    if (!ctx || !n_items || !n_tab_ints) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    if (k < 0 || (size_t)k >= ctx->schedules.size()) return fail(ctx, LBL_ERR_BAD_ARG, "no such schedule (the cache holds %d)", (int)ctx->schedules.size());
+    const lbl_ctx::Schedule& S = *ctx->schedules[ctx->schedules.size() - 1 - (size_t)k];
+    if (S.pending) return fail(ctx, LBL_ERR_STATE, "the schedule has not been built yet (no accumulate batch has used it)");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t n_tabs = (int64_t)std::abs(S.total_spans) * 8;
+    *n_items = S.total;
+    *n_tab_ints = n_tabs;
+    if (built_on_device) *built_on_device = S.total_spans > 0 ? 1 : 0;
+    if (list) {
+        if (list_cap < 2 * (int64_t)S.total) return fail(ctx, LBL_ERR_BAD_ARG, "list too short");
+        if (S.total > 0) HIP_TRY(ctx, hipMemcpy(list, S.d_list, (size_t)S.total * sizeof(int2), hipMemcpyDeviceToHost));
+    }
+    if (tabs && n_tabs > 0) {
+        if (tabs_cap < n_tabs) return fail(ctx, LBL_ERR_BAD_ARG, "tabs too short");
+        HIP_TRY(ctx, hipMemcpy(tabs, S.d_tabs, (size_t)n_tabs * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return LBL_OK;
+} LBL_GUARD_END(ctx)
 
 extern "C" int lbl_xsec_accumulate_dev(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines, const lbl_iso_params* iso,
                                        const lbl_grid* grid, lbl_buffer* const* out) try {
@@ -1306,6 +1428,11 @@ static double uniform_rcp(double c) {
     return rc;
 }
 
+// budget mode (lbl_set_option "accuracy" 1): the per-molecule factor of pyradClasses.py:583 and the Planck exponent's
+// per-layer factor of pyradPlanck.py:42, evaluated once on the host in the reference's left-to-right order
+static double budget_factor(double conc, double P, double T) { return conc * P / 1E4 / kB / T; }
+static double budget_pbkT(double T) { double pa, pb; pa = 0; pb = 100 * hPlanck * cLight; (void)pa; return T > 0 ? pb / kB / T : 0.0; }
+
 static double axis_step(double lo, double hi, int64_t n) { return n > 1 ? (hi - lo) / (double)(n - 1) : 0.0; }
 
 static int check_buf(lbl_ctx* ctx, const lbl_buffer* b, int64_t n, const char* what, bool required) {
@@ -1336,8 +1463,10 @@ extern "C" int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* x
             return fail(ctx, LBL_ERR_BAD_ARG, "iso_mol must be non-decreasing and < n_mol");
         a.xsec[i] = xsec[i]->d;
         a.term_conc[i] = conc[iso_mol[i]];
+        a.term_factor[i] = budget_factor(conc[iso_mol[i]], P, T);
         a.term_flags[i] = (i == n_iso - 1 || iso_mol[i + 1] != iso_mol[i]) ? TERM_LAST_MOL : 0;
     }
+    a.budget = ctx->accuracy; a.pbkT = budget_pbkT(T); a.pbk_surface = budget_pbkT(surface_T);
     if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
     if ((rc = check_buf(ctx, abs_coef, n, "abs_coef", false))) return rc;
     if ((rc = check_buf(ctx, trans, n, "trans", false))) return rc;
@@ -1404,6 +1533,8 @@ extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lin
         f.trans = trans ? trans->d : nullptr;
         f.I_out = I_out ? I_out->d : nullptr;
         f.n = n; f.on = 1;
+        f.budget = ctx->accuracy; f.factor = budget_factor(conc[iso_mol[0]], f.P, f.T);
+        f.pbkT = budget_pbkT(f.T); f.pbk_surface = budget_pbkT(surface_T);
         return enqueue_accumulate(ctx, 1, lines, iso, grids.data(), outs.data(), false, &f, conc[iso_mol[0]]);
     }
     // several line lists, a work grid that needs the regrid kernel, or a kernel variant without the fused
@@ -1488,6 +1619,7 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
                 return fail(ctx, LBL_ERR_BAD_ARG, "layer %d: iso_mol must be non-decreasing and < n_mol", l);
             a->xsec[nt] = xsec[iso0 + i]->d;
             a->term_conc[nt] = conc[mol0 + m];
+            a->term_factor[nt] = budget_factor(conc[mol0 + m], P[l], T[l]);
             a->term_flags[nt] = (i == n_iso[l] - 1 || iso_mol[iso0 + i + 1] != m) ? TERM_LAST_MOL : 0;
             ++nt;
         }
@@ -1504,6 +1636,7 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
         for (int t = nt - std::max(n_iso[l], 1); t < nt; ++t) {
             a->term_P[t] = P[l]; a->term_T[t] = T[l]; a->term_depth[t] = depth[l];
             a->term_rT[t] = uniform_rcp(T[l]);
+            a->term_pbkT[t] = budget_pbkT(T[l]);
         }
         if (abs_coef && abs_coef[l]) { if ((rc = check_buf(ctx, abs_coef[l], n, "abs_coef", true))) return rc; a->abs_coef[l] = abs_coef[l]->d; a->layer_arrays = 1; }
         if (trans && trans[l]) { if ((rc = check_buf(ctx, trans[l], n, "trans", true))) return rc; a->trans[l] = trans[l]->d; a->layer_arrays = 1; }
@@ -1516,6 +1649,7 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
     planck_constants(&a->pa, &a->pb);
     a->surface_T = surface_T;
     a->r_surface_T = uniform_rcp(surface_T);
+    a->pbk_surface = budget_pbkT(surface_T);
     a->I_in = I_in ? I_in->d : nullptr;
     a->I_out = I_out->d;
     a->n = n; a->first = first; a->count = count;
@@ -1523,7 +1657,7 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
     void* d_args = nullptr;
     if ((rc = device_args(ctx, a, sizeof(ColumnStepArgs), &d_args))) return rc;
     hipEvent_t ev = prof_begin(ctx, PROF_COLUMN);
-    launch_column_step((const ColumnStepArgs*)d_args, first, count, ctx->stream);
+    launch_column_step((const ColumnStepArgs*)d_args, first, count, ctx->stream, ctx->accuracy);
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;

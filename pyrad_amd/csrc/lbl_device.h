@@ -58,7 +58,8 @@ struct FusedSweep {
     const double* I_in;
     double* abs_coef; double* trans; double* I_out;
     long long n;
-    int32_t on, pad;
+    int32_t on, budget;             // budget: lbl_set_option "accuracy" 1 (see "budget mode of the sweeps" in lbl_kernels.hip)
+    double factor, pbkT, pbk_surface;   // budget mode: conc * P / 1E4 / k / T; 100 h c / k / T; 100 h c / k / surface_T
 };
 
 struct AccumJob {
@@ -107,9 +108,25 @@ struct PrepJob {
     double ghw_factor;      // sqrt(2 k T / m / c^2), m = molmass/1000/avo (cls:263, 296)
     double q_ratio;         // Q_296 / Q_T                              (int:30-32)
     double inv_T, inv_res, inv_res2;
+    double gauss_cut;       // 2^54: the Gaussian part of a pseudo-Voigt line is evaluated until it cannot change the fp64 value of
+                            // the line's sum; budget mode 2^34: until it is below 2^-34 (5.8e-11) of the line's own Lorentz term
     int32_t n_lines;
     int32_t pad;
 };
+
+// Device-side schedule build (lbl_kernels.hip "Schedule of a launch group"): one per job of the group
+struct SchedJob {
+    const int32_t* cidx;   // centre indices K1 wrote for this job in the current batch
+    int32_t n_lines, H;
+    int32_t p_begin, p_end;
+    int32_t span_first;    // first span of this job in the group's span table
+    int32_t tile_first;    // first (job, tile) item of this job in the group's positional item list
+};
+bool sched_device_supported(int total_tiles, int n_cu);
+size_t sched_scratch_bytes(int total_tiles);
+void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, int total_tiles, int R, int spans_per_tile,
+                           long long far_reach, double cost_near, double cost_edge, double cost_far, double cost_fixed,
+                           int n_cu, int32_t* tabs, void* scratch, int2* worklist, hipStream_t s);
 
 // ---- fused sweep arguments (passed by value / by pointer to the sweep kernels) ----------
 constexpr int kMaxIso = 48;
@@ -121,8 +138,10 @@ struct SweepArgs {
     const double* xsec[kMaxIso];
     double term_conc[kMaxIso];      // volume fraction of the term's molecule
     int32_t term_flags[kMaxIso];
+    double term_factor[kMaxIso];    // budget mode: conc * P / 1E4 / k / T of the term's molecule (host, the reference's order)
+    double pbkT, pbk_surface;       // budget mode: 100 h c / k / T, 100 h c / k / surface_T
     int32_t n_iso, n_mol;
-    int32_t variant, pad;           // 1: streaming (non-temporal) loads and stores (0 in LBL_DIAG builds with debug_ablate bit 64, for A/B)
+    int32_t variant, budget;         // 1: streaming (non-temporal) loads and stores (0 in LBL_DIAG builds with debug_ablate bit 64, for A/B)
     double P, T, depth;
     double rT, r_surface_T;         // RN(1/T), RN(1/surface_T) for div_uniform (0: plain divide)
     double start, stop, step;       // xAxis = linspace(start, stop, n)
@@ -143,6 +162,8 @@ struct ColumnStepArgs {
     // the layer's scalars repeated per term, so that every load of a batch of terms has an address that depends
     // on the term index only (the kernel fetches them with wide scalar loads ahead of the arithmetic)
     double term_P[kMaxColumnIso], term_T[kMaxColumnIso], term_rT[kMaxColumnIso], term_depth[kMaxColumnIso];   // rT = RN(1/T) (0: plain divide)
+    double term_factor[kMaxColumnIso], term_pbkT[kMaxColumnIso];     // budget mode (see SweepArgs)
+    double pbk_surface;
     int32_t term_flags[kMaxColumnIso];
     int32_t n_terms, n_layers;
     int32_t ablate;                     // LBL_DIAG builds only (lbl_set_option debug_ablate): timing-only variants; else 0 and never read
@@ -172,7 +193,7 @@ void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStrea
 void launch_line_quantities(const PrepJob* d_job, int n_lines, long long* index, double* lhw, double* ghw, double* intensity,
                             int32_t* regime, hipStream_t s);
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
-                       const int2* worklist, int total_tiles, hipStream_t s);
+                       const int2* worklist, int total_tiles, hipStream_t s, int budget = 0);
 // narrow windows: every lane walks the lines that reach its own R points (skewed ranges); tiles of 256 R points
 void launch_accumulate_skew(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, const int2* worklist, int total_tiles,
                             hipStream_t s);
@@ -186,7 +207,7 @@ void launch_accumulate_balanced(const AccumJob* d_jobs, int n_jobs, int total_sp
 void launch_regrid(const double* work, long long n_work, double* out, long long n_base, double start, double stop,
                    hipStream_t s);
 void launch_layer_sweep(const SweepArgs& a, hipStream_t s);
-void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s);
+void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s, int budget = 0);
 void launch_column_sweep(const ColumnArgs* d_args, long long n, hipStream_t s);
 void launch_planck(double* out, long long n, double start, double stop, double T, double rT, double pa, double pb, hipStream_t s);
 int band_partial_count(long long n);

@@ -159,6 +159,28 @@ __device__ __forceinline__ double abs_coef_term(double xs, double conc, double P
     return div_uniform(div_uniform(div_uniform(xs * conc * P, 1E4, kRcp1E4), kB, kRcpKB), T, rT);
 }
 
+// ---- budget mode of the sweeps (lbl_set_option "accuracy" 1) ---------------------------------------------------
+// The exact sweeps round where the reference's NumPy expressions round: nine correctly rounded divisions per point and
+// layer (51 of the column step's 161 instructions) and the library exp.  Budget mode keeps fp64 and spends a few ulps:
+// the molecule's factor conc * P / 1E4 / k / T comes from the host (evaluated there in the reference's order) and meets
+// the cross section in ONE multiplication; the Planck exponent is n * (100 h c / k / T) with the bracket from the host;
+// reciprocals by v_rcp_f64 + two Newton steps; exp without the library's range tests.  Each result is within a few
+// 1e-16 of the exact mode's; the tests hold the whole chain to 1e-9 on the absorption coefficient.
+__device__ __forceinline__ double rcp_newton(double x) {           // x finite, positive, normal
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double planck_budget(double n, double pa, double pbkT) {
+    const double b = n * pbkT;
+    const double e = exp_clamped(fmin(b, 700.0)) - 1.0;
+    const double v = (pa * (n * n * n)) * rcp_newton(fmax(e, 1e-300));
+    return (b > 700.0 || !(e > 0.0)) ? ((b > 700.0) ? 0.0 : (pa * (n * n * n)) / e) : v;     // (n = 0: 0/0 like the reference)
+}
+__device__ __forceinline__ double exp_neg_budget(double x) {       // exp(-x), x >= 0 (optical depth)
+    return exp_clamped(fmax(-x, -800.0));
+}
+
 // ----------------------------------------------------------------------------------------
 // K1: per-line preparation
 // ----------------------------------------------------------------------------------------
@@ -253,12 +275,12 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
             const double u2_under = 745.2;           // exp(-745.2) == 0 in fp64
             double u2 = u2_under;
             if (KL != 0.0) {
-                // ratio Gauss/Lorentz at offset u = d/a:  C (1+u^2) exp(-u^2);  solve = 2^-54 for u^2 = v + 1,
+                // ratio Gauss/Lorentz at offset u = d/a:  C (1+u^2) exp(-u^2);  solve = 2^-54 (budget mode: 2^-34) for u^2 = v + 1,
                 // v = ln C + ln(1 + v).  The cut-off only has to err on the far side, so single precision
                 // with a margin does: ln C from the exponent and a hardware log2 of the mantissa, three
                 // fixed-point steps (each contracts by 1/(1+v)), +0.01 for the float roundings and the
                 // remaining contraction (4 double-precision logs were a fifth of this kernel's instructions).
-                const double C = fabs(KG / (r.KL * rc.b)) * 18014398509481984.0;
+                const double C = fabs(KG / (r.KL * rc.b)) * J.gauss_cut;        // 2^54 (exact mode) or 2^34 (budget mode)
                 if (C <= 1.0) {
                     u2 = 0.0;
                 } else {
@@ -875,7 +897,13 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
 #define LBL_FF_NT 30
 #endif
 constexpr int FF_FAR = LBL_FF_FAR;   // a line is far when |c - xc| >= FF_FAR * (32 R)
-constexpr int FF_NT = LBL_FF_NT;     // series terms
+constexpr int FF_NT = LBL_FF_NT;     // series terms (exact mode: remainder below half an ulp)
+// Budget mode (lbl_set_option "accuracy" 1: <= 1e-9 relative on the absorption coefficient instead of the last bits;
+// BASELINE north_star asks for 1e-6): 18 terms.  With rho <= 1/4 the remainder after NT terms is at most
+// rho^NT (NT (1 - rho) + 1) (1 + rho)^2 / (1 - rho)^2 of the line's own smallest term on the span: 5.9e-10 at NT = 18
+// for a line exactly at the threshold, falling by 4x per further half-span; every term of the sum is positive, so the
+// sum's relative error is below the worst line's.
+constexpr int FF_NT_BUDGET = 18;
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_move_f64(double v) {
@@ -931,10 +959,10 @@ __device__ __forceinline__ void wave_sum_rows(double (&C)[NT], double* scratch, 
 }
 
 // Series coefficients of the far lines m0, m0+stride*k.. (chunks of 64, one line per lane) below m1.
-template <int R>
+template <int R, int NT>
 __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec* cold, int m0, int m1, int stride,
                                                 double xc, int wlo, int whi, double x0, double Hf, double* lh, double* lc,
-                                                int lane, double (&C)[FF_NT], WaveAcc<R>& S) {
+                                                int lane, double (&C)[NT], WaveAcc<R>& S) {
     typedef double v2f64 __attribute__((ext_vector_type(2)));
     typedef const v2f64 __attribute__((address_space(1)))* GlobalF64x2;
     const GlobalF64x2 gh = (GlobalF64x2)(unsigned long long)hot;
@@ -986,7 +1014,7 @@ __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec
         double qb = al * qa;
         C[1] += qb;
 #pragma unroll
-        for (int n = 2; n < FF_NT; ++n) {
+        for (int n = 2; n < NT; ++n) {
             const double qn = fma(al, qb, -(bp * qa));
             C[n] += qn;
             qa = qb; qb = qn;
@@ -1174,7 +1202,7 @@ __device__ __forceinline__ void fused_fold(const FusedSweep& A, const AccumJob& 
 #pragma clang fp contract(off)
     if (J.chain_flags & CHAIN_MOL_FIRST) xs_m = 0.0;
     xs_m += xsec;
-    if (J.chain_flags & CHAIN_MOL_LAST) kk += abs_coef_term(xs_m, J.conc, A.P, A.T, A.rT);
+    if (J.chain_flags & CHAIN_MOL_LAST) kk += A.budget ? xs_m * A.factor : abs_coef_term(xs_m, J.conc, A.P, A.T, A.rT);
 }
 
 // after the last line list: transmittance and outgoing radiance of the point
@@ -1182,12 +1210,13 @@ __device__ __forceinline__ void fused_fold(const FusedSweep& A, const AccumJob& 
 __device__ __forceinline__ void fused_finish(const FusedSweep& A, long long j, double kk) {
 #pragma clang fp contract(off)
     if (A.abs_coef) A.abs_coef[j] = kk;
-    const double tr = exp(-kk * A.depth);
+    const double tr = A.budget ? exp_neg_budget(kk * A.depth) : exp(-kk * A.depth);
     if (A.trans) A.trans[j] = tr;
     if (A.I_out) {
         const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
-        const double B = planck_wn(nu, A.T, A.rT, A.pa, A.pb);
-        const double Iin = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.r_surface_T, A.pa, A.pb);
+        const double B = A.budget ? planck_budget(nu, A.pa, A.pbkT) : planck_wn(nu, A.T, A.rT, A.pa, A.pb);
+        const double Iin = A.I_in ? A.I_in[j] : (A.budget ? planck_budget(nu, A.pa, A.pbk_surface)
+                                                          : planck_wn(nu, A.surface_T, A.r_surface_T, A.pa, A.pb));
         const double transmitted = tr * Iin;
         const double emitted = (1.0 - tr) * B;
         A.I_out[j] = transmitted + emitted;
@@ -1195,9 +1224,10 @@ __device__ __forceinline__ void fused_finish(const FusedSweep& A, long long j, d
 }
 
 
-template <int R, int LS, bool FF = false>
+template <int R, int LS, int NT = 0>                                                     // NT: far-field series terms (0: every pair direct)
 __global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), ((R >= 4 && LS <= 4) ? 4 : 1))     // HIP: min waves per SIMD
 void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* __restrict__ worklist) {
+    constexpr bool FF = NT > 0;
     constexpr int NW = LS > 4 ? LS : 4;              // wavefronts per workgroup (LS = 8: 512 threads)
     constexpr int PG = NW / LS;                      // point groups (64*R points each) per workgroup
     // per wave: hot records [0,256), cold records [256,512); after the line loop the same words
@@ -1274,18 +1304,19 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
             skew_edges<R>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, lh, lc, s_ecnt[EDGE_SKEW ? wave : 0][0],
                           s_ecnt[EDGE_SKEW ? wave : 0][1], lane, S);
         if (any_far) {
-            double C[FF_NT];
+            constexpr int NTC = FF ? NT : 2;               // (the array of the instantiations without the series is never touched)
+            double C[NTC];
 #pragma unroll
-            for (int n = 0; n < FF_NT; ++n) C[n] = 0.0;
-            far_field_lines<R>(J.hot, J.cold, iB + ((part + 1) % LS) * 64, iF1, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S);
-            far_field_lines<R>(J.hot, J.cold, iF2 + ((part + 2) % LS) * 64, iC, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S);
-            wave_sum_rows<FF_NT>(C, s_stage[wave], lane);
+            for (int n = 0; n < NTC; ++n) C[n] = 0.0;
+            far_field_lines<R, NTC>(J.hot, J.cold, iB + ((part + 1) % LS) * 64, iF1, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S);
+            far_field_lines<R, NTC>(J.hot, J.cold, iF2 + ((part + 2) % LS) * 64, iC, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S);
+            wave_sum_rows<NTC>(C, s_stage[wave], lane);
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const double tau = ((x0 + (double)k) - xc) * (1.0 / (32.0 * R));
-                double v = C[FF_NT - 1];
+                double v = C[NTC - 1];
 #pragma unroll
-                for (int n = FF_NT - 2; n >= 0; --n) v = fma(v, tau, C[n]);
+                for (int n = NTC - 2; n >= 0; --n) v = fma(v, tau, C[n]);
                 S.acc[k] += v;
             }
         }
@@ -1771,6 +1802,258 @@ void launch_accumulate_balanced(const AccumJob* d_jobs, int n_jobs, int total_sp
 }
 
 // ----------------------------------------------------------------------------------------
+// Schedule of a launch group, built on the device (time to first spectrum: a pressure or range change
+// re-windows the layer, pyradClasses.py:734-752 -> resetData cls:45-56, and the next getter recomputes)
+// ----------------------------------------------------------------------------------------
+// What a launch group's accumulate kernels need besides the line records: for every span of 64 R points the six
+// lower bounds of its edge / near / far lines in the sorted centre indices (one 32-byte row of the span table), and
+// the dispatch order of its (job, tile) workgroups - longest first, XCD-partitioned when the launch has several
+// rounds, bin-packed per CU when it has one (group_schedule in lbl_api.hip has the reasoning and the measurements).
+// Until round 4 the host built both from its own evaluation of the centre indices: 4 ms for the 100-2500 cm^-1
+// cell and 80 ms for the 30-layer column on one host thread, per re-windowing.  Here the bounds are searched in the
+// very array K1 wrote (cidx), right after K1 in the same stream, and the order is sorted on the chip; nothing is
+// copied back and the host never waits.  Dispatch order never changes a result; the span tables are the lower
+// bounds of the same integers either way (tests/test_gpu_parity.py::test_device_schedule_*).
+__global__ __launch_bounds__(256) void sched_spans_kernel(const SchedJob* __restrict__ jobs, int n_jobs, int total_spans, int R,
+                                                          int spans_per_tile, long long far_reach, double cost_near,
+                                                          double cost_edge, double cost_far, double cost_fixed,
+                                                          int32_t* __restrict__ tabs, unsigned int* __restrict__ tile_cost,
+                                                          int2* __restrict__ items) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;               // span of the group, job-major
+    if (g >= total_spans) return;
+    int k = 0;
+    while (k + 1 < n_jobs && g >= jobs[k + 1].span_first) ++k;
+    const SchedJob J = jobs[k];
+    const int q = g - J.span_first;                                     // span of the job's shard
+    const long long span = 64LL * R;
+    const long long lo = (long long)J.p_begin + (long long)q * span;
+    const long long hi = min(lo + span - 1, (long long)J.p_end - 1);
+    const long long H = J.H;
+    int iA = lower_bound_i32(J.cidx, J.n_lines, lo - H);
+    int iB = lower_bound_i32(J.cidx, J.n_lines, hi - H);
+    int iC = lower_bound_i32(J.cidx, J.n_lines, lo + H + 1);
+    int iD = lower_bound_i32(J.cidx, J.n_lines, hi + H + 1);
+    if (hi - H >= lo + H + 1) { iB = iD; iC = iD; }                     // span wider than the support: no interior line
+    int iF1 = iB, iF2 = iC;
+    if (far_reach > 0) {                                                // (same arithmetic as wave_line_ranges_far)
+        iF1 = min(max(lower_bound_i32(J.cidx, J.n_lines, lo + 32 * R - far_reach), iB), iC);     // first line with c > fl
+        iF2 = min(max(lower_bound_i32(J.cidx, J.n_lines, lo + 32 * R + far_reach), iF1), iC);    // first line with c >= fr
+    }
+    int32_t* e = tabs + ((size_t)J.span_first + (size_t)q) * 8;
+    e[0] = iA; e[1] = iB; e[2] = iC; e[3] = iD; e[4] = iF1; e[5] = iF2; e[6] = 0; e[7] = 0;
+    // wave-instructions of the span, as group_schedule prices them
+    const double n_far = (double)((iF1 - iB) + (iC - iF2)), n_edge = (double)((iB - iA) + (iD - iC)), n_near = (double)(iF2 - iF1);
+    const double c = n_near * cost_near + n_edge * cost_edge + n_far * cost_far + cost_fixed;
+    const int tile = q / spans_per_tile;
+    atomicAdd(&tile_cost[J.tile_first + tile], (unsigned int)(c + 0.5));          // integer adds: any order, same sum
+    if (q % spans_per_tile == 0) { int2 it; it.x = k; it.y = tile; items[J.tile_first + tile] = it; }
+}
+
+// ascending bitonic sort of n (a power of two) 64-bit keys in LDS by the whole workgroup
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long* keys, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = keys[i], b = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// key that sorts by decreasing cost, ties by increasing position (what std::stable_sort gives the host)
+__device__ __forceinline__ unsigned long long sched_key(unsigned int cost, int pos) {
+    return ((unsigned long long)(0xFFFFFFFFu - cost) << 32) | (unsigned int)pos;
+}
+
+// chunk (of `chunks` equal shares of the total cost, in positional order) that item i falls into
+__device__ __forceinline__ int sched_chunk_of(const unsigned long long* __restrict__ prefix, int i, double share, int chunks) {
+    const int c = (int)((double)prefix[i] / share);
+    return c < chunks ? c : chunks - 1;
+}
+
+// Launches of several rounds: XCD-partitioned longest-first.  Workgroup i of the accumulate launch runs on XCD i mod 8
+// and every XCD has its own L2: the positional tile sequence is cut into `chunks` (8 x 32) pieces of equal cost,
+// piece c goes to part c mod 8, every part is sorted longest-first and the parts are interleaved - XCD x reads the
+// records of part x only.  One workgroup per part; cap = capacity of the dynamic LDS in keys (a power of two).
+// Parts hold different numbers of items: up to the smallest part the interleave is strict (rank r of part x at slot
+// 8 r + x); what the longer parts have left follows round by round over the parts that still have items (their
+// cheapest tiles; the XCD alignment of that tail does not matter).
+__global__ __launch_bounds__(1024) void sched_order_xcd_kernel(const unsigned long long* __restrict__ prefix,
+                                                               const unsigned int* __restrict__ tile_cost,
+                                                               const int2* __restrict__ items, int N, int chunks, int cap,
+                                                               unsigned long long* __restrict__ g_keys, int g_stride,
+                                                               int2* __restrict__ worklist) {
+    extern __shared__ unsigned long long s_keys_lds[];
+    __shared__ int s_start[8 * 64 + 1];               // first item of every chunk (chunks <= 512)
+    __shared__ int s_count[8];
+    const int x = blockIdx.x;
+    const double share = (double)prefix[N] / (double)chunks + 1e-9;
+    for (int c = threadIdx.x; c <= chunks; c += blockDim.x) {
+        // first i in [0, N] whose chunk is >= c (chunk numbers do not decrease with i)
+        int lo = 0, hi = N;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sched_chunk_of(prefix, mid, share, chunks) < c) lo = mid + 1; else hi = mid;
+        }
+        s_start[c] = (c == chunks) ? N : lo;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        int n = 0;
+        for (int c = threadIdx.x; c < chunks; c += 8) n += s_start[c + 1] - s_start[c];
+        s_count[threadIdx.x] = n;
+    }
+    __syncthreads();
+    const int n_x = s_count[x];
+    int size = 1;
+    while (size < n_x) size <<= 1;
+    // a part that does not fit the LDS (one part can hold most of a group's cheap tiles when a few tiles carry most of
+    // the cost) is sorted in global scratch instead: g_stride >= the next power of two of N keys per part; slow, rare
+    unsigned long long* s_keys = size <= cap ? s_keys_lds : g_keys + (size_t)x * (size_t)g_stride;
+    for (int i = threadIdx.x; i < size; i += blockDim.x) s_keys[i] = ~0ull;
+    __syncthreads();
+    int off = 0;
+    for (int c = x; c < chunks; c += 8) {
+        const int a = s_start[c], b = s_start[c + 1];
+        for (int i = a + (int)threadIdx.x; i < b; i += blockDim.x) s_keys[off + (i - a)] = sched_key(tile_cost[i], i);
+        off += b - a;
+    }
+    bitonic_sort_lds(s_keys, size);
+    int m = s_count[0];
+#pragma unroll
+    for (int y = 1; y < 8; ++y) m = min(m, s_count[y]);
+    for (int r = threadIdx.x; r < n_x; r += blockDim.x) {
+        const int src = (int)(unsigned int)(s_keys[r] & 0xFFFFFFFFull);
+        long long pos;
+        if (r < m) {
+            pos = 8LL * r + x;
+        } else {
+            pos = 8LL * m;
+            for (int y = 0; y < 8; ++y) {
+                pos += max(0, min(s_count[y], r) - m);                 // full rounds m .. r-1
+                if (y < x && s_count[y] > r) pos += 1;                  // parts ahead of x in round r
+            }
+        }
+        worklist[pos] = items[src];
+    }
+}
+
+// Launches of one round (every workgroup resident from the first cycle, nothing dispatched dynamically: the kernel
+// lasts as long as the busiest CU): items sorted longest-first, each to the least loaded of the n_cu bins that still
+// has a free slot, emitted bin-interleaved so that the dispatcher's round robin over the CUs rebuilds the bins.
+// One workgroup of 256; N <= 1024 items, n_cu <= 512 bins (8 per lane of the packing wave).
+__global__ __launch_bounds__(256) void sched_order_pack_kernel(const unsigned int* __restrict__ tile_cost,
+                                                               const int2* __restrict__ items, int N, int n_cu,
+                                                               int2* __restrict__ worklist) {
+    __shared__ unsigned long long s_keys[1024];
+    __shared__ short s_bin[1024], s_tier[1024];
+    __shared__ short s_size[512];
+    __shared__ int s_tier_off[8];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_keys[i] = i < N ? sched_key(tile_cost[i], i) : ~0ull;
+    bitonic_sort_lds(s_keys, 1024);
+    const int slots = (N + n_cu - 1) / n_cu;           // <= 4 (N <= 4 n_cu)
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        unsigned long long load[8];
+        int cnt[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { load[b] = 0ull; cnt[b] = 0; }
+        for (int k = 0; k < N; ++k) {
+            const unsigned int cost = 0xFFFFFFFFu - (unsigned int)(s_keys[k] >> 32);
+            // this lane's best bin: least load among its bins with a free slot, lowest bin number on a tie
+            unsigned long long best = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int bin = b * 64 + lane;
+                const unsigned long long cand = (bin < n_cu && cnt[b] < slots) ? ((load[b] << 10) | (unsigned long long)bin) : ~0ull;
+                best = cand < best ? cand : best;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(best, o, 64);
+                best = other < best ? other : best;
+            }
+            const int bin = (int)(best & 1023ull);
+            if ((bin & 63) == lane) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (b == (bin >> 6)) { s_tier[k] = (short)cnt[b]; load[b] += cost; cnt[b] += 1; }
+                s_bin[k] = (short)bin;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) if (b * 64 + lane < n_cu) s_size[b * 64 + lane] = (short)cnt[b];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < slots && t < 8; ++t) {
+            s_tier_off[t] = run;
+            for (int b = 0; b < n_cu; ++b) run += s_size[b] > t ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+        const int bin = s_bin[k], t = s_tier[k];
+        int rank = 0;
+        for (int b = 0; b < bin; ++b) rank += s_size[b] > t ? 1 : 0;
+        worklist[s_tier_off[t] + rank] = items[(int)(unsigned int)(s_keys[k] & 0xFFFFFFFFull)];
+    }
+}
+
+// What the device build covers (else the caller builds the schedule on the host), and the scratch it needs.
+bool sched_device_supported(int total_tiles, int n_cu) {
+    if (total_tiles <= 4 * n_cu) return total_tiles <= 1024 && n_cu <= 512;
+    return total_tiles <= (1 << 20);
+}
+static int sched_key_stride(int total_tiles) {
+    int p = 1;
+    while (p < total_tiles) p <<= 1;
+    return p;
+}
+size_t sched_scratch_bytes(int total_tiles) {         // tile costs | items | prefix | global sort keys (8 parts)
+    const size_t n = (size_t)total_tiles;
+    return ((n * 4 + 255) & ~(size_t)255) + ((n * 8 + 255) & ~(size_t)255) + (((n + 1) * 8 + 255) & ~(size_t)255) +
+           8 * (size_t)sched_key_stride(total_tiles) * 8 + 256;
+}
+
+void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, int total_tiles, int R, int spans_per_tile,
+                           long long far_reach, double cost_near, double cost_edge, double cost_far, double cost_fixed,
+                           int n_cu, int32_t* tabs, void* scratch, int2* worklist, hipStream_t s) {
+    if (total_spans <= 0 || total_tiles <= 0) return;
+    const size_t n = (size_t)total_tiles;
+    char* base = (char*)scratch;
+    unsigned int* tile_cost = (unsigned int*)base;                      base += (n * 4 + 255) & ~(size_t)255;
+    int2* items = (int2*)base;                                          base += (n * 8 + 255) & ~(size_t)255;
+    unsigned long long* prefix = (unsigned long long*)base;             base += ((n + 1) * 8 + 255) & ~(size_t)255;
+    unsigned long long* g_keys = (unsigned long long*)base;
+    (void)hipMemsetAsync(tile_cost, 0, (size_t)total_tiles * sizeof(unsigned int), s);
+    hipLaunchKernelGGL(sched_spans_kernel, dim3((total_spans + 255) / 256), dim3(256), 0, s, d_jobs, n_jobs, total_spans, R,
+                       spans_per_tile, far_reach, cost_near, cost_edge, cost_far, cost_fixed, tabs, tile_cost, items);
+    if (total_tiles <= 4 * n_cu) {
+        hipLaunchKernelGGL(sched_order_pack_kernel, dim3(1), dim3(256), 0, s, tile_cost, items, total_tiles, n_cu, worklist);
+        return;
+    }
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, tile_cost, total_tiles, prefix);
+    const int cap = 16384;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sched_order_xcd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  cap * (int)sizeof(unsigned long long));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sched_order_xcd_kernel, dim3(8), dim3(1024), cap * sizeof(unsigned long long), s, prefix, tile_cost, items,
+                       total_tiles, 8 * 32, cap, g_keys, sched_key_stride(total_tiles), worklist);
+}
+
+// ----------------------------------------------------------------------------------------
 // K3: np.interp from linspace(min,max,n_work) onto linspace(min,max,n_base)
 //     (pyradClasses.py:401-405, 159-162)
 // ----------------------------------------------------------------------------------------
@@ -1824,7 +2107,7 @@ __device__ __forceinline__ double load_global_f64(const double* p, long long j) 
     return ((GlobalF64)(unsigned long long)p)[j];
 }
 
-template <bool NT, int NP>
+template <bool NT, int NP, bool BUDGET = false>
 __global__ __launch_bounds__(256) void layer_sweep_kernel(const SweepArgs A) {
 #pragma clang fp contract(off)
     // NP grid points per thread (2: 16-byte accesses; the host gives this instantiation an even first point and count)
@@ -1852,7 +2135,10 @@ __global__ __launch_bounds__(256) void layer_sweep_kernel(const SweepArgs A) {
             xs += v;
             if (A.term_flags[t] & TERM_LAST_MOL) {
 #pragma unroll
-                for (int p = 0; p < NP; ++p) { kk[p] += abs_coef_term(xs[p], A.term_conc[t], A.P, A.T, A.rT); xs[p] = 0.0; }
+                for (int p = 0; p < NP; ++p) {
+                    kk[p] += BUDGET ? xs[p] * A.term_factor[t] : abs_coef_term(xs[p], A.term_conc[t], A.P, A.T, A.rT);
+                    xs[p] = 0.0;
+                }
             }
         };
         for (int t0 = 0; t0 < n_full; t0 += NB) {
@@ -1872,17 +2158,23 @@ __global__ __launch_bounds__(256) void layer_sweep_kernel(const SweepArgs A) {
         if (A.abs_coef) st(A.abs_coef, j, kk);
         vec tr;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) tr[p] = exp(-kk[p] * A.depth);            // pyradClasses.py:716
+        for (int p = 0; p < NP; ++p) tr[p] = BUDGET ? exp_neg_budget(kk[p] * A.depth) : exp(-kk[p] * A.depth);     // pyradClasses.py:716
         if (A.trans) st(A.trans, j, tr);
         if (A.I_out) {
             vec out;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const double nu = linspace_at(j + p, A.n, A.start, A.stop, A.step);
-                double pa_n, pb_n;
-                planck_point(nu, A.pa, A.pb, pa_n, pb_n);
-                const double B = planck_at(pa_n, pb_n, A.T, A.rT);              // Layer.planck(self.T)
-                const double Iin = A.I_in ? A.I_in[j + p] : planck_at(pa_n, pb_n, A.surface_T, A.r_surface_T);
+                double B, Iin;
+                if (BUDGET) {
+                    B = planck_budget(nu, A.pa, A.pbkT);
+                    Iin = A.I_in ? A.I_in[j + p] : planck_budget(nu, A.pa, A.pbk_surface);
+                } else {
+                    double pa_n, pb_n;
+                    planck_point(nu, A.pa, A.pb, pa_n, pb_n);
+                    B = planck_at(pa_n, pb_n, A.T, A.rT);                       // Layer.planck(self.T)
+                    Iin = A.I_in ? A.I_in[j + p] : planck_at(pa_n, pb_n, A.surface_T, A.r_surface_T);
+                }
                 const double transmitted = tr[p] * Iin;                     // pyradClasses.py:785
                 const double emitted = (1.0 - tr[p]) * B;                   // pyradClasses.py:786
                 out[p] = transmitted + emitted;
@@ -1922,7 +2214,7 @@ __global__ __launch_bounds__(256) void column_sweep_kernel(const ColumnArgs* __r
 // term of a molecule and of a layer).  NB terms are loaded at once, independent of one another; everything
 // that depends on the grid point only (2E8 h c^2 n^3 and 100 h c n / k of pyradPlanck.py:41-42) is computed
 // once per point, not once per layer.
-template <int NP>
+template <int NP, bool BUDGET = false>
 __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* __restrict__ Ap, long long first, long long count) {
 #pragma clang fp contract(off)
     // NP grid points per thread (2: 16-byte loads; the host gives this instantiation an even first point and an even count)
@@ -1946,8 +2238,13 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const double nu = linspace_at(j + p, A.n, A.start, A.stop, A.step);
-            planck_point(nu, A.pa, A.pb, pa_n[p], pb_n[p]);
-            I[p] = A.I_in ? A.I_in[j + p] : planck_at(pa_n[p], pb_n[p], A.surface_T, A.r_surface_T);
+            if (BUDGET) {
+                pa_n[p] = A.pa * (nu * nu * nu); pb_n[p] = nu;           // (budget: the exponent is nu * term_pbkT)
+                I[p] = A.I_in ? A.I_in[j + p] : planck_budget(nu, A.pa, A.pbk_surface);
+            } else {
+                planck_point(nu, A.pa, A.pb, pa_n[p], pb_n[p]);
+                I[p] = A.I_in ? A.I_in[j + p] : planck_at(pa_n[p], pb_n[p], A.surface_T, A.r_surface_T);
+            }
             kk[p] = 0.0; xs[p] = 0.0;
         }
         int l = 0;
@@ -1958,17 +2255,27 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
             if (LBL_ABLATE(A, 16)) { I[0] += v[0]; return; }       // (diagnostic builds: memory traffic only)
             if (f & TERM_LAST_MOL) {
 #pragma unroll
-                for (int p = 0; p < NP; ++p) { kk[p] += abs_coef_term(xs[p], A.term_conc[t], A.term_P[t], A.term_T[t], A.term_rT[t]); xs[p] = 0.0; }
+                for (int p = 0; p < NP; ++p) {
+                    kk[p] += BUDGET ? xs[p] * A.term_factor[t] : abs_coef_term(xs[p], A.term_conc[t], A.term_P[t], A.term_T[t], A.term_rT[t]);
+                    xs[p] = 0.0;
+                }
             }
             if (f & TERM_LAST_LAYER) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    const double tr = exp(-kk[p] * A.term_depth[t]);
+                    const double tr = BUDGET ? exp_neg_budget(kk[p] * A.term_depth[t]) : exp(-kk[p] * A.term_depth[t]);
                     if (layer_arrays) {
                         if (A.abs_coef[l]) A.abs_coef[l][j + p] = kk[p];
                         if (A.trans[l]) A.trans[l][j + p] = tr;
                     }
-                    const double B = planck_at(pa_n[p], pb_n[p], A.term_T[t], A.term_rT[t]);
+                    double B;
+                    if (BUDGET) {
+                        const double b = pb_n[p] * A.term_pbkT[t];
+                        const double e = exp_clamped(fmin(b, 700.0)) - 1.0;
+                        B = (b > 700.0) ? 0.0 : (e > 0.0 ? pa_n[p] * rcp_newton(fmax(e, 1e-300)) : pa_n[p] / e);
+                    } else {
+                        B = planck_at(pa_n[p], pb_n[p], A.term_T[t], A.term_rT[t]);
+                    }
                     const double transmitted = tr * I[p];
                     const double emitted = (1.0 - tr) * B;
                     I[p] = transmitted + emitted;
@@ -2091,7 +2398,7 @@ static void launch_accum_scalar(const AccumJob* d_jobs, int n_jobs, int max_tile
     }
 }
 
-template <int R, bool FF>
+template <int R, int NT>
 static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, int LS, const int2* worklist,
                              int total_tiles, hipStream_t s) {
     dim3 grid(((max_tiles + 7) / 8) * 8, n_jobs);
@@ -2105,10 +2412,10 @@ static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, 
     constexpr int pad = 0;
 #endif
     switch (LS) {
-        case 8: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 8, FF>), grid, dim3(512), pad, s, d_jobs, worklist); break;
-        case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
-        case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
-        default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1, FF>), grid, dim3(256), pad, s, d_jobs, worklist); break;
+        case 8: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 8, NT>), grid, dim3(512), pad, s, d_jobs, worklist); break;
+        case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4, NT>), grid, dim3(256), pad, s, d_jobs, worklist); break;
+        case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2, NT>), grid, dim3(256), pad, s, d_jobs, worklist); break;
+        default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1, NT>), grid, dim3(256), pad, s, d_jobs, worklist); break;
     }
 }
 
@@ -2132,8 +2439,8 @@ void launch_accumulate_skew(const AccumJob* d_jobs, int n_jobs, int max_tiles, i
 // one (3 instructions per series term and 64 lines against 5 R per line), for the host's schedule
 void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost) {
     *far_half_spans = FF_FAR;
-    *far_cost = (3.0 * FF_NT + 12.0) / 64.0 / (5.0 * R);
-}
+    *far_cost = (3.0 * FF_NT + 12.0) / 64.0 / (5.0 * R);          // (priced at the exact mode's term count in either mode:
+}                                                                  //  one schedule serves both)
 
 // grid points one workgroup covers
 int accumulate_tile_points(int R, int LS, int variant) {
@@ -2141,23 +2448,32 @@ int accumulate_tile_points(int R, int LS, int variant) {
 }
 
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
-                       const int2* worklist, int total_tiles, hipStream_t s) {
+                       const int2* worklist, int total_tiles, hipStream_t s, int budget) {
     if (n_jobs <= 0 || max_tiles <= 0) return;
+    if (variant >= 5 && budget) {
+        switch (R) {
+            case 1: launch_accum_lds<1, FF_NT_BUDGET>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 2: launch_accum_lds<2, FF_NT_BUDGET>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 4: launch_accum_lds<4, FF_NT_BUDGET>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            default: launch_accum_lds<8, FF_NT_BUDGET>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+        }
+        return;
+    }
     if (variant >= 5) {
         switch (R) {
-            case 1: launch_accum_lds<1, true>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-            case 2: launch_accum_lds<2, true>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-            case 4: launch_accum_lds<4, true>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-            default: launch_accum_lds<8, true>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 1: launch_accum_lds<1, FF_NT>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 2: launch_accum_lds<2, FF_NT>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 4: launch_accum_lds<4, FF_NT>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            default: launch_accum_lds<8, FF_NT>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
         }
         return;
     }
     if (variant >= 3) {
         switch (R) {
-            case 1: launch_accum_lds<1, false>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-            case 2: launch_accum_lds<2, false>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-            case 4: launch_accum_lds<4, false>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-            default: launch_accum_lds<8, false>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 1: launch_accum_lds<1, 0>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 2: launch_accum_lds<2, 0>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 4: launch_accum_lds<4, 0>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            default: launch_accum_lds<8, 0>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
         }
         return;
     }
@@ -2188,7 +2504,7 @@ static int sweep_blocks(long long n) {       // (one point per thread on a large
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
-template <bool NT>
+template <bool NT, bool BUDGET>
 static void launch_layer_sweep_nt(const SweepArgs& a, hipStream_t s) {
 #ifdef LBL_DIAG
     static const bool pairs = !getenv("LBL_DIAG_SWEEP_NP1");
@@ -2198,25 +2514,35 @@ static void launch_layer_sweep_nt(const SweepArgs& a, hipStream_t s) {
     if (pairs && (a.first & 1) == 0 && a.count >= 2) {      // two points per thread with 16-byte accesses; an odd last point by itself
         SweepArgs m = a;
         m.count = a.count & ~1LL;
-        hipLaunchKernelGGL((layer_sweep_kernel<NT, 2>), dim3(sweep_blocks(m.count / 2)), dim3(256), 0, s, m);
+        hipLaunchKernelGGL((layer_sweep_kernel<NT, 2, BUDGET>), dim3(sweep_blocks(m.count / 2)), dim3(256), 0, s, m);
         if (a.count & 1) {
             SweepArgs t = a;
             t.first = a.first + m.count; t.count = 1;
-            hipLaunchKernelGGL((layer_sweep_kernel<NT, 1>), dim3(1), dim3(64), 0, s, t);
+            hipLaunchKernelGGL((layer_sweep_kernel<NT, 1, BUDGET>), dim3(1), dim3(64), 0, s, t);
         }
         return;
     }
-    hipLaunchKernelGGL((layer_sweep_kernel<NT, 1>), dim3(sweep_blocks(a.count)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((layer_sweep_kernel<NT, 1, BUDGET>), dim3(sweep_blocks(a.count)), dim3(256), 0, s, a);
 }
 
 void launch_layer_sweep(const SweepArgs& a, hipStream_t s) {
     if (a.count <= 0) return;
-    if (a.variant) launch_layer_sweep_nt<true>(a, s);
-    else launch_layer_sweep_nt<false>(a, s);
+    if (a.budget) { if (a.variant) launch_layer_sweep_nt<true, true>(a, s); else launch_layer_sweep_nt<false, true>(a, s); return; }
+    if (a.variant) launch_layer_sweep_nt<true, false>(a, s);
+    else launch_layer_sweep_nt<false, false>(a, s);
 }
 
-void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s) {
+template <bool BUDGET>
+static void launch_column_step_b(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s);
+
+void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s, int budget) {
     if (count <= 0) return;
+    if (budget) launch_column_step_b<true>(d_args, first, count, s);
+    else launch_column_step_b<false>(d_args, first, count, s);
+}
+
+template <bool BUDGET>
+static void launch_column_step_b(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s) {
 #ifdef LBL_DIAG
     static const bool pairs = !getenv("LBL_DIAG_COLUMN_NP1");
 #else
@@ -2224,11 +2550,11 @@ void launch_column_step(const ColumnStepArgs* d_args, long long first, long long
 #endif
     if (pairs && (first & 1) == 0 && count >= 2) {     // two points per thread with 16-byte loads; an odd last point by itself
         const long long even = count & ~1LL;
-        hipLaunchKernelGGL(column_step_kernel<2>, dim3(sweep_blocks(even / 2)), dim3(256), 0, s, d_args, first, even);
-        if (count & 1) hipLaunchKernelGGL(column_step_kernel<1>, dim3(1), dim3(64), 0, s, d_args, first + even, 1LL);
+        hipLaunchKernelGGL((column_step_kernel<2, BUDGET>), dim3(sweep_blocks(even / 2)), dim3(256), 0, s, d_args, first, even);
+        if (count & 1) hipLaunchKernelGGL((column_step_kernel<1, BUDGET>), dim3(1), dim3(64), 0, s, d_args, first + even, 1LL);
         return;
     }
-    hipLaunchKernelGGL(column_step_kernel<1>, dim3(sweep_blocks(count)), dim3(256), 0, s, d_args, first, count);
+    hipLaunchKernelGGL((column_step_kernel<1, BUDGET>), dim3(sweep_blocks(count)), dim3(256), 0, s, d_args, first, count);
 }
 
 void launch_column_sweep(const ColumnArgs* d_args, long long count, hipStream_t s) {

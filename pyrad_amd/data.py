@@ -36,10 +36,14 @@ class MemorySource:
 
     def register(self, global_iso: int, lines: dict, q: dict, params: list):
         order = np.argsort(np.asarray(lines["nu"]), kind="stable")
-        self._lines[global_iso] = {f: np.ascontiguousarray(np.asarray(lines[f], dtype=np.float64)[order])
-                                   for f in FIELDS if f in lines}
-        if "a" not in self._lines[global_iso]:
-            self._lines[global_iso]["a"] = np.zeros_like(self._lines[global_iso]["nu"])
+        full = {f: np.ascontiguousarray(np.asarray(lines[f], dtype=np.float64)[order]) for f in FIELDS if f in lines}
+        if "a" not in full:
+            full["a"] = np.zeros_like(full["nu"])
+        # duplicated wavenumbers collapse once, here (rows with equal nu are in or out of any window together, so
+        # collapsing the whole list first gives what collapsing each selection gave): a window is then a SLICE
+        full = _Master({f: np.ascontiguousarray(v) for f, v in _dedupe_last_wins(full).items()})
+        self._lines[global_iso] = full
+        _MASTERS[id(full["nu"])] = full                   # lets a consumer recognise a window as a slice of this list
         self._q[global_iso] = q
         self._params[global_iso] = list(params)
 
@@ -51,10 +55,42 @@ class MemorySource:
 
     def gatherData(self, global_iso, range_min, range_max):
         lines = self._lines[global_iso]
-        nu = lines["nu"]
-        m = (nu > range_min) & (nu < range_max)          # strict, ut:437-438
-        sel = {f: v[m] for f, v in lines.items()}
-        return _dedupe_last_wins(sel)
+        nu = lines["nu"]                                  # sorted, duplicates collapsed (register)
+        first = int(np.searchsorted(nu, range_min, "right"))          # strict range_min < nu < range_max, ut:437-438
+        end = max(int(np.searchsorted(nu, range_max, "left")), first)
+        return {f: v[first:end] for f, v in lines.items()}             # views: no copy
+
+
+# line lists registered with a MemorySource, by id of their wavenumber array: a selection handed out by gatherData
+# is a slice of one of them, which the device side turns into a VIEW of the list's one resident copy (lbl_lines_view)
+class _Master(dict):
+    """a registered line list (a dict that can be weakly referenced: the registry must not keep dropped sources alive)"""
+    __slots__ = ("__weakref__",)
+
+
+import weakref as _weakref
+_MASTERS = _weakref.WeakValueDictionary()
+
+
+def master_slice(lines: dict, fields):
+    """(master dict, first, count) if every array of ``lines`` named in ``fields`` is the same contiguous slice of one
+    registered line list; else None."""
+    nu = lines.get("nu")
+    base = getattr(nu, "base", None)
+    if base is None or nu.ndim != 1 or nu.dtype != np.float64 or not nu.flags.c_contiguous:
+        return None
+    master = _MASTERS.get(id(base))
+    if master is None or master["nu"] is not base:
+        return None
+    first = (nu.__array_interface__["data"][0] - base.__array_interface__["data"][0]) // 8
+    n = nu.size
+    for f in fields:
+        a, m = lines.get(f), master.get(f)
+        if a is None or m is None or a.base is not m or a.size != n or a.dtype != np.float64:
+            return None
+        if (a.__array_interface__["data"][0] - m.__array_interface__["data"][0]) // 8 != first:
+            return None
+    return master, int(first), int(n)
 
 
 def _dedupe_last_wins(lines):

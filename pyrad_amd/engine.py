@@ -84,8 +84,27 @@ class Engine:
 
     def __init__(self, device: int = 0):
         self.ctx = nat.Context(device)
+        self._line_masters = {}          # id(master wavenumber array) -> (resident nat.Lines, master dict)
+
+    def pooled_lines(self, lines: dict):
+        """A view (lbl_lines_view) of the resident copy of the registered line list that ``lines`` is a slice of
+        (data.master_slice), uploading that list on first use; None if ``lines`` is not such a slice."""
+        from . import data
+        hit = data.master_slice(lines, nat.Lines.ORDER)
+        if hit is None:
+            return None
+        master, first, count = hit
+        key = id(master["nu"])
+        entry = self._line_masters.get(key)
+        if entry is None or entry[1] is not master or entry[0].h is None:
+            entry = self._line_masters[key] = (self.ctx.lines(master), master)
+            if len(self._line_masters) > 64:                      # lists nobody windows any more
+                for k in [k for k, (dev, _) in self._line_masters.items() if k != key and dev.h is not None and not dev.has_views()]:
+                    self._line_masters.pop(k)[0].free()
+        return entry[0].view(first, count)
 
     def close(self):
+        self._line_masters = {}
         self.ctx.close()
 
 

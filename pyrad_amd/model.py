@@ -294,6 +294,25 @@ class _LazyArray:
         obj.__dict__[self.loader] = loader
 
 
+def _zeros_later(descriptor, obj, n):
+    """``obj.<array> = np.zeros(n)`` without making the array until somebody reads it (a 2.4e6-point layer with three
+    molecules would otherwise write 150 MB of zeros at construction, most of which nobody ever looks at)"""
+    loader = lambda n=int(n): np.zeros(n)
+    descriptor.defer(obj, loader)
+    obj.__dict__[descriptor.host + "_zeros"] = loader
+
+
+def _copy_of_layer_cross_section(descriptor, obj, layer):
+    """``obj.crossSection = np.copy(layer.crossSection)`` (cls:290, 512): while the layer's array is still its initial
+    zeros the copy is zeros made on first read; a computed array is copied now, as the reference does"""
+    d = Layer.crossSection
+    pending = layer.__dict__.get(d.loader)
+    if pending is not None and pending is layer.__dict__.get(d.host + "_zeros"):
+        _zeros_later(descriptor, obj, int((layer.rangeMax - layer.rangeMin) / utils.BASE_RESOLUTION))
+    else:
+        setattr(obj, "crossSection", np.copy(layer.crossSection))
+
+
 def _free_buffers(bufs):
     for b in bufs.values():
         try:
@@ -528,7 +547,7 @@ class Isotope(_OpticalMixin, list):
         self._dev_xsec_valid = False
         self._xs_version = 0
         self._regime_counts = (0, 0, 0)
-        self.crossSection = np.copy(self.layer.crossSection)
+        _copy_of_layer_cross_section(Isotope.crossSection, self, self.layer)
         self.exotic = molecule.exotic
         self._lines = {f: np.zeros(0) for f in self._FIELDS}
         if number not in EXOTIC_IDS:
@@ -543,7 +562,7 @@ class Isotope(_OpticalMixin, list):
             self.gj = params[6]
             self.molmass = params[7]
             self.q = {}
-            self.lineSurvey = np.zeros(int((self.layer.rangeMax - self.layer.rangeMin) / utils.BASE_RESOLUTION))
+            _zeros_later(Isotope.lineSurvey, self, int((self.layer.rangeMax - self.layer.rangeMin) / utils.BASE_RESOLUTION))
             self.progressCrossSection = False
 
     # -- list protocol over the SoA ------------------------------------------------------
@@ -625,7 +644,11 @@ class Isotope(_OpticalMixin, list):
     # -- device residency ----------------------------------------------------------------
     def _device_lines(self, ctx):
         if self._dev_lines is None or self._dev_lines.h is None:
-            self._dev_lines = ctx.lines(self._lines)
+            # a window handed out by a MemorySource is a slice of a registered list: a VIEW of that list's one resident
+            # copy (lbl_lines_view) instead of another upload - the 30 layers of a column, or a layer whose range or
+            # pressure keeps changing, re-window the same three lists
+            pooled = _engine.get_engine().pooled_lines(self._lines)
+            self._dev_lines = pooled if pooled is not None else ctx.lines(self._lines)
         return self._dev_lines
 
     def _device_xsec(self, ctx, n):
@@ -732,7 +755,7 @@ class Molecule(_OpticalMixin, list):
             self._init_from_xsc(shortNameOrMolNum)
             return
         self.isotopeDepth = isotopeDepth
-        self.crossSection = np.copy(layer.crossSection)
+        _copy_of_layer_cross_section(Molecule.crossSection, self, layer)
         try:
             int(shortNameOrMolNum)
             self.ID = int(shortNameOrMolNum)
@@ -940,7 +963,7 @@ class Layer(_OpticalMixin, list):
         else:
             self.atmosphere = atmosphere
             self.hasAtmosphere = atmosphere
-        self.crossSection = np.zeros(int((rangeMax - rangeMin) / utils.BASE_RESOLUTION))
+        _zeros_later(Layer.crossSection, self, int((rangeMax - rangeMin) / utils.BASE_RESOLUTION))
         self.progressCrossSection = False
         if not name:
             name = 'layer %s' % self.atmosphere.nextLayerName()

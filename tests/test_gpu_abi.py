@@ -115,7 +115,7 @@ def test_graph_capture_replays_the_step_bit_for_bit(ctx):
         o.enqueue(surface_T=288.0)
         others.append(o)
     with pytest.raises(nat.LblError) as e:
-        graph.launch()
+        graph.g.launch()                                  # (the library's graph object: lbl_graph_launch refuses)
     assert e.value.code == -6 and "stale" in str(e.value)
     L.enqueue(surface_T=288.0)                            # the kernel-by-kernel route still works, and a new capture too
     g2 = L.capture_step(surface_T=288.0)
@@ -124,8 +124,17 @@ def test_graph_capture_replays_the_step_bit_for_bit(ctx):
     # freeing ANY buffer or line list of the context makes its graphs stale too: a captured kernel node may hold the address
     ctx.buffer(16).free()
     with pytest.raises(nat.LblError) as e:
-        g2.launch()
+        g2.g.launch()
     assert e.value.code == -6 and "stale" in str(e.value)
+    # engine.StepGraph (what capture_step returns) takes a stale graph in its stride: the step runs kernel by kernel
+    # once and is recorded again for the launches that follow
+    for b in (L.abs_coef, L.trans, L.I_out):
+        b.fill(0.0)
+    g2.launch()
+    assert g2.recaptures == 1 and all(np.array_equal(L.results()[k], ref[k]) for k in ref)
+    L.abs_coef.fill(0.0)
+    g2.launch()
+    assert g2.recaptures == 1 and np.array_equal(L.results()["abs_coef"], ref["abs_coef"])
     for x in (graph, g1, gc, g2):
         x.free()
     for o in others + [L, one, col]:
@@ -279,3 +288,71 @@ def test_line_list_views_share_the_parent_arrays(ctx):
     master.free()
     for o in outs:
         o.free()
+
+
+def test_closing_a_context_under_a_live_column_frees_views_before_lists():
+    """Context.close() with a ResidentColumn (line-list masters + one view per layer and molecule) still alive: views go
+    before the lists they window, nothing raises, nothing leaks (lbl_ctx_destroy refuses a context with live objects)."""
+    from pyrad_amd import _native as nat, engine
+    g = engine.layer_grid(1013.25, 640, 660, .001, False)
+    lines = synthetic.make_lines(91, 2000, 630.0, 670.0)
+    sp = synthetic.SPECIES["co2"]
+    mols = [dict(conc=4e-4, isotopologues=[dict(lines=lines, molmass=sp["molmass"], q_T=synthetic.q_value("co2", 270), q296=sp["q296"])])]
+    c = nat.Context(0)
+    cfgs = [dict(depth=1e4, T=270, P=P, range_min=640, range_max=660, base_resolution=.001, dynamic_resolution=False, molecules=mols)
+            for P in (1013.25, 300.0, 30.0)]
+    col = engine.ResidentColumn(c, cfgs, 288.0)
+    col.enqueue(layer_arrays=False)
+    assert any(isinstance(x, nat.Lines) and x._parent is not None for x in c._children)      # views exist
+    c.close()                                             # must not raise "views still alive"
+    assert c.h is None
+
+
+def test_destroying_a_chained_predecessor_unlinks_it():
+    """lbl_ctx_chain_accumulate: the successor of a destroyed context simply stops waiting (no use of the freed event);
+    a chained context refuses graph capture, and a capturing context cannot be chained."""
+    from pyrad_amd import _native as nat, engine
+    g = engine.layer_grid(1013.25, 640, 660, .001, False)
+    sp = synthetic.SPECIES["co2"]
+    mols = [dict(conc=4e-4, isotopologues=[dict(lines=synthetic.make_lines(92, 1500, g["eff_min"], g["eff_max"]),
+                                                molmass=sp["molmass"], q_T=synthetic.q_value("co2", 280), q296=sp["q296"])])]
+    a, b = nat.Context(0), nat.Context(0)
+    try:
+        La, Lb = (engine.ResidentLayer(c, 10.0, 280, 1013.25, 640, 660, mols, .001, False) for c in (a, b))
+        Lb.enqueue(surface_T=288.0)
+        ref = Lb.results()
+        b.chain_accumulate(a)
+        La.enqueue(surface_T=288.0); Lb.enqueue(surface_T=288.0)
+        with pytest.raises(nat.LblError) as e:            # either end of a link: no capture
+            b.capture(lambda: Lb.enqueue(surface_T=288.0))
+        assert e.value.code == -6 and "chain" in str(e.value)
+        with pytest.raises(nat.LblError) as e:
+            a.capture(lambda: La.enqueue(surface_T=288.0))
+        assert e.value.code == -6
+        La.free()
+        a.close()                                          # the predecessor goes first
+        Lb.abs_coef.fill(0.0)
+        Lb.enqueue(surface_T=288.0)                        # would wait on a destroyed event without the unlink
+        assert np.array_equal(Lb.results()["abs_coef"], ref["abs_coef"])
+        gb = Lb.capture_step(surface_T=288.0)              # and b is unchained now: capture works
+        gb.launch()
+        assert np.array_equal(Lb.results()["abs_coef"], ref["abs_coef"])
+        gb.free(); Lb.free()
+    finally:
+        a.close(); b.close()
+
+
+def test_production_library_has_no_ablation_option(ctx):
+    from pyrad_amd import _native as nat
+    with pytest.raises(nat.LblError) as e:
+        ctx.set_option("debug_ablate", 1)
+    assert e.value.code == -1 and "unknown option" in str(e.value)
+
+
+def test_line_view_bounds_cannot_overflow(ctx):
+    from pyrad_amd import _native as nat
+    L = ctx.lines(synthetic.make_lines(93, 100, 600.0, 700.0))
+    h = nat._P()
+    assert ctx.lib.lbl_lines_view(L.h, 50, 2**63 - 1, nat.C.byref(h)) == -1
+    assert ctx.lib.lbl_lines_view(L.h, 2**62, 2**62, nat.C.byref(h)) == -1
+    L.free()

@@ -865,3 +865,60 @@ def test_skew_kernel_resident_column_matches_span_kernel(ctx, orc):
         toa[part.first:part.first + part.count] = part.results()["toa"][part.first:part.first + part.count]
         part.free()
     assert rel_err(toa, res[1]["toa"]) <= 1e-13
+
+
+@pytest.mark.parametrize("mode,seed", [("skew", s) for s in range(32)] + [("edges", s) for s in range(100, 132)])
+def test_stress_cells_skewed_walk(ctx, orc, mode, seed):
+    """64 seeded cells of the round-3 stress generator (scripts/stress_skew.py ran thousands of them ad hoc):
+    "skew": the job through the skewed-range kernel at a random R (windows from 1 point to thousands, every regime,
+    duplicate centres); "edges": windows of 642 points and more through the far-field kernel's unsplit 256-point spans,
+    whose edge lines take the skewed walk (skew_edges).  Whole spectrum against the oracle, per-point tolerance."""
+    from conftest import point_tolerance, rel_err_points
+    from pyrad_amd import _native as nat, engine
+    rng = np.random.default_rng(9000 + seed)
+    base = float(rng.choice([0.01, 0.001, 0.0001]))
+    if mode == "edges":
+        base = float(rng.choice([0.001, 0.0001]))
+        P = float(np.exp(rng.uniform(np.log(140.0 * base / 0.001), np.log(3000.0 * base / 0.001))))
+        dyn = False
+    else:
+        P = float(np.exp(rng.uniform(np.log(0.05), np.log(20000.0))))
+        dyn = bool(rng.integers(0, 2))
+    T = int(rng.integers(150, 351))
+    rmin = float(rng.choice([0.0, 0.5, 37.0, 600.0, 2499.3, 12000.0]))
+    g0 = orc.layer_grid(P, rmin, rmin + 1.0, base, dyn)
+    width = float(min(rng.uniform(0.02, 30.0), 60000 * g0["resolution"], 20000 * base))
+    rmax = rmin + width
+    g = orc.layer_grid(P, rmin, rmax, base, dyn)
+    if g["W"] < 1 or g["n_base"] < 1 or g["n_work"] < 1 or (mode == "edges" and g["W"] < 642):
+        pytest.skip("degenerate grid, or a window below the far-field kernel's limit")
+    n_lines = int(rng.choice([1, 2, 17, 150, 400, 1500, 4000]))
+    n_lines = int(min(n_lines, max(1, 4e6 // max(g["W"], 1))))
+    try:
+        lines = synthetic.make_lines(6000 + seed, n_lines, g["eff_min"], g["eff_max"], decimals=int(rng.choice([3, 5, 7])))
+    except RuntimeError:           # too many lines for that few decimals in this window
+        lines = synthetic.make_lines(6000 + seed, n_lines, g["eff_min"], g["eff_max"], decimals=9)
+    species = str(rng.choice(["co2", "h2o", "ch4", "o3"]))
+    conc = float(rng.choice([4e-4, 1e-2, 0.5, 1.8e-6]))
+    sp = synthetic.SPECIES[species]
+    sel = engine.select_window(lines, g["eff_min"], g["eff_max"])
+    iso = nat.IsoParams(float(T), float(P), conc, sp["molmass"], synthetic.q_value(species, T), sp["q296"])
+    try:
+        if mode == "skew":
+            ctx.set_option("accum_skew", 2)
+            ctx.set_option("accum_skew_points_per_lane", int(rng.choice([1, 2, 4, 8])))
+        else:
+            ctx.set_option("accum_points_per_lane", 4)
+            ctx.set_option("accum_line_split", 1)
+        xs, counts = ctx.xsec_accumulate(sel, iso, engine.native_grid(g))
+    finally:
+        ctx.set_option("accum_skew", 1)
+        ctx.set_option("accum_skew_points_per_lane", 8)
+        ctx.set_option("accum_points_per_lane", 0)
+        ctx.set_option("accum_line_split", 0)
+    ref, rc = orc.create_cross_section(sel, T, P, conc, sp["molmass"], synthetic.q_value(species, T), sp["q296"], g)
+    tol = point_tolerance(orc.x_axis(rmin, rmax, base), T, g["dfc"])
+    floor = float(np.max(np.abs(ref))) * FLOOR_REL if ref.size else 0.0
+    e = rel_err_points(xs, ref, floor)
+    assert tuple(counts) == tuple(rc)
+    assert np.all(e <= tol), (float(e.max()), float((e / tol).max()), g["W"], n_lines)

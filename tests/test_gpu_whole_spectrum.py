@@ -107,24 +107,88 @@ def test_whole_spectrum_cell_vs_c_oracle(ctx, workload):
     L.free()
 
 
-def test_whole_spectrum_column_layers_vs_c_oracle(ctx):
-    """C5 at full size: the cross sections and transmittance of layers 0 (W = 5000, far-field kernel), 14
-    (W = 552, narrow-window kernel) and 29 (W = 49, the narrowest) at every grid point."""
+def test_whole_spectrum_column_all_layers_and_toa_vs_c_oracle(ctx):
+    """C5 at full size: the cross sections and the absorption coefficient of ALL 30 layers (windows from 5000 points
+    down to 50: far-field kernel, the layers either side of the routing boundary at 640 points, skewed-range kernel)
+    and the top-of-atmosphere radiance (the fold of pyradClasses.py:784-787 over the layers) at EVERY grid point.
+    90 oracle jobs on a thread pool (ctypes releases the GIL).  The radiance is compared with an error bound
+    propagated through the fold: an error tol k depth T of a layer's transmittance moves I by at most that times
+    |I_in - B|, and T times what came in."""
     from oracle import pyrad_oracle as orc
+    from oracle import c_oracle
     from pyrad_amd import engine
+    c_oracle.load()
     col = synthetic.config_c5()
     cfgs = [dict(c, molecules=mols_of(c)) for c in col["layers"]]
     column = engine.ResidentColumn(ctx, cfgs, col["surface_T"])
     column.enqueue(layer_arrays=True)
-    for li in (0, 14, 29):
-        c = cfgs[li]
-        g = orc.layer_grid(c["P"], c["range_min"], c["range_max"], c["base_resolution"], c["dynamic_resolution"])
-        ref, k_ref = oracle_layer(c, c["molecules"], g)
-        xa = orc.x_axis(c["range_min"], c["range_max"], c["base_resolution"])
-        tol = point_tolerance(xa, c["T"], g["dfc"])
-        Lr = column.layers[li]
-        assert Lr.evals == sum(r[2] for r in ref)
-        for i, m in enumerate(c["molecules"]):
-            worst("C5 layer %d (W = %d) %s xsec" % (li, g["W"], m["species"]), Lr.jobs[i][3].download(column.n), ref[i][0], tol)
-        worst("C5 layer %d abs_coef" % li, Lr.abs_coef.download(column.n), k_ref, tol)
+    grids = [orc.layer_grid(c["P"], c["range_min"], c["range_max"], c["base_resolution"], c["dynamic_resolution"]) for c in cfgs]
+    jobs = []
+    for c, g in zip(cfgs, grids):
+        for m in c["molecules"]:
+            iso = m["isotopologues"][0]
+            sel = orc.select_window(iso["lines"], g["eff_min"], g["eff_max"])
+            jobs.append((sel, c["T"], c["P"], m["conc"], iso["molmass"], iso["q_T"], iso["q296"], g))
+    xa = orc.x_axis(cfgs[0]["range_min"], cfgs[0]["range_max"], cfgs[0]["base_resolution"])
+    I_ref = orc.planckWavenumber(xa, col["surface_T"])
+    I_bound = 4e-16 * I_ref
+    worst_all = 0.0
+    with ThreadPoolExecutor(max_workers=14) as ex:
+        futs = [ex.submit(c_oracle.create_cross_section_work, *j) for j in jobs]
+        for li, (c, g) in enumerate(zip(cfgs, grids)):
+            n_mol = len(c["molecules"])
+            ref = [futs[li * n_mol + i].result() for i in range(n_mol)]
+            tol = point_tolerance(xa, c["T"], g["dfc"])
+            Lr = column.layers[li]
+            assert Lr.evals == sum(r[2] for r in ref)
+            k_ref = np.zeros(g["n_base"])
+            for i, m in enumerate(c["molecules"]):
+                worst_all = max(worst_all, worst("C5 layer %d (W = %d) %s xsec" % (li, g["W"], m["species"]),
+                                                 Lr.jobs[i][3].download(column.n), ref[i][0], tol))
+                k_ref = k_ref + orc.abs_coef(np.zeros(g["n_base"]) + ref[i][0], m["conc"], c["P"], c["T"])
+            worst_all = max(worst_all, worst("C5 layer %d abs_coef" % li, Lr.abs_coef.download(column.n), k_ref, tol))
+            tr = orc.transmittance(k_ref, c["depth"])
+            B = orc.planckWavenumber(xa, c["T"])
+            d_tr = (tol * k_ref * c["depth"] + 4e-16) * tr
+            I_bound = tr * I_bound + d_tr * np.abs(I_ref - B) + 8e-16 * np.maximum(I_ref, B)
+            I_ref = orc.transmission(tr, I_ref, B)
+            for i in range(n_mol):
+                futs[li * n_mol + i] = None                    # (free the 19 MB arrays as we go)
+    toa = column.results()["toa"]
+    e = np.abs(toa - I_ref)
+    i = int(np.argmax(e / I_bound))
+    print("C5 top-of-atmosphere radiance, every point: max rel err %.3e (point %d, bound there %.1e relative); "
+          "worst cross section / absorption coefficient of the 30 layers %.3e"
+          % (float(np.max(e / I_ref)), i, float(I_bound[i] / I_ref[i]), worst_all))
+    assert np.all(e <= I_bound), (float((e / I_bound).max()), i)
+    assert float(np.max(e / I_ref)) <= 1e-11
     column.free()
+
+
+@pytest.mark.parametrize("W", [639, 640, 641, 642, 643, 738, 770])
+def test_whole_spectrum_windows_at_the_kernel_routing_boundary(ctx, W):
+    """Windows either side of the far-field kernel's lower limit (H = W - 2 < 640 points routes a line list to the
+    skewed-range kernel) and the 738-point window of the column (spans that have no far line at all), through the
+    DEFAULT routing on a grid large enough for it to engage (3 x 2.4e6 points): every point against the C oracle."""
+    from oracle import pyrad_oracle as orc
+    from pyrad_amd import engine
+    P = (W - 0.5) * 0.001 * 1013.25 / 5.0
+    cfg = synthetic.config_c3(n_lines=30000)
+    cfg = dict(cfg, P=P, T=250)
+    mols = mols_of(cfg)
+    g = orc.layer_grid(cfg["P"], cfg["range_min"], cfg["range_max"], cfg["base_resolution"], cfg["dynamic_resolution"])
+    assert g["W"] == W and g["resolution"] == g["base_resolution"]
+    ref, k_ref = oracle_layer(cfg, mols, g)
+    xa = orc.x_axis(cfg["range_min"], cfg["range_max"], cfg["base_resolution"])
+    tol = point_tolerance(xa, cfg["T"], g["dfc"])
+    L = engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"], mols,
+                             cfg["base_resolution"], cfg["dynamic_resolution"])
+    assert L.evals == sum(r[2] for r in ref)
+    L.enqueue(surface_T=288)
+    lst, tabs, _ = ctx.schedule_export(0)
+    skew = tabs.shape[0] * 512 >= 3 * g["n_work"] > tabs.shape[0] * 256          # spans of 512 points: the skewed-range kernel
+    assert skew == (W - 2 < 640), (W, tabs.shape)
+    for i, m in enumerate(mols):
+        worst("W = %d (%s kernel) %s xsec" % (W, "skewed-range" if skew else "far-field", m["species"]), L.xsec_host(i), ref[i][0], tol)
+    worst("W = %d abs_coef" % W, L.results()["abs_coef"], k_ref, tol)
+    L.free()
