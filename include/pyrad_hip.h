@@ -137,6 +137,14 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "debug_ablate"           ONLY in diagnostic builds of the library (make EXTRA=-DLBL_DIAG): timing experiments,
  *                            bits switch off parts of kernels, results are wrong.  The production library has no
  *                            such code in its kernels and answers LBL_ERR_BAD_ARG (unknown option)
+ *   "accuracy"               0 (default) "exact": every array as close to the reference's fp64 values as the arithmetic allows
+ *                            (measured 1e-14 at every grid point of every BASELINE configuration) |
+ *                            1 "budget": <= 1e-9 relative on the absorption coefficient (BASELINE north_star asks for 1e-6),
+ *                            everything still fp64: 18 instead of 30 far-field series terms (remainder <= 5.9e-10 of a
+ *                            line's own term), the Gaussian part of a pseudo-Voigt line dropped where it is below 2^-34
+ *                            of the line's Lorentz part (exact: 2^-54), absorption coefficient as cross section x one
+ *                            host-computed factor conc P / 1E4 / k / T, Planck and transmittance without the correctly
+ *                            rounded division chains.  Applies to the batches and sweeps enqueued after the call
  *   "schedule_build"         1 (default) span tables and dispatch order of a launch group are built on the device, in
  *                            stream, by the first batch that uses them (no host search, no copy, no wait) | 0 on the host
  *                            (one thread; 4 ms for the 100-2500 cm^-1 cell, 80 ms for a 30-layer column).  Same tables,

@@ -958,6 +958,31 @@ __device__ __forceinline__ void wave_sum_rows(double (&C)[NT], double* scratch, 
     __builtin_amdgcn_wave_barrier();
 }
 
+// Terms a chunk of far lines needs, by the distance d (in half-spans) of its NEAREST line from the span centre:
+// rho <= 1/d, and the remainder bound above falls fast with d.  Exact mode (NT = 30, remainder below half an ulp of
+// the line's own smallest term on the span): d >= 8: 20 terms (2.7e-17), d >= 16: 15 (1.7e-17), d >= 32: 12 (1.2e-17).
+// Budget mode (NT = 18, 5.9e-10): d >= 8: 12 (2.8e-10), d >= 16: 9 (1.8e-10), d >= 32: 7 (2.6e-10).  With a window of
+// +-39 half-spans two thirds of the far lines are beyond 16 half-spans: 17 terms on average instead of 30.
+template <int NT> struct FarTerms {
+    static constexpr int t8 = NT >= 30 ? 20 : (NT >= 18 ? 12 : NT);
+    static constexpr int t16 = NT >= 30 ? 15 : (NT >= 18 ? 9 : NT);
+    static constexpr int t32 = NT >= 30 ? 12 : (NT >= 18 ? 7 : NT);
+};
+
+// q_N0 .. q_{N1-1} of one line per lane added to the per-lane sums (qa, qb: q_{N0-2}, q_{N0-1}; carried on)
+template <int N0, int N1, int NT>
+__device__ __forceinline__ void series_terms(double al, double bp, double& qa, double& qb, double (&C)[NT]) {
+#pragma unroll
+    for (int n = N0; n < N1; ++n) {
+        const double qn = fma(al, qb, -(bp * qa));
+        C[n] += qn;
+        // (an empty statement the scheduler may not move code across: without it the compiler runs the whole chain of
+        // q_n first and sinks the additions behind the term-count branches - 20 more live values, spilled in the loop)
+        if ((n & 1) == 1) asm volatile("" : "+v"(C[n]));
+        qa = qb; qb = qn;
+    }
+}
+
 // Series coefficients of the far lines m0, m0+stride*k.. (chunks of 64, one line per lane) below m1.
 template <int R, int NT>
 __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec* cold, int m0, int m1, int stride,
@@ -1013,11 +1038,18 @@ __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec
         C[0] += qa;
         double qb = al * qa;
         C[1] += qb;
-#pragma unroll
-        for (int n = 2; n < NT; ++n) {
-            const double qn = fma(al, qb, -(bp * qa));
-            C[n] += qn;
-            qa = qb; qb = qn;
+        // the chunk's nearest line (centres are sorted and a call stays on one side of the span: the first or the last
+        // valid lane) decides how many terms the whole chunk takes; wave-uniform branch
+        const int nv = min(64, m1 - c0);
+        const double dmin = fmin(fabs(readlane_f64(w0.x, 0) - xc), fabs(readlane_f64(w0.x, nv - 1) - xc));
+        typedef FarTerms<NT> FT;
+        series_terms<2, FT::t32, NT>(al, bp, qa, qb, C);
+        if (dmin < 32.0 * hh) {
+            series_terms<FT::t32, FT::t16, NT>(al, bp, qa, qb, C);
+            if (dmin < 16.0 * hh) {
+                series_terms<FT::t16, FT::t8, NT>(al, bp, qa, qb, C);
+                if (dmin < 8.0 * hh) series_terms<FT::t8, NT, NT>(al, bp, qa, qb, C);
+            }
         }
     }
 }
@@ -1304,6 +1336,9 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
             skew_edges<R>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, lh, lc, s_ecnt[EDGE_SKEW ? wave : 0][0],
                           s_ecnt[EDGE_SKEW ? wave : 0][1], lane, S);
         if (any_far) {
+            // the running fraction of the edge lines is folded in first: N = 0, D = 1 are then constants through the series
+            // phase instead of 16 live registers beside its 60 of coefficients (28 instructions per span)
+            S.flush();
             constexpr int NTC = FF ? NT : 2;               // (the array of the instantiations without the series is never touched)
             double C[NTC];
 #pragma unroll

@@ -84,6 +84,12 @@ class Engine:
 
     def __init__(self, device: int = 0):
         self.ctx = nat.Context(device)
+        if settings.ACCURACY == "budget":
+            self.ctx.set_option("accuracy", 1)
+        # page-locked staging for the arrays getters hand back (hipHostMalloc of 32 MiB takes ~6 ms: paid with the
+        # engine, once per process, instead of inside the first getter; the pool grows on demand)
+        if settings.PINNED_POOL_BYTES > 0:
+            self.ctx.host_array(settings.PINNED_POOL_BYTES // 8)
         self._line_masters = {}          # id(master wavenumber array) -> (resident nat.Lines, master dict)
 
     def pooled_lines(self, lines: dict):

@@ -8,9 +8,25 @@ RES_MULTIPLIER = 1
 BASE_RESOLUTION = .01 * RES_MULTIPLIER
 VERSION = '1.75'
 DEVICE = 0          # HIP device index used by the default engine
+PINNED_POOL_BYTES = 32 << 20     # page-locked host staging allocated with the engine (0: allocate on first use)
 
 
 def set_resolution_multiplier(mult):
     global RES_MULTIPLIER, BASE_RESOLUTION
     RES_MULTIPLIER = mult
     BASE_RESOLUTION = .01 * mult
+
+
+ACCURACY = "exact"  # "exact": the device reproduces the reference's fp64 values to 1e-14 (default);
+                    # "budget": <= 1e-9 relative on the absorption coefficient, still fp64, faster (lbl_set_option "accuracy")
+
+
+def set_accuracy(mode):
+    """Accuracy mode of the default engine, now and for engines created later."""
+    global ACCURACY
+    if mode not in ("exact", "budget"):
+        raise ValueError("accuracy mode must be 'exact' or 'budget'")
+    ACCURACY = mode
+    from . import engine
+    if engine._engine is not None and engine._engine.ctx.h is not None:
+        engine._engine.ctx.set_option("accuracy", 1 if mode == "budget" else 0)
