@@ -84,7 +84,7 @@ struct AccumJob {
     // Fused layer step of a single-line-list layer (lbl_layer_step_dev): the sweep of a point runs in
     // this job's output stage with the molecule's volume fraction `conc`.
     int32_t chain_flags;
-    int32_t ablate;        // LBL_DIAG builds only (lbl_set_option debug_ablate): timing-only runs skip parts of the kernel; else 0 and never read
+    int32_t ablate;        // LBL_DIAG builds only (lbl_set_option debug_ablate, scripts/ablate.sh): timing-only runs skip parts of the kernel; else 0 and never read
     double conc;
     FusedSweep fuse;       // fuse.on: sweep every point right after its cross section is final
 };
@@ -166,7 +166,7 @@ struct ColumnStepArgs {
     double pbk_surface;
     int32_t term_flags[kMaxColumnIso];
     int32_t n_terms, n_layers;
-    int32_t ablate;                     // LBL_DIAG builds only (lbl_set_option debug_ablate): timing-only variants; else 0 and never read
+    int32_t ablate;                     // LBL_DIAG builds only (lbl_set_option debug_ablate, scripts/ablate.sh): timing-only variants; else 0 and never read
     int32_t layer_arrays;               // any of trans[] / abs_coef[] set
     double r_surface_T;
     double* trans[kMaxLayers];          // optional per-layer transmittance outputs

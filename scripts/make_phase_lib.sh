@@ -21,7 +21,7 @@ def rep(a, b):
     assert a in s, a[:60]
     s = s.replace(a, b, 1)
 rep("    constexpr bool FF = NT > 0;\n", "    constexpr bool FF = NT > 0;\n    unsigned long long t_ph[5] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0};\n")
-rep("        if (any_far) {\n            constexpr int NTC", "        t_ph[1] = __builtin_amdgcn_s_memrealtime();\n        if (any_far) {\n            constexpr int NTC")
+rep("        if (any_far) {\n            // the running fraction of the edge lines", "        t_ph[1] = __builtin_amdgcn_s_memrealtime();\n        if (any_far) {\n            // the running fraction of the edge lines")
 rep("        // the direct classes: left-edge, near and right-edge lines.", "        t_ph[2] = __builtin_amdgcn_s_memrealtime();\n        // the direct classes: left-edge, near and right-edge lines.")
 rep("    // Results leave through LDS so that every store instruction writes 512 contiguous bytes\n    // (a lane owns R CONSECUTIVE points;", "    t_ph[3] = __builtin_amdgcn_s_memrealtime();\n    // Results leave through LDS so that every store instruction writes 512 contiguous bytes\n    // (a lane owns R CONSECUTIVE points;")
 marker = """                    fused_finish(J.fuse, wlo + o, kk);

@@ -1,5 +1,7 @@
-"""Diagnostic (needs the instrumented build scripts/bin/libpyrad_hip_dbg.so): per-wave start/end
-realtime and placement of the LS accumulate kernel on C2."""
+"""Diagnostic (needs the instrumented build scripts/bin/libpyrad_hip_phase.so, scripts/make_phase_lib.sh): per-wave
+start/end realtime and placement (XCD, CU, SIMD) of the far-field accumulate kernel; scripts/phase_times.py splits the
+same stamps by phase.
+    WORKLOAD=C3 SHARD=8,4 PYRAD_HIP_LIB=$PWD/scripts/bin/libpyrad_hip_phase.so python scripts/wave_times.py"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,12 +26,12 @@ for _ in range(3):
 ctx.sync()
 pts = L.count * len(L.jobs)
 nb = 8 * ((pts // (64 * int(os.environ.get("R", "4")) * (4 // int(os.environ.get("LS", "1" if workload != "C2" else "2")))) + 8) // 8)
-n = nb * 4 * 3
+n = nb * 4 * 6
 buf = (C.c_uint64 * n)()
 ctx.lib.lbl_debug_times.restype = C.c_int
 ctx.lib.lbl_debug_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 ctx.lib.lbl_debug_times(ctx.h, buf, n)
-t = np.array(buf[:n], dtype=np.uint64).reshape(-1, 3)
+t = np.array(buf[:n], dtype=np.uint64).reshape(-1, 6)[:, [0, 4, 5]]       # entry, exit, placement (the phase stamps between)
 t = t[t[:, 1] > 0]
 t0 = float(t[:, 0].min())
 start = (t[:, 0].astype(np.float64) - t0) / 100.0
