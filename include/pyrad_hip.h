@@ -140,8 +140,8 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "accuracy"               0 (default) "exact": every array as close to the reference's fp64 values as the arithmetic allows
  *                            (measured 1e-14 at every grid point of every BASELINE configuration) |
  *                            1 "budget": <= 1e-9 relative on the absorption coefficient (BASELINE north_star asks for 1e-6),
- *                            everything still fp64: 18 instead of 30 far-field series terms (remainder <= 5.9e-10 of a
- *                            line's own term), the Gaussian part of a pseudo-Voigt line dropped where it is below 2^-34
+ *                            everything still fp64: 18 / 12 / 9 / 7 far-field series terms by distance instead of 30 / 20 / 15 / 12
+ *                            (remainder <= 5.9e-10 of a line's own term), the Gaussian part of a pseudo-Voigt line dropped where it is below 2^-34
  *                            of the line's Lorentz part (exact: 2^-54), absorption coefficient as cross section x one
  *                            host-computed factor conc P / 1E4 / k / T, Planck and transmittance without the correctly
  *                            rounded division chains.  Applies to the batches and sweeps enqueued after the call

@@ -86,7 +86,7 @@ struct lbl_ctx {
     std::vector<std::unique_ptr<Schedule>> schedules;
     int accuracy = 0;        // 0 exact (default): every result as close to the reference's fp64 as the arithmetic allows (1e-14);
                              // 1 budget: <= 1e-9 relative on the absorption coefficient (north_star asks 1e-6), still fp64:
-                             // 18 instead of 30 far-field terms, Gaussian cut-off at 2^-34 instead of 2^-54 of the line's
+                             // 18..7 far-field series terms by distance (exact: 30..12), Gaussian cut-off at 2^-34 instead of 2^-54 of the line's
                              // Lorentz term, one-factor absorption coefficient and cheaper Planck / exp in the sweeps
     int sched_build = 1;     // 1 (default): span tables and dispatch order built on the device, in stream; 0: on the host
     DeviceArena sched;       // scratch of the device build
@@ -784,8 +784,8 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
     const bool far_field = variant == 5;
     int far_half_spans = 0;
     double far_cost = 1.0;
-    if (far_field) accumulate_far_field_params(R, &far_half_spans, &far_cost);
-    key.push_back((uint64_t)R << 32 | (uint64_t)LS << 8 | (uint64_t)ctx->sched_build << 4 | (uint64_t)ctx->lpt << 1 | (uint64_t)far_field);
+    if (far_field) accumulate_far_field_params(R, &far_half_spans, &far_cost, ctx->accuracy);      // (the span tables hold the far bounds)
+    key.push_back((uint64_t)R << 32 | (uint64_t)far_half_spans << 16 | (uint64_t)LS << 8 | (uint64_t)ctx->sched_build << 4 | (uint64_t)ctx->lpt << 1 | (uint64_t)far_field);
     for (int j : jobs_in_group) {
         long long sf, sc;
         shard_range(grid[j], &sf, &sc);

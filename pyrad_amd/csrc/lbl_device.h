@@ -198,7 +198,7 @@ void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R,
 void launch_accumulate_skew(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, const int2* worklist, int total_tiles,
                             hipStream_t s);
 int accumulate_tile_points(int R, int LS, int variant);
-void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost);
+void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost, int budget = 0);
 // balanced variant (4): span ranges -> prefix sum -> equal shares of (span, line) pairs per wave -> slab reduce
 int balanced_workers(int R, int n_cu);
 void launch_accumulate_balanced(const AccumJob* d_jobs, int n_jobs, int total_spans, int R, int n_workers,

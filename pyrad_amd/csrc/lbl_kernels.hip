@@ -899,11 +899,16 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
 constexpr int FF_FAR = LBL_FF_FAR;   // a line is far when |c - xc| >= FF_FAR * (32 R)
 constexpr int FF_NT = LBL_FF_NT;     // series terms (exact mode: remainder below half an ulp)
 // Budget mode (lbl_set_option "accuracy" 1: <= 1e-9 relative on the absorption coefficient instead of the last bits;
-// BASELINE north_star asks for 1e-6): 18 terms.  With rho <= 1/4 the remainder after NT terms is at most
-// rho^NT (NT (1 - rho) + 1) (1 + rho)^2 / (1 - rho)^2 of the line's own smallest term on the span: 5.9e-10 at NT = 18
-// for a line exactly at the threshold, falling by 4x per further half-span; every term of the sum is positive, so the
-// sum's relative error is below the worst line's.
+// BASELINE north_star asks for 1e-6).  The remainder after NT terms is at most
+// rho^NT (NT (1 - rho) + 1) (1 + rho)^2 / (1 - rho)^2 of the line's own smallest term on the span; every term of the sum
+// is positive, so the sum's relative error is below the worst line's.  At rho <= 1/4: 5.9e-10 with 18 terms, falling by
+// 4x per further half-span.
 constexpr int FF_NT_BUDGET = 18;
+// (Measured and dropped: far from 3 half-spans on in budget mode - rho <= 1/3, 24 terms leave 2.4e-10 - takes a quarter of
+// the near lines out of the direct loop but lengthens the reduction and the polynomial: C3 K2 231.9 vs 230.5 us, C2 55.1 vs
+// 50.2, the column 3.78 vs 3.90 ms: no gain overall.  The threshold stays a template constant per mode.)
+constexpr int FF_FAR_BUDGET = 4;
+template <int NT> struct FarThreshold { static constexpr int value = NT == FF_NT_BUDGET ? FF_FAR_BUDGET : FF_FAR; };
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_move_f64(double v) {
@@ -964,9 +969,11 @@ __device__ __forceinline__ void wave_sum_rows(double (&C)[NT], double* scratch, 
 // Budget mode (NT = 18, 5.9e-10): d >= 8: 12 (2.8e-10), d >= 16: 9 (1.8e-10), d >= 32: 7 (2.6e-10).  With a window of
 // +-39 half-spans two thirds of the far lines are beyond 16 half-spans: 17 terms on average instead of 30.
 template <int NT> struct FarTerms {
-    static constexpr int t8 = NT >= 30 ? 20 : (NT >= 18 ? 12 : NT);
-    static constexpr int t16 = NT >= 30 ? 15 : (NT >= 18 ? 9 : NT);
-    static constexpr int t32 = NT >= 30 ? 12 : (NT >= 18 ? 7 : NT);
+    static constexpr bool exact = NT == FF_NT, budget = NT == FF_NT_BUDGET;
+    static constexpr int t4 = budget ? 18 : NT;            // (exact mode's threshold IS 4 half-spans: its nearest class takes all NT)
+    static constexpr int t8 = exact ? 20 : (budget ? 12 : NT);
+    static constexpr int t16 = exact ? 15 : (budget ? 9 : NT);
+    static constexpr int t32 = exact ? 12 : (budget ? 7 : NT);
 };
 
 // q_N0 .. q_{N1-1} of one line per lane added to the per-lane sums (qa, qb: q_{N0-2}, q_{N0-1}; carried on)
@@ -1048,7 +1055,10 @@ __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec
             series_terms<FT::t32, FT::t16, NT>(al, bp, qa, qb, C);
             if (dmin < 16.0 * hh) {
                 series_terms<FT::t16, FT::t8, NT>(al, bp, qa, qb, C);
-                if (dmin < 8.0 * hh) series_terms<FT::t8, NT, NT>(al, bp, qa, qb, C);
+                if (dmin < 8.0 * hh) {
+                    series_terms<FT::t8, FT::t4, NT>(al, bp, qa, qb, C);
+                    if (FT::t4 < NT && dmin < 4.0 * hh) series_terms<FT::t4, NT, NT>(al, bp, qa, qb, C);
+                }
             }
         }
     }
@@ -1318,8 +1328,9 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         // interior lines at least FF_FAR half-spans from the span centre go through the series; the
         // chunks of every class are dealt round-robin to the LS waves, each class starting at a
         // different wave so that the short classes do not all land on wave 0
-        const long long fl = (long long)wlo + 32 * R - 1 - (long long)FF_FAR * 32 * R;
-        const long long fr = (long long)wlo + 32 * R + (long long)FF_FAR * 32 * R;
+        constexpr int FAR = FarThreshold<NT>::value;
+        const long long fl = (long long)wlo + 32 * R - 1 - (long long)FAR * 32 * R;
+        const long long fr = (long long)wlo + 32 * R + (long long)FAR * 32 * R;
         const double xc = (double)wlo + (32.0 * R - 0.5);
         int iA, iB, iC, iD, iF1, iF2;
         if (tab) {           // wave-uniform values: keep them in scalar registers
@@ -2474,10 +2485,10 @@ void launch_accumulate_skew(const AccumJob* d_jobs, int n_jobs, int max_tiles, i
 
 // far-field threshold (in half-spans of 32 R points) and the cost of a far line relative to a near
 // one (3 instructions per series term and 64 lines against 5 R per line), for the host's schedule
-void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost) {
-    *far_half_spans = FF_FAR;
-    *far_cost = (3.0 * FF_NT + 12.0) / 64.0 / (5.0 * R);          // (priced at the exact mode's term count in either mode:
-}                                                                  //  one schedule serves both)
+void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost, int budget) {
+    *far_half_spans = budget ? FF_FAR_BUDGET : FF_FAR;
+    *far_cost = (3.0 * 17.0 + 12.0) / 64.0 / (5.0 * R);           // (17 terms: the average over a +-39 half-span window, either mode)
+}
 
 // grid points one workgroup covers
 int accumulate_tile_points(int R, int LS, int variant) {

@@ -88,8 +88,10 @@ class Engine:
             self.ctx.set_option("accuracy", 1)
         # page-locked staging for the arrays getters hand back (hipHostMalloc of 32 MiB takes ~6 ms: paid with the
         # engine, once per process, instead of inside the first getter; the pool grows on demand)
+        # (two blocks: a caller usually still holds the previous spectrum when it asks for the next)
         if settings.PINNED_POOL_BYTES > 0:
-            self.ctx.host_array(settings.PINNED_POOL_BYTES // 8)
+            keep = [self.ctx.host_array(settings.PINNED_POOL_BYTES // 8) for _ in range(2)]
+            del keep
         self._line_masters = {}          # id(master wavenumber array) -> (resident nat.Lines, master dict)
 
     def pooled_lines(self, lines: dict):

@@ -24,6 +24,11 @@ def cell(wl, profile):
     data.set_source(data.synthetic_source({m["species"]: m["lines"] for m in cfg["molecules"]}))
     model.Layer.hasAtmosphere = False
     engine.get_engine()                      # context creation is not part of any leg
+    if "--warm" in sys.argv:                 # the HIP runtime's own first-use costs (first hipMalloc, first copies) paid by a small cell
+        w = model.Layer(10.0, 296, 1013.25, 600, 601, dynamicResolution=False)
+        w.addMolecule(cfg["molecules"][0]["species"], ppm=400)
+        model.getAbsCoef(w)
+        print("---- warmed up", file=sys.stderr)
 
     def build():
         layer = model.Layer(cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"], dynamicResolution=False)

@@ -11,7 +11,7 @@ Tolerance: conftest.point_tolerance (per point: 2e-12 + the nu -> 0 amplificatio
 stimulated-emission factor stated in ulps); the worst point of every comparison is printed.
 
 Every test runs in both accuracy modes of the library (lbl_set_option "accuracy"): "exact" (the default; tolerance as
-above, measured 1e-14) and "budget" (18 far-field terms, Gaussian cut-off at 2^-34 of the line's Lorentz term, one-factor
+above, measured 1e-14) and "budget" (18..7 far-field series terms by distance, Gaussian cut-off at 2^-34 of the line's Lorentz term, one-factor
 absorption coefficient, cheaper Planck / exp: stated bound 1e-9 relative on the absorption coefficient, which replaces the
 2e-12 of the per-point tolerance; BASELINE north_star asks for 1e-6).
 """
