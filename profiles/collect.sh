@@ -1,12 +1,12 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box:
-#   gpurun -- 'bash profiles/collect.sh r02 C3'     (workloads: C1 C2 C3 C5; a third argument G,r profiles one shard)
+#   gpurun -- 'bash profiles/collect.sh r04 C3'     (workloads: C1 C2 C3 C5; a third argument G,r profiles one shard)
 # writes gpurun_out/<tag>/..., which profiles/summarize.py turns into the committed summaries
 # (gpurun_out/<tag>/final/: copy its files into profiles/).
 # Counters are collected in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass,
 # MI355X_MICROARCH.md "rocprofv3 PMC slots") and never together with the trace domains.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 WORKLOAD=${2:-C3}
 SHARD=$3          # optional "G,r": shard r of a G-way sharding (what a rank of a G-GPU run computes); label <workload>s<G>
 R=$GRAFT_REPO_ROOT
@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 WL=$WORKLOAD
 EXTRA=""
 if [ -n "$SHARD" ]; then WL=${WORKLOAD}s${SHARD%%,*}; EXTRA="--shard-of $SHARD"; fi
-CMD="$R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-api-path --no-direct-pass --workload $WORKLOAD $EXTRA"
+CMD="$R/bench.py --steps 20 --warmup 3 --blocks 1 --no-cpu-baseline --no-api-path --no-direct-pass --workload $WORKLOAD $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$WL -- python3 $CMD > $OUT/trace_$WL.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$WL -- python3 $CMD > $OUT/pmc_fetch_$WL.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$WL -- python3 $CMD > $OUT/pmc_write_$WL.log 2>&1
@@ -24,6 +24,16 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES GRBM_G
 # summaries first (pmc_traffic.json then carries this build's source hash), then the bench line that quotes them
 python3 $R/profiles/summarize.py $OUT $TAG $WL > $OUT/summary_$WL.txt
 python3 $R/bench.py --steps 20 --warmup 3 --workload $WORKLOAD $EXTRA > $R/profiles/${TAG}_${WL}_bench.json 2> $OUT/bench_$WL.err
+# which box was this?  every collection appends its line to the round's list (profiles/<tag>_boxes.jsonl): the set is collected
+# ONCE per round, whatever box comes up; the steady-state blocks inside the bench line say how much this box scatters
+python3 - "$R/profiles/${TAG}_${WL}_bench.json" "$R/profiles/${TAG}_boxes.jsonl" "$WL" <<'PY'
+import json, sys, time, socket
+d = json.load(open(sys.argv[1]))
+rec = {"workload": sys.argv[3], "ms_per_step": d["ms_per_step"], "blocks": d.get("ms_per_step_blocks", {}).get("blocks"),
+       "budget_ms_per_step": (d.get("budget_leg") or {}).get("ms_per_step"), "utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+       "host": socket.gethostname(), "source": "profiles/collect.sh"}
+open(sys.argv[2], "a").write(json.dumps(rec) + "\n")
+PY
 # everything to commit, where gpurun brings it back from
 mkdir -p $OUT/final
 cp $R/profiles/${TAG}_${WL}_* $R/profiles/pmc_traffic.json $OUT/final/

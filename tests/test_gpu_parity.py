@@ -713,27 +713,56 @@ def test_far_field_random_against_direct_kernel(ctx, seed):
     assert rel_err(series, direct) <= 5e-14, (seed, g["W"], R, LS)
 
 
-def test_schedule_cache_survives_eviction(ctx):
-    """The host schedule (dispatch order + per-span line ranges) is cached per (line lists, grid), 16
-    entries, least recently used out first: 40 different grids in one context, revisited in another
-    order, give the same bits as on first sight."""
+def resident_xsec(ctx, dev_lines, species, conc, T, P, rmin, rmax, base, dyn):
+    """one resident accumulate batch (lbl_xsec_accumulate_dev: the path that builds and caches dispatch schedules; the
+    one-shot lbl_xsec_accumulate of device_xsec never does) -> (cross section, regime counts)"""
+    from pyrad_amd import _native as nat, engine
+    g = engine.layer_grid(P, rmin, rmax, base, dyn)
+    sp = synthetic.SPECIES[species]
+    iso = nat.IsoParams(float(T), float(P), float(conc), sp["molmass"], synthetic.q_value(species, T), sp["q296"])
+    out = ctx.buffer(max(g["n_base"], 1)).fill(float("nan"))
+    try:
+        ctx.xsec_accumulate_dev([(dev_lines, iso, engine.native_grid(g), out)])
+        return out.download(g["n_base"]), tuple(ctx.last_regime_counts(1)[0])
+    finally:
+        out.free()
+
+
+@pytest.mark.parametrize("build", [1, 0])
+def test_schedule_cache_survives_eviction(ctx, build):
+    """The schedule (dispatch order + per-span line ranges; built on the device or on the host) is cached per (line
+    lists, grid), 16 entries, least recently used out first: 40 different grids over one resident line list, revisited in
+    another order, give the same bits as on first sight - and as the kernel that searches its ranges itself."""
     lines = synthetic.make_lines(321, 700, 630, 700)
-    first = {}
-    for i in range(40):
-        rmin = 640.0 + 0.25 * i
-        xs, _, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, rmin, rmin + 8.0, .001, False)
-        first[i] = xs
-    for i in list(range(0, 40, 3)) + [39, 0, 20]:
-        rmin = 640.0 + 0.25 * i
-        xs, _, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, rmin, rmin + 8.0, .001, False)
-        assert np.array_equal(xs, first[i]), i
+    L = ctx.lines(lines)
+    ctx.set_option("schedule_build", build)
+    try:
+        first = {}
+        for i in range(40):
+            rmin = 640.0 + 0.25 * i
+            first[i], _ = resident_xsec(ctx, L, "co2", 4e-4, 296, 1013.25, rmin, rmin + 8.0, .001, False)
+            assert np.all(np.isfinite(first[i]))
+        for i in list(range(0, 40, 3)) + [39, 0, 20]:
+            rmin = 640.0 + 0.25 * i
+            xs, _ = resident_xsec(ctx, L, "co2", 4e-4, 296, 1013.25, rmin, rmin + 8.0, .001, False)
+            assert np.array_equal(xs, first[i]), i
+        ctx.set_option("accum_longest_first", 0)              # no schedule: every wave searches the centre indices
+        for i in (0, 17, 39):
+            rmin = 640.0 + 0.25 * i
+            xs, _ = resident_xsec(ctx, L, "co2", 4e-4, 296, 1013.25, rmin, rmin + 8.0, .001, False)
+            assert np.array_equal(xs, first[i]), i
+    finally:
+        ctx.set_option("accum_longest_first", 4)
+        ctx.set_option("schedule_build", 1)
+        L.free()
 
 
-def test_host_span_tables_agree_with_device_search(ctx):
-    """The host tabulates every span's line ranges from its own evaluation of the centre index; the
-    kernel without a schedule (positional order) searches the indices K1 wrote.  Line centres placed
-    on grid points and one ulp either side of them (where truncation decides the index), window
-    edges and far-threshold boundaries included: both paths must give the same bits."""
+def test_span_tables_agree_with_the_kernels_own_search(ctx):
+    """Three ways to a span's line ranges: the device build tabulates lower bounds of the centre indices K1 wrote; the
+    host build evaluates the centre index itself (the same IEEE expression); the kernel without a schedule searches
+    K1's indices per wave.  Line centres placed on grid points and one ulp either side of them (where truncation
+    decides the index), window edges and far-threshold boundaries included: the same bits all three ways, for the
+    default launch shape and forced ones."""
     rng = np.random.default_rng(99)
     rmin, rmax, res = 650.0, 662.0, .001
     n = 3000
@@ -747,15 +776,30 @@ def test_host_span_tables_agree_with_device_search(ctx):
     lines = dict(base, nu=np.sort(nu))
     keep = np.concatenate([[True], np.diff(lines["nu"]) > 0])
     lines = {f: v[keep] for f, v in lines.items()}
-    for R, LS in ((None, None), (4, 1), (2, 2), (1, 4)):
-        ctx.set_option("accum_longest_first", 0)
-        try:
-            a, ca, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, rmin, rmax, res, False, 5, R, LS)
-        finally:
-            ctx.set_option("accum_longest_first", 3)
-        b, cb, _, _, _ = device_xsec(ctx, lines, "co2", 4e-4, 296, 1013.25, rmin, rmax, res, False, 5, R, LS)
-        assert tuple(ca) == tuple(cb)
-        assert np.array_equal(a, b), (R, LS)
+    L = ctx.lines(lines)
+    try:
+        for R, LS in ((0, 0), (4, 1), (2, 2), (1, 4)):
+            ctx.set_option("accum_points_per_lane", R)
+            ctx.set_option("accum_line_split", LS)
+            got = {}
+            for tag, lpt, build in (("search", 0, 1), ("device", 4, 1), ("host", 4, 0), ("host, plain longest-first", 1, 1)):
+                ctx.set_option("accum_longest_first", lpt)
+                ctx.set_option("schedule_build", build)
+                got[tag] = resident_xsec(ctx, L, "co2", 4e-4, 296, 1013.25, rmin, rmax, res, False)
+                if lpt:
+                    _, tabs, on_dev = ctx.schedule_export(0)
+                    assert on_dev == (tag == "device")
+                    got[tag] += (tabs,)
+            for tag in ("device", "host", "host, plain longest-first"):
+                assert got[tag][1] == got["search"][1]
+                assert np.array_equal(got[tag][0], got["search"][0]), (R, LS, tag)
+                assert np.array_equal(got[tag][2], got["device"][2]), (R, LS, tag)
+    finally:
+        ctx.set_option("accum_longest_first", 4)
+        ctx.set_option("schedule_build", 1)
+        ctx.set_option("accum_points_per_lane", 0)
+        ctx.set_option("accum_line_split", 0)
+        L.free()
 
 
 def random_cell(rng, seed, orc, max_evals=2e6):

@@ -142,3 +142,43 @@ def test_pair_split_matches_a_brute_force_classification():
             evals += max(min(ci + H, first + cnt - 1) - max(ci - H, first) + 1, 0)
         assert got["pairs"] == pairs and got["pairs_series"] == far and got["pairs_direct"] == pairs - far, (H, n)
         assert got["evals"] == evals and got["evals_series"] == far_evals and got["evals_direct"] == evals - far_evals
+
+
+def test_memory_source_windows_are_slices_with_the_reference_semantics():
+    """MemorySource.gatherData: strict bounds (ut:437-438), duplicated wavenumbers keep the LAST row's values at the
+    FIRST row's position (ut:447) - collapsed once at registration - and every window is a zero-copy slice of the
+    registered list that data.master_slice recognises (what lets the device hand out views instead of uploads)."""
+    from pyrad_amd import data, synthetic
+    rng = np.random.default_rng(7)
+    lines = synthetic.make_lines(5, 400, 600.0, 700.0, decimals=1)             # one decimal: many duplicated wavenumbers
+    order = rng.permutation(len(lines["nu"]))
+    shuffled = {k: v[order] for k, v in lines.items()}
+    src = data.MemorySource()
+    src.register(7, shuffled, {296: 286.0}, synthetic.mol_params("co2"))
+
+    def reference(lo, hi):                       # the pre-round-4 implementation: mask, then collapse
+        o = np.argsort(shuffled["nu"], kind="stable")
+        full = {k: np.asarray(v, dtype=np.float64)[o] for k, v in shuffled.items()}
+        if "a" not in full:
+            full["a"] = np.zeros_like(full["nu"])
+        m = (full["nu"] > lo) & (full["nu"] < hi)
+        return data._dedupe_last_wins({k: v[m] for k, v in full.items()})
+
+    nu_all = np.unique(lines["nu"])
+    for lo, hi in ((599.0, 701.0), (nu_all[3], nu_all[40]), (650.0, 650.0), (nu_all[10], nu_all[10]), (640.05, 640.15), (800.0, 900.0)):
+        got, want = src.gatherData(7, lo, hi), reference(lo, hi)
+        assert set(got) == set(want)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (k, lo, hi)
+        if got["nu"].size:
+            assert got["nu"][0] > lo and got["nu"][-1] < hi and np.all(np.diff(got["nu"]) > 0)
+        hit = data.master_slice(got, ("nu", "sw", "elower", "gamma_air", "gamma_self", "n_air", "delta_air"))
+        if got["nu"].size:
+            master, first, count = hit
+            assert count == got["nu"].size and np.array_equal(master["nu"][first:first + count], got["nu"])
+            assert got["nu"].base is master["nu"]                                  # no copy
+    # anything that is not such a slice is not recognised
+    sel = src.gatherData(7, 610.0, 690.0)
+    assert data.master_slice({k: v.copy() for k, v in sel.items()}, ("nu", "sw")) is None
+    assert data.master_slice(dict(sel, sw=sel["sw"][::-1].copy()), ("nu", "sw")) is None
+    assert data.master_slice(dict(sel, sw=src.gatherData(7, 620.0, 690.0)["sw"]), ("nu", "sw")) is None
