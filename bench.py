@@ -868,8 +868,7 @@ def main():
         budget_leg = {"ms_per_step": t_bl * 1e3, "evals_per_s": float(layer.evals) / t_bl,
                       "kernel_ms_per_step": {k_: pb[k_][1] / n_extra for k_ in ("line_prep", "xsec_accumulate", "layer_sweep", "column_sweep")},
                       "what": "the same resident step with lbl_set_option accuracy = 1 (budget: 18..7 far-field series terms by distance, Gaussian cut-off "
-                              "2^-34, one-factor absorption coefficient, cheaper Planck / exp; tests hold it to 1e-9 relative on the "
-                              "absorption coefficient at every grid point): %d steps between barriers, then %d steps with every "
+                              "2^-34; tests hold it to 1e-9 relative on the absorption coefficient at every grid point): %d steps between barriers, then %d steps with every "
                               "kernel class bracketed by events; not the line's value" % (n_bl, n_extra)}
 
     # With a communicator: where the sharded step's time goes, in two short untimed passes (every rank runs

@@ -140,11 +140,15 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "accuracy"               0 (default) "exact": every array as close to the reference's fp64 values as the arithmetic allows
  *                            (measured 1e-14 at every grid point of every BASELINE configuration) |
  *                            1 "budget": <= 1e-9 relative on the absorption coefficient (BASELINE north_star asks for 1e-6),
- *                            everything still fp64: 18 / 12 / 9 / 7 far-field series terms by distance instead of 30 / 20 / 15 / 12
- *                            (remainder <= 5.9e-10 of a line's own term), the Gaussian part of a pseudo-Voigt line dropped where it is below 2^-34
- *                            of the line's Lorentz part (exact: 2^-54), absorption coefficient as cross section x one
- *                            host-computed factor conc P / 1E4 / k / T, Planck and transmittance without the correctly
- *                            rounded division chains.  Applies to the batches and sweeps enqueued after the call
+ *                            everything still fp64: 18 / 12 / 9 / 7 far-field series terms by distance instead of
+ *                            30 / 20 / 15 / 12 (remainder <= 5.9e-10 of a line's own term), the Gaussian part of a pseudo-Voigt
+ *                            line dropped where it is below 2^-34 of the line's Lorentz part (exact: 2^-54).  Applies to the
+ *                            batches enqueued after the call
+ *   "sweep_ieee_divisions"   0 (default) the sweeps form the absorption coefficient as cross section x one host-computed
+ *                            factor conc P / 1E4 / k / T, the Planck exponent as n x (100 h c / k / T), reciprocals by
+ *                            rcp + Newton steps: a few 1e-16 from | 1 the reference's own chain of correctly rounded
+ *                            divisions (k bit-identical to NumPy's crossSection * concentration * P / 1E4 / k / T on the
+ *                            same cross section; 2.5x the instructions per point and layer)
  *   "schedule_build"         1 (default) span tables and dispatch order of a launch group are built on the device, in
  *                            stream, by the first batch that uses them (no host search, no copy, no wait) | 0 on the host
  *                            (one thread; 4 ms for the 100-2500 cm^-1 cell, 80 ms for a 30-layer column).  Same tables,

@@ -87,7 +87,11 @@ struct lbl_ctx {
     int accuracy = 0;        // 0 exact (default): every result as close to the reference's fp64 as the arithmetic allows (1e-14);
                              // 1 budget: <= 1e-9 relative on the absorption coefficient (north_star asks 1e-6), still fp64:
                              // 18..7 far-field series terms by distance (exact: 30..12), Gaussian cut-off at 2^-34 instead of 2^-54 of the line's
-                             // Lorentz term, one-factor absorption coefficient and cheaper Planck / exp in the sweeps
+                             // Lorentz term
+    int sweep_ieee = 0;      // sweeps (absorption coefficient, transmittance, Planck): 0 (default) cross section x one host-computed factor
+                             // conc P / 1E4 / k / T, reciprocals by rcp + Newton, exp without the library's range tests (each result
+                             // within a few 1e-16 of the other form); 1 the reference's own chain of correctly rounded divisions
+                             // (k bit-identical to NumPy's crossSection * concentration * P / 1E4 / k / T on the same cross section)
     int sched_build = 1;     // 1 (default): span tables and dispatch order built on the device, in stream; 0: on the host
     DeviceArena sched;       // scratch of the device build
     uint64_t lines_serial = 0;
@@ -497,6 +501,9 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) try {
     } else if (!strcmp(key, "accuracy")) {
         if (value < 0 || value > 1) return fail(ctx, LBL_ERR_BAD_ARG, "accuracy must be 0 (exact) or 1 (budget: 1e-9)");
         ctx->accuracy = value;
+    } else if (!strcmp(key, "sweep_ieee_divisions")) {
+        if (value < 0 || value > 1) return fail(ctx, LBL_ERR_BAD_ARG, "sweep_ieee_divisions must be 0 or 1");
+        ctx->sweep_ieee = value;
     } else if (!strcmp(key, "schedule_build")) {
         if (value < 0 || value > 1) return fail(ctx, LBL_ERR_BAD_ARG, "schedule_build must be 0 (host) or 1 (device)");
         ctx->sched_build = value;
@@ -1466,7 +1473,7 @@ extern "C" int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* x
         a.term_factor[i] = budget_factor(conc[iso_mol[i]], P, T);
         a.term_flags[i] = (i == n_iso - 1 || iso_mol[i + 1] != iso_mol[i]) ? TERM_LAST_MOL : 0;
     }
-    a.budget = ctx->accuracy; a.pbkT = budget_pbkT(T); a.pbk_surface = budget_pbkT(surface_T);
+    a.budget = !ctx->sweep_ieee; a.pbkT = budget_pbkT(T); a.pbk_surface = budget_pbkT(surface_T);
     if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
     if ((rc = check_buf(ctx, abs_coef, n, "abs_coef", false))) return rc;
     if ((rc = check_buf(ctx, trans, n, "trans", false))) return rc;
@@ -1533,7 +1540,7 @@ extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lin
         f.trans = trans ? trans->d : nullptr;
         f.I_out = I_out ? I_out->d : nullptr;
         f.n = n; f.on = 1;
-        f.budget = ctx->accuracy; f.factor = budget_factor(conc[iso_mol[0]], f.P, f.T);
+        f.budget = !ctx->sweep_ieee; f.factor = budget_factor(conc[iso_mol[0]], f.P, f.T);
         f.pbkT = budget_pbkT(f.T); f.pbk_surface = budget_pbkT(surface_T);
         return enqueue_accumulate(ctx, 1, lines, iso, grids.data(), outs.data(), false, &f, conc[iso_mol[0]]);
     }
@@ -1568,12 +1575,14 @@ extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* cons
         a->trans[l] = trans[l]->d;
         a->layer_T[l] = layer_T[l];
         a->r_layer_T[l] = uniform_rcp(layer_T[l]);
+        a->pbkT[l] = budget_pbkT(layer_T[l]);
     }
     a->n_layers = n_layers;
     a->start = range_min; a->stop = range_max; a->step = axis_step(range_min, range_max, n);
     planck_constants(&a->pa, &a->pb);
     a->surface_T = surface_T;
     a->r_surface_T = uniform_rcp(surface_T);
+    a->pbk_surface = budget_pbkT(surface_T);
     a->I_in = I_in ? I_in->d : nullptr;
     a->I_out = I_out->d;
     a->n = n; a->first = first; a->count = count;
@@ -1581,7 +1590,7 @@ extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* cons
     void* d_args = nullptr;
     if ((rc = device_args(ctx, a, sizeof(ColumnArgs), &d_args))) return rc;
     hipEvent_t ev = prof_begin(ctx, PROF_COLUMN);
-    launch_column_sweep((const ColumnArgs*)d_args, count, ctx->stream);
+    launch_column_sweep((const ColumnArgs*)d_args, count, ctx->stream, !ctx->sweep_ieee);
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;
@@ -1657,7 +1666,7 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
     void* d_args = nullptr;
     if ((rc = device_args(ctx, a, sizeof(ColumnStepArgs), &d_args))) return rc;
     hipEvent_t ev = prof_begin(ctx, PROF_COLUMN);
-    launch_column_step((const ColumnStepArgs*)d_args, first, count, ctx->stream, ctx->accuracy);
+    launch_column_step((const ColumnStepArgs*)d_args, first, count, ctx->stream, !ctx->sweep_ieee);
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;

@@ -58,8 +58,8 @@ struct FusedSweep {
     const double* I_in;
     double* abs_coef; double* trans; double* I_out;
     long long n;
-    int32_t on, budget;             // budget: lbl_set_option "accuracy" 1 (see "budget mode of the sweeps" in lbl_kernels.hip)
-    double factor, pbkT, pbk_surface;   // budget mode: conc * P / 1E4 / k / T; 100 h c / k / T; 100 h c / k / surface_T
+    int32_t on, budget;             // budget: the sweeps' default arithmetic ("sweep_ieee_divisions" 0; see lbl_kernels.hip)
+    double factor, pbkT, pbk_surface;   // for it: conc * P / 1E4 / k / T; 100 h c / k / T; 100 h c / k / surface_T
 };
 
 struct AccumJob {
@@ -138,8 +138,8 @@ struct SweepArgs {
     const double* xsec[kMaxIso];
     double term_conc[kMaxIso];      // volume fraction of the term's molecule
     int32_t term_flags[kMaxIso];
-    double term_factor[kMaxIso];    // budget mode: conc * P / 1E4 / k / T of the term's molecule (host, the reference's order)
-    double pbkT, pbk_surface;       // budget mode: 100 h c / k / T, 100 h c / k / surface_T
+    double term_factor[kMaxIso];    // default arithmetic: conc * P / 1E4 / k / T of the term's molecule (host, the reference's order)
+    double pbkT, pbk_surface;       // default arithmetic: 100 h c / k / T, 100 h c / k / surface_T
     int32_t n_iso, n_mol;
     int32_t variant, budget;         // 1: streaming (non-temporal) loads and stores (0 in LBL_DIAG builds with debug_ablate bit 64, for A/B)
     double P, T, depth;
@@ -162,7 +162,7 @@ struct ColumnStepArgs {
     // the layer's scalars repeated per term, so that every load of a batch of terms has an address that depends
     // on the term index only (the kernel fetches them with wide scalar loads ahead of the arithmetic)
     double term_P[kMaxColumnIso], term_T[kMaxColumnIso], term_rT[kMaxColumnIso], term_depth[kMaxColumnIso];   // rT = RN(1/T) (0: plain divide)
-    double term_factor[kMaxColumnIso], term_pbkT[kMaxColumnIso];     // budget mode (see SweepArgs)
+    double term_factor[kMaxColumnIso], term_pbkT[kMaxColumnIso];     // default arithmetic (see SweepArgs)
     double pbk_surface;
     int32_t term_flags[kMaxColumnIso];
     int32_t n_terms, n_layers;
@@ -180,6 +180,7 @@ struct ColumnArgs {
     const double* trans[kMaxLayers];
     double layer_T[kMaxLayers];
     double r_layer_T[kMaxLayers];       // RN(1/layer_T[l]) (0: plain divide)
+    double pbkT[kMaxLayers], pbk_surface;   // default arithmetic: 100 h c / k / T per layer and for the surface
     double r_surface_T;
     int32_t n_layers;
     double start, stop, step, pa, pb, surface_T;
@@ -208,7 +209,7 @@ void launch_regrid(const double* work, long long n_work, double* out, long long 
                    hipStream_t s);
 void launch_layer_sweep(const SweepArgs& a, hipStream_t s);
 void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s, int budget = 0);
-void launch_column_sweep(const ColumnArgs* d_args, long long n, hipStream_t s);
+void launch_column_sweep(const ColumnArgs* d_args, long long n, hipStream_t s, int budget = 0);
 void launch_planck(double* out, long long n, double start, double stop, double T, double rT, double pa, double pb, hipStream_t s);
 int band_partial_count(long long n);
 void launch_band_integral(const double* y, long long n, double* partial, double* result, hipStream_t s);

@@ -159,13 +159,16 @@ __device__ __forceinline__ double abs_coef_term(double xs, double conc, double P
     return div_uniform(div_uniform(div_uniform(xs * conc * P, 1E4, kRcp1E4), kB, kRcpKB), T, rT);
 }
 
-// ---- budget mode of the sweeps (lbl_set_option "accuracy" 1) ---------------------------------------------------
-// The exact sweeps round where the reference's NumPy expressions round: nine correctly rounded divisions per point and
-// layer (51 of the column step's 161 instructions) and the library exp.  Budget mode keeps fp64 and spends a few ulps:
-// the molecule's factor conc * P / 1E4 / k / T comes from the host (evaluated there in the reference's order) and meets
-// the cross section in ONE multiplication; the Planck exponent is n * (100 h c / k / T) with the bracket from the host;
-// reciprocals by v_rcp_f64 + two Newton steps; exp without the library's range tests.  Each result is within a few
-// 1e-16 of the exact mode's; the tests hold the whole chain to 1e-9 on the absorption coefficient.
+// ---- the sweeps' default arithmetic (lbl_set_option "sweep_ieee_divisions" 0; flag `budget` in the argument blocks) ----
+// The reference's NumPy expressions round nine times per point and layer where it does not matter: crossSection *
+// concentration * P / 1E4 / k / T is three correctly rounded divisions (51 of the column step's 161 instructions with
+// div_uniform), and the Planck function two more plus the library exp.  The cross section entering them already differs
+// from NumPy's in its last bits (K2 is 1e-14, not bit-exact), so the chain buys nothing a comparison with the reference can
+// see.  By default the molecule's factor conc * P / 1E4 / k / T comes from the host (evaluated there in the reference's
+// order) and meets the cross section in ONE multiplication; the Planck exponent is n * (100 h c / k / T) with the bracket
+// from the host; reciprocals by v_rcp_f64 + two Newton steps; exp without the library's range tests.  Each result is within
+// a few 1e-16 of the chain's (tests/test_gpu_abi.py::test_sweep_divisions_are_ieee_exact checks both).  "sweep_ieee_divisions"
+// 1 selects the chain: k is then bit-identical to NumPy's expression applied to the same cross section.
 __device__ __forceinline__ double rcp_newton(double x) {           // x finite, positive, normal
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
@@ -2235,6 +2238,7 @@ __global__ __launch_bounds__(256) void layer_sweep_kernel(const SweepArgs A) {
 // ----------------------------------------------------------------------------------------
 // K5: column fold (pyradClasses.py:784-787 applied layer after layer)
 // ----------------------------------------------------------------------------------------
+template <bool BUDGET>
 __global__ __launch_bounds__(256) void column_sweep_kernel(const ColumnArgs* __restrict__ Ap) {
 #pragma clang fp contract(off)
     const ColumnArgs& A = *Ap;
@@ -2242,10 +2246,11 @@ __global__ __launch_bounds__(256) void column_sweep_kernel(const ColumnArgs* __r
     const long long jend = A.first + A.count;
     for (long long j = A.first + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < jend; j += stride) {
         const double nu = linspace_at(j, A.n, A.start, A.stop, A.step);
-        double I = A.I_in ? A.I_in[j] : planck_wn(nu, A.surface_T, A.r_surface_T, A.pa, A.pb);
+        double I = A.I_in ? A.I_in[j] : (BUDGET ? planck_budget(nu, A.pa, A.pbk_surface)
+                                                : planck_wn(nu, A.surface_T, A.r_surface_T, A.pa, A.pb));
         for (int l = 0; l < A.n_layers; ++l) {
             const double tr = A.trans[l][j];
-            const double B = planck_wn(nu, A.layer_T[l], A.r_layer_T[l], A.pa, A.pb);
+            const double B = BUDGET ? planck_budget(nu, A.pa, A.pbkT[l]) : planck_wn(nu, A.layer_T[l], A.r_layer_T[l], A.pa, A.pb);
             const double transmitted = tr * I;
             const double emitted = (1.0 - tr) * B;
             I = transmitted + emitted;
@@ -2606,9 +2611,10 @@ static void launch_column_step_b(const ColumnStepArgs* d_args, long long first, 
     hipLaunchKernelGGL((column_step_kernel<1, BUDGET>), dim3(sweep_blocks(count)), dim3(256), 0, s, d_args, first, count);
 }
 
-void launch_column_sweep(const ColumnArgs* d_args, long long count, hipStream_t s) {
+void launch_column_sweep(const ColumnArgs* d_args, long long count, hipStream_t s, int budget) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(column_sweep_kernel, dim3(sweep_blocks(count)), dim3(256), 0, s, d_args);
+    if (budget) hipLaunchKernelGGL(column_sweep_kernel<true>, dim3(sweep_blocks(count)), dim3(256), 0, s, d_args);
+    else hipLaunchKernelGGL(column_sweep_kernel<false>, dim3(sweep_blocks(count)), dim3(256), 0, s, d_args);
 }
 
 // emissivity / absorbance / optical depth from a transmittance array

@@ -177,6 +177,9 @@ def test_sweep_divisions_are_ieee_exact(ctx):
     k_B = 1.38064852E-23
     rng = np.random.default_rng(77)
     n = 200_000
+    # (round 4: the sweeps' default arithmetic is cross section x one host-computed factor - a few 1e-16 from this chain,
+    # checked below; "sweep_ieee_divisions" 1 selects the reference's own rounding chain, which is what must be bit-exact)
+    ctx.set_option("sweep_ieee_divisions", 1)
     cases = [(296, 1013.25, -42, -16), (217, 10.0, -42, -16), (287.65, 843.21, -42, -16), (1.0, 1e-3, -42, -16),
              (3000, 2e5, -42, -16), (255.99999999999997, 500.0, -42, -16),
              (296, 1013.25, -270, 250)]          # the whole range the 5-instruction form is stated for (lbl_kernels.hip div_uniform)
@@ -203,8 +206,16 @@ def test_sweep_divisions_are_ieee_exact(ctx):
         ctx.column_step_dev([dict(xsec=bufs, iso_mol=iso_mol, conc=conc, P=P, T=T, depth=12.5, abs_coef=k_col, trans=None)],
                             600.0, 800.0, n, out, surface_T=288.0)
         assert np.array_equal(k_col.download(n), k_ref), (T, P)
+        # the default arithmetic (one factor from the host): a few 1e-16 from the chain, zeros exactly zero
+        ctx.set_option("sweep_ieee_divisions", 0)
+        ctx.layer_sweep_dev(bufs, iso_mol, conc, P, T, 12.5, 600.0, 800.0, n, abs_coef=k_dev, trans=t_dev)
+        k_fast = k_dev.download(n)
+        ctx.set_option("sweep_ieee_divisions", 1)
+        ok = k_ref > 1e-290                                   # (below: the chain's own intermediate products go subnormal)
+        assert np.all(np.abs(k_fast[ok] - k_ref[ok]) <= 1e-15 * k_ref[ok]) and np.all(k_fast[k_ref == 0] == 0)
         for b in bufs + [k_dev, t_dev, out, k_col]:
             b.free()
+    ctx.set_option("sweep_ieee_divisions", 0)
 
 
 def test_plain_c_host_reproduces_the_reference_peak(tmp_path):

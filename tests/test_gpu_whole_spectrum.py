@@ -11,9 +11,9 @@ Tolerance: conftest.point_tolerance (per point: 2e-12 + the nu -> 0 amplificatio
 stimulated-emission factor stated in ulps); the worst point of every comparison is printed.
 
 Every test runs in both accuracy modes of the library (lbl_set_option "accuracy"): "exact" (the default; tolerance as
-above, measured 1e-14) and "budget" (18..7 far-field series terms by distance, Gaussian cut-off at 2^-34 of the line's Lorentz term, one-factor
-absorption coefficient, cheaper Planck / exp: stated bound 1e-9 relative on the absorption coefficient, which replaces the
-2e-12 of the per-point tolerance; BASELINE north_star asks for 1e-6).
+above, measured 1e-14) and "budget" (18..7 far-field series terms by distance, Gaussian cut-off at 2^-34 of the line's
+Lorentz term: stated bound 1e-9 relative on the absorption coefficient, which replaces the 2e-12 of the per-point
+tolerance; BASELINE north_star asks for 1e-6).
 """
 from concurrent.futures import ThreadPoolExecutor
 
@@ -155,7 +155,7 @@ def test_whole_spectrum_column_all_layers_and_toa_vs_c_oracle(ctx, mode):
             jobs.append((sel, c["T"], c["P"], m["conc"], iso["molmass"], iso["q_T"], iso["q296"], g))
     xa = orc.x_axis(cfgs[0]["range_min"], cfgs[0]["range_max"], cfgs[0]["base_resolution"])
     I_ref = orc.planckWavenumber(xa, col["surface_T"])
-    I_bound = 4e-16 * I_ref * (1.0 if mode == "exact" else 2.0 + 1.4387773538277202 * xa / col["surface_T"])
+    I_bound = 4e-16 * I_ref * (2.0 + 1.4387773538277202 * xa / col["surface_T"])
     worst_all = 0.0
     with ThreadPoolExecutor(max_workers=14) as ex:
         futs = [ex.submit(c_oracle.create_cross_section_work, *j) for j in jobs]
@@ -174,9 +174,9 @@ def test_whole_spectrum_column_all_layers_and_toa_vs_c_oracle(ctx, mode):
             tr = orc.transmittance(k_ref, c["depth"])
             B = orc.planckWavenumber(xa, c["T"])
             d_tr = (tol * k_ref * c["depth"] + 4e-16) * tr
-            # budget mode forms the Planck exponent as n * (100 h c / k / T): two roundings placed differently, worth
-            # b * 2^-52 relative on exp(b) (b = c2 n / T is up to 17 here), instead of the reference's operation order
-            dB = 0.0 if mode == "exact" else 6e-16 * (1.0 + 1.4387773538277202 * xa / c["T"]) * B
+            # the sweeps form the Planck exponent as n * (100 h c / k / T): two roundings placed differently from the
+            # reference's operation order, worth b * 2^-52 relative on exp(b) (b = c2 n / T is up to 17 here)
+            dB = 6e-16 * (1.0 + 1.4387773538277202 * xa / c["T"]) * B
             I_bound = tr * I_bound + d_tr * np.abs(I_ref - B) + 8e-16 * np.maximum(I_ref, B) + (1.0 - tr) * dB
             I_ref = orc.transmission(tr, I_ref, B)
             for i in range(n_mol):
