@@ -50,6 +50,17 @@ def test_default_contract():
     sw = d["roofline_sweep"]
     assert sw["kernel"] == "layer_sweep_kernel" and sw["algorithmic_bytes_per_launch"] == 8.0 * 2400000 * 6 and sw["frac"] > 0.2
     assert "api_path" in d and d["api_path"]["ms_per_call"] > 0
+    # round 4: re-windowing legs (the getter AFTER changePressure / changeRange; schedules are built on the device), the
+    # steady state in blocks, where each kernel figure comes from, the accuracy mode and the other mode's leg
+    a = d["api_path"]
+    assert 0 < a["ms_change_pressure"] < 50 and 0 < a["ms_change_range"] < 50 and a["ms_change_pressure_mutator"] >= 0
+    assert a["ms_first_call"] > 0 and a["ms_engine_create"] > 0 and "finite True" in a["rewindow_what"]
+    bl = d["ms_per_step_blocks"]
+    assert len(bl["blocks"]) == 5 and bl["blocks"][0] == pytest.approx(d["ms_per_step"], rel=1e-5) and bl["min"] <= bl["median"] <= bl["max"]
+    assert "SEPARATE pass" in d["kernel_ms_per_step"]["source"] and "TIMED REGION" in d["kernel_ms_per_step"]["source"]
+    assert d["config"]["accuracy"] == "exact" and "ablated" not in d
+    bg = d["budget_leg"]
+    assert 0 < bg["ms_per_step"] < d["ms_per_step"] * 1.02 and bg["kernel_ms_per_step"]["xsec_accumulate"] > 0
     # the headline cannot be read as 1e13 evaluated profiles per second: the direct / series split travels with it
     pr = d["pairs"]
     assert pr["pairs_direct"] + pr["pairs_series"] == pr["pairs"] and pr["evals_direct"] + pr["evals_series"] == pr["evals"]
@@ -132,3 +143,10 @@ def test_column_line_carries_the_atmosphere_api_leg():
     a = d["api_path"]
     assert a["ms_per_call"] > 0 and a["bytes_downloaded_per_call"] == 8 * 2400000 and "30 layers" in a["what"] and "finite True" in a["what"]
     assert a["evals_per_s"] > 1e11 and d["roofline_sweep"]["kernel"] == "column_step_kernel"
+    assert 0 < a["ms_change_pressure"] < 500 and "30 changePressure calls" in a["rewindow_what"]
+
+
+def test_budget_mode_line_says_so():
+    d = run_bench(["--workload", "C2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-api-path", "--accuracy", "budget",
+                   "--blocks", "2"])
+    assert d["config"]["accuracy"] == "budget" and "budget_leg" not in d and len(d["ms_per_step_blocks"]["blocks"]) == 2

@@ -132,3 +132,38 @@ def test_schedule_is_built_once_and_reused(ctx):
     ctx.sync()
     g.free()
     L.free()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_cells_device_schedule_equals_host_schedule_and_in_kernel_search(ctx, seed):
+    """random gas cells (windows from 1 point to thousands, regrid on and off, empty and tiny line lists, grids from a few
+    points to 60,000, so every launch shape: line splits, small spans, the skewed-range routing when forced) through the
+    resident path: device-built schedule, host-built schedule and no schedule at all give the same bits"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_parity import random_cell, resident_xsec
+    from oracle import pyrad_oracle as orc
+    rng = np.random.default_rng(4000 + seed)
+    cell = random_cell(rng, seed, orc)
+    if cell is None:
+        pytest.skip("degenerate grid (the reference raises)")
+    lines, species, conc, T, P, rmin, rmax, base, dyn, g = cell
+    from pyrad_amd import engine
+    L = ctx.lines(engine.select_window(lines, g["eff_min"], g["eff_max"]))
+    got = {}
+    try:
+        for skew in (1, 2):
+            ctx.set_option("accum_skew", skew)
+            for tag, lpt, build in (("search", 0, 1), ("device", 4, 1), ("host", 4, 0)):
+                ctx.set_option("accum_longest_first", lpt)
+                ctx.set_option("schedule_build", build)
+                got[tag] = resident_xsec(ctx, L, species, conc, T, P, rmin, rmax, base, dyn)
+            for tag in ("device", "host"):
+                assert got[tag][1] == got["search"][1]
+                assert np.array_equal(got[tag][0], got["search"][0], equal_nan=True), (tag, skew, g["W"], len(lines["nu"]))
+            assert np.all(np.isfinite(got["device"][0]))
+    finally:
+        ctx.set_option("accum_skew", 1)
+        ctx.set_option("accum_longest_first", 4)
+        ctx.set_option("schedule_build", 1)
+        L.free()
