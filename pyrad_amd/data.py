@@ -119,8 +119,11 @@ class PyradDataDir:
     A missing segment file is an error here (the reference would try to download it).
     """
 
-    def __init__(self, root: str):
+    def __init__(self, root: str, cache: bool = True):
         self.root = root
+        self.cache = cache               # keep parsed segments (False: read and parse on every call, as the reference does)
+        self._segments = {}              # (global_iso, segment) -> parsed file
+        self._masters = {}               # global_iso -> the sorted, duplicate-free list of its kept segments
 
     @staticmethod
     def _rows(path):
@@ -162,13 +165,19 @@ class PyradDataDir:
         return out
 
     def gatherData(self, global_iso, range_min, range_max):
+        """gatherData (ut:173-189) over readHitranOnlineFile (ut:421-448).  Parsed segments are kept (the reference re-reads
+        and re-parses the files on every range or pressure change: a 30-layer column asks for the same ten files ninety
+        times); while every kept segment of the isotopologue is well formed the window is a SLICE of one sorted,
+        duplicate-free list per isotopologue - what lets the device keep one resident copy and hand out views - and the
+        reference's row-by-row semantics are reproduced by construction (see _window_of_master); anything unusual (a row
+        filed in the wrong segment, an unparsable column) takes the row-by-row path below, which is the reference's."""
+        segs = self.segments(range_min, range_max)
+        parsed = [self._segment(global_iso, seg) for seg in segs]
+        if self.cache and all(p["clean"] for p in parsed):
+            return self._window_of_master(global_iso, range_min, range_max)
         info = {}            # nu -> row, insertion ordered, later rows override (ut:447, dict.update ut:187)
-        for segment in self.segments(range_min, range_max):
-            path = '%s/%s/%s.pyr' % (self.root, global_iso, segment)
-            rows = self._rows(path)
-            if rows is None:
-                raise FileNotFoundError("%s (PyRad would download it; this build has no network code)" % path)
-            for row in rows:
+        for seg, p in zip(segs, parsed):
+            for row in p["rows"]:
                 cell = row.split(',')                          # a malformed row raises IndexError / ValueError, as ut:434-446
                 nu = float(cell[2])
                 if range_min < nu and nu < range_max:          # ut:437-438
@@ -183,6 +192,60 @@ class PyradDataDir:
                "gamma_self": vals[:, 4], "delta_air": vals[:, 5], "n_air": vals[:, 6]}
         order = np.argsort(nu, kind="stable")
         return {k: np.ascontiguousarray(v[order]) for k, v in out.items()}
+
+    def _segment(self, global_iso, segment):
+        """One segment file, read once (again if its size or modification time changes): its rows as text, and - when every
+        row parses and lies inside the segment's own 100 cm^-1 - as arrays ("clean")."""
+        path = '%s/%s/%s.pyr' % (self.root, global_iso, segment)
+        try:
+            st = os.stat(path)
+            stamp = (st.st_mtime_ns, st.st_size)
+        except OSError:
+            stamp = None
+        key = (global_iso, segment)
+        hit = self._segments.get(key) if self.cache else None
+        if hit is not None and hit["stamp"] == stamp:
+            return hit
+        rows = self._rows(path)
+        if rows is None:
+            raise FileNotFoundError("%s (PyRad would download it; this build has no network code)" % path)
+        p = {"stamp": stamp, "rows": rows, "clean": False}
+        try:
+            cells = [row.split(',') for row in rows]
+            nu = np.array([float(c[2]) for c in cells], dtype=np.float64)
+            for c in cells:
+                int(c[1])
+            vals = np.array([[float(c[k]) for k in range(3, 10)] for c in cells], dtype=np.float64).reshape(len(cells), 7)
+            p.update(nu=nu, vals=vals, clean=bool(np.all((nu >= segment) & (nu < segment + 100))) if nu.size else True)
+        except (IndexError, ValueError):
+            pass                                               # the row-by-row path raises where (and only if) the reference would
+        if self.cache:
+            self._segments[key] = p
+            self._masters.pop(global_iso, None)                # the isotopologue's list is rebuilt from its kept segments
+        return p
+
+    def _window_of_master(self, global_iso, range_min, range_max):
+        """All kept, well-formed segments of the isotopologue as one list in the reference's visiting order (segments
+        ascending, rows in file order), duplicated wavenumbers collapsed last-wins (ut:447), sorted; a window is a slice.
+        Equal to the row-by-row result: a well-formed row with range_min < nu < range_max lies in a segment the window
+        visits, rows of equal nu are in or out of a window together, and among them the last in visiting order wins
+        either way."""
+        m = self._masters.get(global_iso)
+        if m is None:
+            keys = sorted(k for k in self._segments if k[0] == global_iso and self._segments[k]["clean"])
+            nu = np.concatenate([self._segments[k]["nu"] for k in keys]) if keys else np.zeros(0)
+            vals = np.concatenate([self._segments[k]["vals"] for k in keys]) if keys else np.zeros((0, 7))
+            order = np.argsort(nu, kind="stable")
+            full = {"nu": nu[order], "sw": vals[order, 0], "a": vals[order, 1], "elower": vals[order, 2],
+                    "gamma_air": vals[order, 3], "gamma_self": vals[order, 4], "delta_air": vals[order, 5],
+                    "n_air": vals[order, 6]}
+            m = _Master({f: np.ascontiguousarray(v) for f, v in _dedupe_last_wins(full).items()})
+            self._masters[global_iso] = m
+            _MASTERS[id(m["nu"])] = m
+        nu = m["nu"]
+        first = int(np.searchsorted(nu, range_min, "right"))
+        end = max(int(np.searchsorted(nu, range_max, "left")), first)
+        return {f: v[first:end] for f, v in m.items()}
 
     # -- writer, so tests and users can materialise a tree in PyRad's format ----------------
     @staticmethod
@@ -290,8 +353,11 @@ def returnXscFileContents(filepath):
 class XscDir:
     """PyRad's measured cross-section cache ``<root>/<molecule>/<file>.txt`` (``data/xsc``, ut:19)."""
 
-    def __init__(self, root: str):
+    def __init__(self, root: str, cache: bool = True):
         self.root = root
+        self.cache = cache               # keep parsed segments (False: read and parse on every call, as the reference does)
+        self._segments = {}              # (global_iso, segment) -> parsed file
+        self._masters = {}               # global_iso -> the sorted, duplicate-free list of its kept segments
 
     parseXscFileName = staticmethod(parseXscFileName)
 

@@ -135,3 +135,56 @@ def test_oracle_line_survey_matches_g10():
     # range fills bins 0..199 and lines from the +50 cm^-1 window margin land in bins 200..699 of the 2000
     s3 = z["S3.layer"]
     assert s3.size == 2000 and np.count_nonzero(s3[200:700]) > 0 and np.count_nonzero(s3[700:]) == 0
+
+
+def test_cached_reader_equals_the_uncached_one(tree, tmp_path, monkeypatch):
+    """PyradDataDir keeps parsed segments (round 4: re-windowing re-asks for the same files) and hands out slices of one
+    sorted, duplicate-free list per isotopologue while its segments are well formed; with cache=False it reads and
+    parses row by row on every call, like the reference.  Same results on the G9 tree (which holds a row filed in the
+    wrong segment: that isotopologue stays on the row-by-row path) and on a well-formed tree; files are read once and
+    re-read when they change."""
+    z, cached = tree
+    plain = data.PyradDataDir(cached.root, cache=False)
+    for qi, (iso, lo, hi) in enumerate(json.loads(str(z["queries_json"]))):
+        if "q%d.raises" % qi in z.files:
+            continue
+        a, b = cached.gatherData(iso, lo, hi), plain.gatherData(iso, lo, hi)
+        assert set(a) == set(b) and all(np.array_equal(a[k], b[k]) for k in a), qi
+    # a well-formed tree: duplicates within a file and across windows, unsorted rows
+    root = str(tmp_path / "clean")
+    lines = synthetic.make_lines(11, 3000, 480.0, 920.0, decimals=2)          # two decimals: duplicated wavenumbers
+    rng = np.random.default_rng(3)
+    shuffled = {k: v[rng.permutation(len(lines["nu"]))] for k, v in lines.items()}
+    shuffled["a"] = np.zeros_like(shuffled["nu"])
+    data.PyradDataDir.write_tree(root, 7, shuffled, {296: 286.0}, synthetic.mol_params("co2"))
+    cached, plain = data.PyradDataDir(root), data.PyradDataDir(root, cache=False)
+    reads = []
+    real_rows = data.PyradDataDir._rows
+    monkeypatch.setattr(data.PyradDataDir, "_rows", staticmethod(lambda path: (reads.append(path), real_rows(path))[1]))
+    for lo, hi in ((595.0, 705.0), (600.0, 700.0), (612.34, 612.36), (520.0, 880.0), (595.0, 705.0), (640.0, 641.0)):
+        a, b = cached.gatherData(7, lo, hi), plain.gatherData(7, lo, hi)
+        assert set(a) == set(b) and all(np.array_equal(a[k], b[k]) for k in a), (lo, hi)
+        hit = data.master_slice(a, ("nu", "sw", "elower", "gamma_air", "gamma_self", "n_air", "delta_air"))
+        assert a["nu"].size == 0 or (hit is not None and hit[2] == a["nu"].size)            # a slice of the isotopologue's list
+    assert len(set(reads)) == 4                                                          # segments 500 .. 800
+    assert len(reads) == 4 + sum(len(data.PyradDataDir.segments(lo, hi)) for lo, hi in
+                                            ((595.0, 705.0), (600.0, 700.0), (612.34, 612.36), (520.0, 880.0), (595.0, 705.0), (640.0, 641.0)))
+    # a file that changes on disk is read again
+    path = os.path.join(root, "7", "600.pyr")
+    rows = open(path).read().splitlines()
+    extra = rows[0].split(","); extra[2] = "650.555555"; extra[3] = "1.25e-19"
+    with open(path, "w") as f:
+        f.write("\n".join(rows + [",".join(extra)]) + "\n")
+    os.utime(path, ns=(os.stat(path).st_atime_ns, os.stat(path).st_mtime_ns + 10_000_000))
+    a, b = cached.gatherData(7, 640.0, 660.0), plain.gatherData(7, 640.0, 660.0)
+    assert 650.555555 in a["nu"] and all(np.array_equal(a[k], b[k]) for k in a)
+    # an unparsable column only matters for the rows a window reads (ut:434-446), cached or not
+    rows = open(path).read().splitlines()
+    bad = rows[1].split(","); bad[2] = "699.987654"; bad[5] = "not-a-number"
+    with open(path, "w") as f:
+        f.write("\n".join(rows + [",".join(bad)]) + "\n")
+    os.utime(path, ns=(os.stat(path).st_atime_ns, os.stat(path).st_mtime_ns + 20_000_000))
+    for src in (cached, plain):
+        assert 699.987654 not in src.gatherData(7, 640.0, 660.0)["nu"]
+        with pytest.raises(ValueError):
+            src.gatherData(7, 690.0, 700.0)
