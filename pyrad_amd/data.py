@@ -86,7 +86,7 @@ def master_slice(lines: dict, fields):
     n = nu.size
     for f in fields:
         a, m = lines.get(f), master.get(f)
-        if a is None or m is None or a.base is not m or a.size != n or a.dtype != np.float64:
+        if a is None or m is None or a.base is not m or a.size != n or a.dtype != np.float64 or not a.flags.c_contiguous:
             return None
         if (a.__array_interface__["data"][0] - m.__array_interface__["data"][0]) // 8 != first:
             return None

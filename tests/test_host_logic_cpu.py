@@ -182,3 +182,9 @@ def test_memory_source_windows_are_slices_with_the_reference_semantics():
     assert data.master_slice({k: v.copy() for k, v in sel.items()}, ("nu", "sw")) is None
     assert data.master_slice(dict(sel, sw=sel["sw"][::-1].copy()), ("nu", "sw")) is None
     assert data.master_slice(dict(sel, sw=src.gatherData(7, 620.0, 690.0)["sw"]), ("nu", "sw")) is None
+    full = src.gatherData(7, 0.0, 1e9)
+    n = sel["nu"].size
+    first = int(np.searchsorted(full["nu"], sel["nu"][0]))
+    strided = full["sw"].base[first:first + 2 * n:2] if full["sw"].base is not None else None      # same start, same length, every other element
+    if strided is not None and strided.size == n:
+        assert data.master_slice(dict(sel, sw=strided), ("nu", "sw")) is None
