@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LBL_ABI_VERSION 2
+#define LBL_ABI_VERSION 3
 
 typedef enum lbl_status {
     LBL_OK = 0,
