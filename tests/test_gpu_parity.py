@@ -966,3 +966,51 @@ def test_stress_cells_skewed_walk(ctx, orc, mode, seed):
     e = rel_err_points(xs, ref, floor)
     assert tuple(counts) == tuple(rc)
     assert np.all(e <= tol), (float(e.max()), float((e / tol).max()), g["W"], n_lines)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_cells_budget_mode(ctx, orc, seed):
+    """The budget accuracy mode (lbl_set_option "accuracy" 1: 18..7 far-field series terms by distance, Gaussian parts of
+    pseudo-Voigt lines dropped below 2^-34 of the line's own Lorentz part) on random gas cells - every regime, windows
+    from 1 point to thousands, regrid on and off, ranges that start at 0 cm^-1: every point within its stated bound, 1e-9
+    relative (plus the nu -> 0 amplification of the stimulated-emission factor, as in exact mode), through the default
+    kernels and through the skewed-range kernel; exact zeros stay exact zeros."""
+    from conftest import point_tolerance, rel_err_points
+    rng = np.random.default_rng(1000 + seed)                 # the cells of test_random_cells_against_oracle
+    cell = random_cell(rng, seed, orc, max_evals=4e6)
+    if cell is None:
+        pytest.skip("degenerate grid (the reference raises)")
+    lines, species, conc, T, P, rmin, rmax, base, dyn, g = cell
+    sp = synthetic.SPECIES[species]
+    ref, rc = orc.create_cross_section(orc.select_window(lines, g["eff_min"], g["eff_max"]), T, P, conc, sp["molmass"],
+                                       synthetic.q_value(species, T), sp["q296"], g)
+    tol = point_tolerance(orc.x_axis(rmin, rmax, base), T, g["dfc"], rtol_base=1e-9)
+    floor = float(np.max(np.abs(ref))) * FLOOR_REL if ref.size else 0.0
+    ctx.set_option("accuracy", 1)
+    try:
+        for skew in (1, 2):
+            ctx.set_option("accum_skew", skew)
+            xs, counts, _, _, _ = device_xsec(ctx, lines, species, conc, T, P, rmin, rmax, base, dyn)
+            assert tuple(counts) == tuple(rc)
+            e = rel_err_points(xs, ref, floor)
+            assert np.all(e <= tol), (skew, float(e.max()), int(np.argmax(e / tol)), g["W"])
+    finally:
+        ctx.set_option("accuracy", 0)
+        ctx.set_option("accum_skew", 1)
+
+
+@pytest.mark.parametrize("T", [296, 250])
+def test_g1_cell_budget_mode_against_the_reference(ctx, T):
+    """G1 (the reference's own C1 cell at two temperatures): the cross section in budget mode against what pyradClasses
+    computed, 1e-9 (exact mode: 1e-11, test_g1_cell_all_variants)."""
+    from pyrad_amd import _native as nat, engine
+    z = load_golden("G1_c1_cell")
+    lines = unpack_lines(z, "lines")
+    ctx.set_option("accuracy", 1)
+    try:
+        for variant in (5, 3):
+            xs, counts, g, sel, iso = device_xsec(ctx, lines, "co2", 400 * 10**-6, T, 1013.25, 600, 700, .01, True, variant)
+            check(xs, z["T%d.xsec" % T], tol=1e-9)
+            assert sum(counts) == 2000 and counts[0] == 0
+    finally:
+        ctx.set_option("accuracy", 0)
