@@ -1071,7 +1071,7 @@ def main():
                                      "buffer), overlapped with the steps that fill the set's other batch buffer" % n_batch)},
             "pairs": dict(layer.pairs, **{
                 "what": "how the default kernel treats the step's (line, span of 256 grid points) pairs: pairs_series go through "
-                        "the 30-term far-field series about the span centre (fp64-exact: remainder below half an ulp), pairs_direct "
+                        "the far-field series about the span centre (30 terms at 4 half-spans, 20 / 15 / 12 from 8 / 16 / 32 on: the remainder stays below half an ulp; budget mode 18 / 12 / 9 / 7), pairs_direct "
                         "are evaluated point by point; evals_series = 256 per far pair, evals_direct the rest of evals_per_step. "
                         "`value` counts every contribution the reference's loop adds (both kinds); value_direct_kernel is the "
                         "same workload through the all-direct kernel (accum_variant 3), every pair evaluated point by point"}),
