@@ -583,6 +583,12 @@ def main():
                     help="experiment on ONE GPU: run only shard r of a G-way sharding of the workload (no communicator): "
                          "what rank r of G would compute per step")
     ap.add_argument("--unfused", action="store_true", help="accumulate launch + separate sweep launch (A/B)")
+    ap.add_argument("--step", default="merged", choices=["merged", "per-list"],
+                    help="merged (default): ONE accumulate job per layer over its merged, factor-weighted line lists, the layer's "
+                         "absorption coefficient accumulated directly with the sweep in the kernel's output stage "
+                         "(lbl_layer_merged_step_dev / lbl_layers_merged_accumulate_dev + lbl_column_fold_dev); per-list: one job and "
+                         "one cross-section array per line list, then the sweep over them (lbl_layer_step_dev / lbl_column_step_dev). "
+                         "Every (line, grid point) contribution is evaluated either way")
     ap.add_argument("--graph", action="store_true",
                     help="replay the captured hipGraph of the step instead of enqueueing kernel by kernel (measured slower on "
                          "ROCm 7.2: C1 0.021 vs 0.017 ms, C2 0.077 vs 0.074, a shard of 8 of C3 0.074 vs 0.071)")
@@ -715,8 +721,9 @@ def main():
     # setup also builds the host-side schedule of every resident set (dispatch order + per-span line
     # ranges, cached by the library per line lists and grid): one priming pass each, outside the
     # timed region whatever --warmup is
-    step_kwargs = (dict(layer_arrays=bool(args.column_layer_arrays)) if args.workload == "C5"
-                   else dict(surface_T=288.0, fused=not args.unfused))
+    merged = args.step == "merged" and not args.unfused and args.variant in (None, 3, 5)
+    step_kwargs = (dict(layer_arrays=bool(args.column_layer_arrays), merged=merged) if args.workload == "C5"
+                   else dict(surface_T=288.0, fused=not args.unfused, merged=merged))
 
     def prime(L):
         L.enqueue(**step_kwargs)
@@ -1028,6 +1035,8 @@ def main():
         t_acc_step = (ms_acc / max(n_sampled, 1)) * 1e-3        # all K2 launches of one (sampled) step
         launches_per_step = max(n_acc // max(n_sampled, 1), 1)   # a column launches K2 once per window group
         n_xsec_written = (n_arrays * len(layer.layers)) if is_column else n_arrays
+        if merged:          # no per-line-list cross sections: a column writes one absorption coefficient per layer, a cell none beside the sweep's
+            n_xsec_written = len(layer.layers) if is_column else 0
         balg_acc = (56.0 * layer.n_lines + 8.0 * pts * n_xsec_written + (24.0 * pts if fused_sweep else 0.0)) / launches_per_step
         achieved = balg_acc / t_acc / 1e9 if t_acc > 0 else 0.0
         # per sweep launch: M xsec reads + k, T (, I_out) writes; I_in is computed in-kernel

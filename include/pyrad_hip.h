@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LBL_ABI_VERSION 3
+#define LBL_ABI_VERSION 4
 
 typedef enum lbl_status {
     LBL_OK = 0,
@@ -277,6 +277,47 @@ int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lines, const l
                        const lbl_grid* grid, lbl_buffer* const* xsec, const int32_t* iso_mol, int n_mol,
                        const double* conc, double depth, lbl_buffer* I_in, double surface_T,
                        lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out);
+
+/* ---- the layer's absorption coefficient accumulated directly (ABI 4) -----------------------------------------
+ * Layer.absCoef is sum over molecules m of (sum over isotopologues of crossSection) * conc_m * P / 1E4 / k / T
+ * (pyradClasses.py:707-712, 581-583, 566-571), and the reference computes its parts lazily (progressCrossSection,
+ * pyradClasses.py:32-88).  These entry points run ONE accumulate job per LAYER: the line preparation multiplies every
+ * line's amplitude by its molecule's factor f_m = conc_m P / 1E4 / k / T (host, the reference's order of operations) and
+ * writes the records of all the layer's line lists into one array in centre-index order (the merged order is built on
+ * the device once per (line lists, grid), beside the dispatch schedule); the accumulate kernel then sums every
+ * (line, grid point) contribution of the layer into the absorption coefficient itself - one pass over the grid instead
+ * of one per line list, no per-line-list cross-section arrays written and read back.  Every contribution the
+ * reference's loop adds (pyradClasses.py:392-400) is still evaluated.  A per-isotopologue cross section
+ * (Isotope.crossSection) is produced on demand by lbl_xsec_accumulate_dev, as before.
+ * Arithmetic: fp64; differs from the per-line-list path by the order of summation and one rounding per line (the
+ * factor rides on the amplitude instead of on the sum): a few 1e-16 relative; the sweeps' default arithmetic
+ * ("sweep_ieee_divisions" 0) for transmittance and Planck radiance whatever that option says.  "accuracy" applies as
+ * usual.  Needs "accum_variant" 3 or 5 and the device schedule build (LBL_ERR_BAD_ARG otherwise: use the per-list step).
+ *
+ * lbl_layer_merged_step_dev: one layer (gas cell) - line prep, ONE accumulate job over the merged lists, and in its
+ * output stage k, transmittance exp(-k depth) and outgoing radiance trans * I_in + (1 - trans) * B(nu, T)
+ * (pyradClasses.py:714-716, 784-787; pyradPlanck.py:38-44).  Arguments as lbl_layer_step_dev without the xsec buffers;
+ * any of abs_coef / trans / I_out may be NULL (not all).  A work grid coarser than the base grid (dynamic resolution)
+ * is regridded (np.interp of pyradClasses.py:401-405 applied to k) and swept by the sweep kernel. */
+int lbl_layer_merged_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lines, const lbl_iso_params* iso,
+                              const lbl_grid* grid, const int32_t* iso_mol, int n_mol, const double* conc,
+                              double depth, lbl_buffer* I_in, double surface_T,
+                              lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out);
+/* The same for a batch of layers (a column: every layer's merged job in ONE launch sequence, so that layers fill the
+ * chip together): layer l owns n_iso[l] consecutive entries of lines / iso / iso_mol (molecule index 0-based inside the
+ * layer, non-decreasing), n_mol[l] consecutive entries of conc, its own grid[l], and receives its absorption
+ * coefficient in abs_coef[l] (n_base doubles). */
+int lbl_layers_merged_accumulate_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_iso, lbl_lines* const* lines,
+                                     const lbl_iso_params* iso, const lbl_grid* grid, const int32_t* iso_mol,
+                                     const int32_t* n_mol, const double* conc, lbl_buffer* const* abs_coef);
+/* Column step from the layers' absorption coefficients (bottom to top): per grid point and layer
+ * trans = exp(-k depth), I <- trans * I + (1 - trans) * B(nu_j, T_l), I_0 = I_in or B(nu_j, surface_T)
+ * (pyradClasses.py:714-716, 784-787) in one pass over the n_layers arrays.  trans: NULL, or n_layers buffers of which
+ * any may be NULL (that layer's transmittance is then not written). */
+int lbl_column_fold_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const* abs_coef, const double* T,
+                        const double* depth, double range_min, double range_max, int64_t n,
+                        int64_t first, int64_t count, lbl_buffer* I_in, double surface_T,
+                        lbl_buffer* const* trans, lbl_buffer* I_out);
 
 /* Column fold of Layer.transmission over layers bottom to top (pyradClasses.py:784-787):
  *   I <- trans_l * I + (1 - trans_l) * B(nu_j, layer_T[l]),  I_0 = I_in or B(nu_j, surface_T). */

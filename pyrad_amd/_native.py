@@ -90,6 +90,13 @@ SIGNATURES = {
                                       C.c_int64, C.c_int64, _P, C.c_double, _P, _P, _P]),
     "lbl_layer_step_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(IsoParams), C.POINTER(Grid), C.POINTER(_P),
                                      C.POINTER(C.c_int32), C.c_int, _D, C.c_double, _P, C.c_double, _P, _P, _P]),
+    "lbl_layer_merged_step_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(IsoParams), C.POINTER(Grid),
+                                            C.POINTER(C.c_int32), C.c_int, _D, C.c_double, _P, C.c_double, _P, _P, _P]),
+    "lbl_layers_merged_accumulate_dev": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.POINTER(_P), C.POINTER(IsoParams),
+                                                   C.POINTER(Grid), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _D,
+                                                   C.POINTER(_P)]),
+    "lbl_column_fold_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), _D, _D, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                                      C.c_int64, _P, C.c_double, C.POINTER(_P), _P]),
     "lbl_column_sweep_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), _D, C.c_double, C.c_double, C.c_int64,
                                        C.c_int64, C.c_int64, _P, C.c_double, _P]),
     "lbl_column_step_dev": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.POINTER(_P), C.POINTER(C.c_int32),
@@ -406,6 +413,53 @@ class Context:
         h = lambda b: b.h if b is not None else None
         self.check(self.lib.lbl_layer_step_dev(self.h, n, L, I, C.byref(grid), X, M, len(conc), cc, float(depth), h(I_in),
                                                float(surface_T), h(abs_coef), h(trans), h(I_out)))
+
+    def layer_merged_step_dev(self, lines, iso, grid: Grid, iso_mol, conc, depth, I_in=None, surface_T=0.0,
+                              abs_coef=None, trans=None, I_out=None):
+        """One layer through ONE accumulate job over its merged, factor-weighted line lists with the sweep in the
+        output stage (lbl_layer_merged_step_dev): the absorption coefficient is accumulated directly, no
+        per-line-list cross section is written.  Arguments as layer_step_dev without ``xsec``."""
+        if isinstance(lines, Lines):
+            lines, iso = [lines], [iso]
+        if np.isscalar(conc):
+            conc = [conc]
+        if iso_mol is None:
+            iso_mol = list(range(len(lines)))
+        n = len(lines)
+        L = (_P * n)(*[l.h for l in lines])
+        I = (IsoParams * n)(*iso)
+        M = (C.c_int32 * n)(*[int(m) for m in iso_mol])
+        cc = (C.c_double * max(len(conc), 1))(*[float(c) for c in conc])
+        h = lambda b: b.h if b is not None else None
+        self.check(self.lib.lbl_layer_merged_step_dev(self.h, n, L, I, C.byref(grid), M, len(conc), cc, float(depth),
+                                                      h(I_in), float(surface_T), h(abs_coef), h(trans), h(I_out)))
+
+    def layers_merged_accumulate_dev(self, layers):
+        """layers: list of dict(lines=[Lines], iso=[IsoParams], grid=Grid, iso_mol=[int], conc=[float], abs_coef=Buffer):
+        every layer's absorption coefficient through one merged accumulate job per layer, all in one launch sequence
+        (lbl_layers_merged_accumulate_dev)."""
+        nl = len(layers)
+        if nl == 0:
+            return
+        arr = lambda typ, vals: (typ * max(len(vals), 1))(*vals)
+        ls = [l for L in layers for l in L["lines"]]
+        self.check(self.lib.lbl_layers_merged_accumulate_dev(
+            self.h, nl, arr(C.c_int32, [len(L["lines"]) for L in layers]), arr(_P, [l.h for l in ls]),
+            arr(IsoParams, [i for L in layers for i in L["iso"]]), arr(Grid, [L["grid"] for L in layers]),
+            arr(C.c_int32, [int(m) for L in layers for m in L["iso_mol"]]), arr(C.c_int32, [len(L["conc"]) for L in layers]),
+            arr(C.c_double, [float(c) for L in layers for c in L["conc"]]), arr(_P, [L["abs_coef"].h for L in layers])))
+
+    def column_fold_dev(self, abs_coef, layer_T, depth, range_min, range_max, n, I_out, I_in=None, surface_T=0.0,
+                        trans=None, first=0, count=0):
+        """Column step from the layers' absorption coefficients, bottom to top (lbl_column_fold_dev); ``trans``: None or
+        a list (entries may be None) of buffers that receive the layers' transmittances."""
+        nl = len(abs_coef)
+        arr = lambda typ, vals: (typ * max(len(vals), 1))(*vals)
+        hb = lambda b: b.h if b is not None else None
+        self.check(self.lib.lbl_column_fold_dev(
+            self.h, nl, arr(_P, [b.h for b in abs_coef]), arr(C.c_double, [float(t) for t in layer_T]),
+            arr(C.c_double, [float(d) for d in depth]), float(range_min), float(range_max), int(n), int(first), int(count),
+            hb(I_in), float(surface_T), arr(_P, [hb(b) for b in trans]) if trans is not None else None, I_out.h))
 
     def gather_compact_dev(self, gathered, slot, bounds, out):
         """padded all-gather result (slot r = rank r's shard) -> grid order (lbl_gather_compact_dev)."""

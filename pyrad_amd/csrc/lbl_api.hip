@@ -82,6 +82,11 @@ struct lbl_ctx {
         long long far_reach = 0;
         double cost_near = 0, cost_edge = 0, cost_far = 0, cost_fixed = 0;
         std::vector<int32_t> span_first, tile_first;
+        // merged layer jobs (several line lists in one record array): the merged position of every line, built on the
+        // device by the first batch that uses the schedule (launch_merge_ranks), ahead of its line prep
+        int32_t* d_dest = nullptr;
+        std::vector<size_t> dest_off;         // per job of the group: first entry of its lists' positions in d_dest (SIZE_MAX: one list, no merge)
+        bool merge_pending = false;
     };
     std::vector<std::unique_ptr<Schedule>> schedules;
     int accuracy = 0;        // 0 exact (default): every result as close to the reference's fp64 as the arithmetic allows (1e-14);
@@ -94,6 +99,9 @@ struct lbl_ctx {
                              // (k bit-identical to NumPy's crossSection * concentration * P / 1E4 / k / T on the same cross section)
     int sched_build = 1;     // 1 (default): span tables and dispatch order built on the device, in stream; 0: on the host
     DeviceArena sched;       // scratch of the device build
+    DeviceArena ktmp;        // lbl_layer_merged_step_dev on a work grid that needs the regrid kernel, without an abs_coef buffer: the regridded k
+    DeviceArena merge_tmp;   // merged layer jobs: per-list centre indices + list descriptors while the merged positions are built
+    bool sched_refused = false;   // group_schedule: a merged layer job on a launch the device build does not cover
     uint64_t lines_serial = 0;
     int lpt = 4;             // longest-first worklist: 4 (default) = 3 + XCD-partitioned when the launch has several rounds; 3 bin-packed per CU when the launch is one round; 2 snake; 1 plain; 0 positional
     int tile_order = 1;      // 1: natural order (default; measured 8 % faster on the clustered C2 grid:
@@ -368,7 +376,7 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) try {
     for (auto& sc : ctx->schedules) if (sc->d_block) (void)hipFree(sc->d_block);
     for (auto& e : ctx->desc_cache) if (e.dptr) (void)hipFree(e.dptr);
     for (auto& e : ctx->arg_cache) if (e.dptr) (void)hipFree(e.dptr);
-    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->bal, &ctx->red, &ctx->zeros, &ctx->sched};
+    DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->bal, &ctx->red, &ctx->zeros, &ctx->sched, &ctx->merge_tmp, &ctx->ktmp};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     (void)hipStreamDestroy(ctx->stream);
@@ -462,8 +470,28 @@ void comm_prof_end(lbl_ctx* ctx, void* start) { prof_end(ctx, PROF_GATHER, (hipE
 
 // Tuning knobs for benchmarking and A/B parity runs (not part of the reference surface):
 //   "accum_variant" 0 | 1 | 2,  "accum_points_per_lane" 0 (auto) | 1 | 2 | 4 | 8
+// Every option decides which kernels, launch shapes or arithmetic the batches enqueued afterwards use; a graph captured
+// before (lbl_capture_end) would go on replaying the old ones.  A change of any option therefore bumps the context's epoch:
+// lbl_graph_launch reports the graph stale (LBL_ERR_STATE) and the caller captures again (engine.StepGraph does by itself).
+static uint64_t option_state(const lbl_ctx* c) {
+    const long long v[] = {c->accum_variant, c->accum_R, c->accum_LS, c->lpt, c->tile_order, c->skew, c->skew_R, c->far_min_H,
+                           c->ablate, c->accuracy, c->sweep_ieee, c->sched_build, c->no_fuse ? 1 : 0,
+                           c->bal_workers[1], c->bal_workers[2], c->bal_workers[4], c->bal_workers[8]};
+    uint64_t h = 1469598103934665603ull;
+    for (long long x : v) { h ^= (uint64_t)x; h *= 1099511628211ull; }
+    return h;
+}
+static int set_option_value(lbl_ctx* ctx, const char* key, int value);
+
 extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) try {
     if (!ctx || !key) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    const uint64_t before = option_state(ctx);
+    const int rc = set_option_value(ctx, key, value);
+    if (option_state(ctx) != before) ctx->epoch++;
+    return rc;
+} LBL_GUARD_END(ctx)
+
+static int set_option_value(lbl_ctx* ctx, const char* key, int value) {
     if (!strcmp(key, "accum_variant")) {
         if (value < 0 || value > 5) return fail(ctx, LBL_ERR_BAD_ARG, "accum_variant must be 0..5");
         ctx->accum_variant = value;
@@ -519,7 +547,7 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) try {
         return fail(ctx, LBL_ERR_BAD_ARG, "unknown option '%s'", key);
     }
     return LBL_OK;
-} LBL_GUARD_END(ctx)
+}
 
 // ----------------------------------------------------------------------------------------
 // buffers
@@ -726,19 +754,36 @@ static void choose_shape(const lbl_ctx* ctx, int variant, long long total_points
         // far-field kernel: R = 4 and as little line split as the line count asks for, unless the grid
         // is too small to give every SIMD two wavefronts: then split more, then shrink the spans
         // (C1, 10^4 points: R = 1 with 8 waves per span is 4x faster than R = 4 unsplit)
+        // Round 5 (merged layer jobs carry three times the lines per span): the split is the one a small model of the kernel
+        // prefers - a span costs W = 600 + lps (1.5 + 1.5 r) wave-instructions (PMC: 5,000 per span and line list of the
+        // 100-2500 cm^-1 cell, 13,800 per span of its merged job), every further wave sharing it repeats ~600 of them
+        // (series reduction, polynomial, start-up, output), and a SIMD holding w < 4 waves runs at 0.51 / 0.82 / 0.96 of its
+        // 4-wave rate (measured occupancy curve).  It reproduces the measured choices: the whole cell unsplit
+        // (per-list and merged; the old line-count rule split the merged job in two: 0.288 vs 0.263 ms), the 500-900 cm^-1
+        // cell in two, a merged shard of 8 in four (0.060 vs 0.072 in two, 0.112 unsplit).
         const long long want_waves = 8 * cus;
+        auto simd_rate = [](double w) {
+            static const double pt[5] = {0.0, 0.507, 0.818, 0.958, 1.0};
+            if (w >= 4.0) return 1.0;
+            const int i = (int)w;
+            return pt[i] + (pt[i + 1] - pt[i]) * (w - i);
+        };
         int best_R = 1, best_LS = 1;
         bool found = false;
         for (int r = 4; r >= 1 && !found; r >>= 1) {
             if (r > 1 && 64LL * r > 2 * min_H + 1) continue;
             const long long spans = std::max<long long>((total_points + 64LL * r - 1) / (64LL * r), 1);
             const double lps = lines_per_span(r);
-            int by_lines = lps >= 4096.0 ? 4 : lps >= 1024.0 ? 2 : 1;
-            int by_fill = 1;
-            while (by_fill < 8 && spans * by_fill < want_waves) by_fill <<= 1;
             int cap = 1;                                   // at least one 64-line chunk per wave of a span
             while (cap < 8 && lps >= 128.0 * cap) cap <<= 1;
-            best_R = r; best_LS = std::max(by_lines, std::min(by_fill, cap));
+            const double W = 600.0 + lps * (1.5 + 1.5 * r);
+            double best_cost = 0.0;
+            int ls_pick = 1;
+            for (int ls = 1; ls <= cap; ls <<= 1) {
+                const double cost = (double)spans * (W + (ls - 1) * 600.0) / std::max(simd_rate((double)spans * ls / (4.0 * cus)), 1e-3);
+                if (ls == 1 || cost < 0.97 * best_cost) { best_cost = cost; ls_pick = ls; }
+            }
+            best_R = r; best_LS = ls_pick;
             found = spans * best_LS >= want_waves || r == 1;
         }
         *R_out = best_R; *LS_out = best_LS;
@@ -785,20 +830,30 @@ static void choose_shape(const lbl_ctx* ctx, int variant, long long total_points
 #ifndef LBL_COST_GAUSS
 #define LBL_COST_GAUSS 15.0      // wave-instructions a near line's Gaussian passes add per span (0.6 passes of ~25; 29 before the 16-point runs)
 #endif
+// list_first (merged layer jobs, else NULL): job j accumulates the line lists [list_first[j], list_first[j + 1]) of `lines`
+// as ONE record array; without it job j is line list j.
 static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::vector<int>& jobs_in_group,
-                                         lbl_lines* const* lines, const lbl_grid* grid, int R, int LS, long long tile_pts) {
+                                         lbl_lines* const* lines, const lbl_grid* grid, int R, int LS, long long tile_pts,
+                                         const int* list_first = nullptr) {
     std::vector<uint64_t> key;
     const bool far_field = variant == 5;
     int far_half_spans = 0;
     double far_cost = 1.0;
     if (far_field) accumulate_far_field_params(R, &far_half_spans, &far_cost, ctx->accuracy);      // (the span tables hold the far bounds)
-    key.push_back((uint64_t)R << 32 | (uint64_t)far_half_spans << 16 | (uint64_t)LS << 8 | (uint64_t)ctx->sched_build << 4 | (uint64_t)ctx->lpt << 1 | (uint64_t)far_field);
+    auto l0 = [&](int j) { return list_first ? list_first[j] : j; };
+    auto l1 = [&](int j) { return list_first ? list_first[j + 1] : j + 1; };
+    bool merged = false;                       // any job of the group with several line lists
+    for (int j : jobs_in_group) merged = merged || l1(j) - l0(j) > 1;
+    // (a merged group's tables and merged positions only come from the device build, whatever the options say)
+    const int build_bits = merged ? 1 : ctx->sched_build, lpt_bits = merged ? 4 : ctx->lpt;
+    key.push_back((uint64_t)R << 32 | (uint64_t)far_half_spans << 16 | (uint64_t)LS << 8 | (uint64_t)build_bits << 4 | (uint64_t)lpt_bits << 1 | (uint64_t)far_field);
     for (int j : jobs_in_group) {
         long long sf, sc;
         shard_range(grid[j], &sf, &sc);
         uint64_t bits_a, bits_b;
         memcpy(&bits_a, &grid[j].range_min, 8); memcpy(&bits_b, &grid[j].resolution, 8);
-        key.push_back(lines[j]->serial); key.push_back((uint64_t)lines[j]->n);
+        if (list_first) key.push_back(0xFFFFFFFF00000000ull | (uint64_t)(l1(j) - l0(j)));      // (a job of k lists is not k jobs)
+        for (int l = l0(j); l < l1(j); ++l) { key.push_back(lines[l]->serial); key.push_back((uint64_t)lines[l]->n); }
         key.push_back(bits_a); key.push_back(bits_b);
         key.push_back((uint64_t)sf); key.push_back((uint64_t)sc); key.push_back((uint64_t)grid[j].window);
     }
@@ -818,12 +873,15 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
             ctx->schedules.erase(ctx->schedules.begin());
         }
     };
-    auto one_block = [&](size_t n_items, size_t n_tab_ints, int2** d_list, int32_t** d_tabs) -> void* {
+    auto one_block = [&](size_t n_items, size_t n_tab_ints, int2** d_list, int32_t** d_tabs, size_t n_dest = 0,
+                         int32_t** d_dest = nullptr) -> void* {
         const size_t list_bytes = (std::max<size_t>(n_items, 1) * sizeof(int2) + 255) & ~(size_t)255;
+        const size_t tab_bytes = (std::max<size_t>(n_tab_ints, 8) * sizeof(int32_t) + 255) & ~(size_t)255;
         void* blk = nullptr;
-        if (hipMalloc(&blk, list_bytes + std::max<size_t>(n_tab_ints, 8) * sizeof(int32_t)) != hipSuccess) return nullptr;
+        if (hipMalloc(&blk, list_bytes + tab_bytes + n_dest * sizeof(int32_t)) != hipSuccess) return nullptr;
         *d_list = (int2*)blk;
         *d_tabs = (int32_t*)((char*)blk + list_bytes);
+        if (d_dest) *d_dest = n_dest ? (int32_t*)((char*)blk + list_bytes + tab_bytes) : nullptr;
         return blk;
     };
     {
@@ -837,8 +895,9 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
             n_spans_all += (sc + 64LL * R - 1) / (64LL * R);
         }
         const int n_cu_i = ctx->n_cu > 0 ? ctx->n_cu : 256;
-        if (ctx->sched_build == 1 && ctx->lpt == 4 && n_items > 0 && n_spans_all < (1LL << 27) &&
-            sched_device_supported((int)n_items, n_cu_i)) {
+        const bool device_ok = n_items > 0 && n_spans_all < (1LL << 27) && sched_device_supported((int)n_items, n_cu_i);
+        if (merged && !device_ok) { ctx->sched_refused = true; return nullptr; }
+        if (build_bits == 1 && lpt_bits == 4 && device_ok) {
             std::unique_ptr<lbl_ctx::Schedule> S(new lbl_ctx::Schedule());
             S->key = key;
             S->R = R; S->spans_per_tile = (int)(tile_pts / (64LL * R));
@@ -854,9 +913,17 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
                 tile_run += (int32_t)((sc + tile_pts - 1) / tile_pts);
             }
             S->total_spans = span_run; S->total = tile_run;
-            S->d_block = one_block((size_t)tile_run, (size_t)span_run * 8, &S->d_list, &S->d_tabs);
+            size_t n_dest = 0;
+            for (int j : jobs_in_group) {
+                size_t n = 0;
+                for (int l = l0(j); l < l1(j); ++l) n += (size_t)lines[l]->n;
+                S->dest_off.push_back(l1(j) - l0(j) > 1 ? n_dest : SIZE_MAX);
+                if (l1(j) - l0(j) > 1) n_dest += n;
+            }
+            S->d_block = one_block((size_t)tile_run, (size_t)span_run * 8, &S->d_list, &S->d_tabs, n_dest, &S->d_dest);
             if (!S->d_block) return nullptr;
             S->pending = true;
+            S->merge_pending = n_dest > 0;
             evict_oldest();
             ctx->schedules.push_back(std::move(S));
             return ctx->schedules.back().get();
@@ -871,7 +938,7 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
     const long long reach = (long long)far_half_spans * 32 * R;
     for (size_t k = 0; k < jobs_in_group.size(); ++k) {
         const int j = jobs_in_group[k];
-        const lbl_lines* L = lines[j];
+        const lbl_lines* L = lines[l0(j)];           // (one list per job on this path: merged groups took the device build)
         idx.resize((size_t)L->n);
         for (int64_t i = 0; i < L->n; ++i) idx[i] = (long long)((L->host_nu[i] - grid[j].range_min) / grid[j].resolution);
         long long sf, sc;
@@ -1010,29 +1077,48 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
     return ctx->schedules.back().get();
 }
 
+// Merged layer jobs (lbl_layer_merged_step_dev, lbl_layers_merged_accumulate_dev): accumulate job j takes the line lists
+// [first[j], first[j + 1]) of `lines` / `iso` as ONE record array in centre-index order; list l's amplitudes carry weight[l]
+// and job j's sums leave the kernel multiplied by out_scale[j] (see PrepJob.weight, AccumJob.out_scale).
+struct MergeSpec {
+    const int* first;          // n_jobs + 1 offsets into lines / iso
+    const double* weight;      // per line list
+    const double* out_scale;   // per job
+};
+
 static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines, const lbl_iso_params* iso,
                               const lbl_grid* grid, double* const* out_dev, bool prep_only,
-                              const FusedSweep* fuse = nullptr, double fuse_conc = 0.0) {
+                              const FusedSweep* fuse = nullptr, double fuse_conc = 0.0, const MergeSpec* merge = nullptr) {
     // fuse != NULL (n_jobs == 1): the layer sweep runs in the output stage of the one job
+    // merge == NULL: job j is line list j; lines / iso hold n_jobs entries.  grid and out_dev are per JOB either way.
     if (n_jobs <= 0) return LBL_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // layout of the scratch arenas
-    std::vector<size_t> line_off(n_jobs), work_off(n_jobs);
+    auto l0 = [&](int j) { return merge ? merge->first[j] : j; };
+    auto l1 = [&](int j) { return merge ? merge->first[j + 1] : j + 1; };
+    const int n_lists = l1(n_jobs - 1);
+    if (merge && !(ctx->accum_variant == 3 || ctx->accum_variant == 5))
+        return fail(ctx, LBL_ERR_BAD_ARG, "merged layer jobs run on the LDS accumulate kernels only (accum_variant 3 or 5)");
+    // layout of the scratch arenas: the lists of a job are neighbours, so a job's merged record array is one range
+    std::vector<size_t> line_off(n_lists), work_off(n_jobs), job_lines(n_jobs, 0);
     size_t tot_lines = 0, tot_work = 0;
     long long min_H = 1LL << 40;
     int max_lines = 0;
     for (int j = 0; j < n_jobs; ++j) {
-        if (!lines[j] || lines[j]->ctx != ctx) return fail(ctx, LBL_ERR_STATE, "job %d: line list missing or from another context", j);
         int rc = check_grid(ctx, &grid[j]);
         if (rc) return rc;
-        if (!(iso[j].T > 0) || !(iso[j].P > 0) || !(iso[j].molmass > 0) || !(iso[j].Q_T > 0))
-            return fail(ctx, LBL_ERR_BAD_ARG, "job %d: T, P, molmass and Q_T must be > 0", j);
-        line_off[j] = tot_lines;
-        tot_lines += (size_t)lines[j]->n;
+        for (int l = l0(j); l < l1(j); ++l) {
+            if (!lines[l] || lines[l]->ctx != ctx) return fail(ctx, LBL_ERR_STATE, "line list %d: missing or from another context", l);
+            if (!(iso[l].T > 0) || !(iso[l].P > 0) || !(iso[l].molmass > 0) || !(iso[l].Q_T > 0))
+                return fail(ctx, LBL_ERR_BAD_ARG, "line list %d: T, P, molmass and Q_T must be > 0", l);
+            line_off[l] = tot_lines;
+            tot_lines += (size_t)lines[l]->n;
+            job_lines[j] += (size_t)lines[l]->n;
+            max_lines = std::max<int>(max_lines, (int)lines[l]->n);
+        }
+        if (job_lines[j] > 2000000000ull) return fail(ctx, LBL_ERR_BAD_ARG, "job %d: too many lines for int32 indexing", j);
         work_off[j] = tot_work;
         if (needs_regrid(grid[j])) tot_work += (size_t)grid[j].n_work;
         min_H = std::min<long long>(min_H, std::max<long long>(grid[j].window - 2, 0));
-        max_lines = std::max<int>(max_lines, (int)lines[j]->n);
     }
     int rc;
     if ((rc = arena_reserve(ctx, ctx->recs, std::max<size_t>(tot_lines, 1) * sizeof(HotRec)))) return rc;
@@ -1041,8 +1127,8 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     if ((rc = arena_reserve(ctx, ctx->work, std::max<size_t>(tot_work, 1) * sizeof(double)))) return rc;
     // per-block regime counts (3 x u32 per block of 256 lines), summed on the host on demand
     const int blocks_per_job = (max_lines + 255) / 256;
-    const size_t prep_bytes = (size_t)n_jobs * sizeof(PrepJob), acc_bytes = (size_t)n_jobs * sizeof(AccumJob);
-    const size_t cnt_bytes = (size_t)n_jobs * std::max(blocks_per_job, 1) * 3 * sizeof(unsigned int);
+    const size_t prep_bytes = (size_t)n_lists * sizeof(PrepJob), acc_bytes = (size_t)n_jobs * sizeof(AccumJob);
+    const size_t cnt_bytes = (size_t)n_lists * std::max(blocks_per_job, 1) * 3 * sizeof(unsigned int);
     if ((rc = arena_reserve(ctx, ctx->counts, cnt_bytes))) return rc;
     // descriptors are built in pageable host memory first: a batch that repeats (the usual case:
     // same layer, step after step) finds its descriptor block already on the device and skips the copy
@@ -1096,7 +1182,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         while (e < n_jobs && group_key(order[e]) == group_key(order[k])) {
             long long f, c;
             shard_range(grid[order[e]], &f, &c);
-            pts += c; lns += lines[order[e]]->n;
+            pts += c; lns += (long long)job_lines[order[e]];
             const long long H = std::max<long long>(grid[order[e]].window - 2, 0);
             mh = std::min(mh, H); mxh = std::max(mxh, H);
             ++e;
@@ -1109,40 +1195,56 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             // with the R actually chosen (a small grid may have shrunk it): does any job of the group have far lines?
             if (ctx->accum_variant == 5 && mxh < 32LL * g.R * (far_half_spans + 1)) g.variant = 3;
         }
-        if ((g.variant == 3 || g.variant == 5 || g.variant == 6) && ctx->lpt) {
-            // cached host schedule of this group: dispatch order + the line ranges of every span
+        if ((g.variant == 3 || g.variant == 5 || g.variant == 6) && (ctx->lpt || merge)) {
+            // cached schedule of this group: dispatch order + the line ranges of every span (+ merged positions)
             std::vector<int> members(order.begin() + k, order.begin() + e);
+            ctx->sched_refused = false;
             lbl_ctx::Schedule* sc = group_schedule(ctx, g.variant == 6 ? 3 : g.variant, members, lines, grid, g.R, g.LS,
-                                                   accumulate_tile_points(g.R, g.LS, g.variant));
+                                                   accumulate_tile_points(g.R, g.LS, g.variant), merge ? merge->first : nullptr);
+            if (!sc && ctx->sched_refused)
+                return fail(ctx, LBL_ERR_BAD_ARG, "merged layer jobs need the device schedule build, which does not cover a launch of this size: use the per-line-list step");
             if (!sc) return ctx->capturing ? LBL_ERR_STATE : fail(ctx, LBL_ERR_OOM, "schedule allocation failed");
-            if (sc->pending && ctx->capturing) return capture_refuses(ctx, "building a dispatch schedule");
+            if ((sc->pending || sc->merge_pending) && ctx->capturing) return capture_refuses(ctx, "building a dispatch schedule");
             g.worklist = sc->d_list; g.total_tiles = sc->total; g.tabs = sc->d_tabs; g.tab_off = sc->tab_off; g.sched = sc;
         }
         groups.push_back(g);
         k = e;
     }
+    // where the group's schedule keeps the merged positions of job order[k]'s lines (NULL: a job of one list)
+    std::vector<const int32_t*> job_dest(n_jobs, nullptr);
+    for (const Group& g : groups)
+        for (int k = g.first; k < g.first + g.count; ++k)
+            if (g.sched && g.sched->d_dest && g.sched->dest_off[(size_t)(k - g.first)] != SIZE_MAX)
+                job_dest[order[k]] = g.sched->d_dest + g.sched->dest_off[(size_t)(k - g.first)];
     PrepJob* hp = (PrepJob*)stage;
     AccumJob* ha = (AccumJob*)((char*)stage + prep_bytes);
     for (int j = 0; j < n_jobs; ++j) {
-        const lbl_lines* L = lines[j];
-        PrepJob& p = hp[j];
-        memset(&p, 0, sizeof p);
-        p.nu = L->field(0); p.sw = L->field(1); p.elower = L->field(2); p.gamma_air = L->field(3);
-        p.gamma_self = L->field(4); p.n_air = L->field(5); p.delta_air = L->field(6);
-        p.hot = (HotRec*)ctx->recs.ptr + line_off[j];
-        p.cold = (ColdRec*)ctx->cold.ptr + line_off[j];
-        p.cidx = (int32_t*)ctx->cidx.ptr + line_off[j];
-        p.block_counts = d_counts + (size_t)j * blocks_per_job * 3;
-        p.T = iso[j].T; p.P = iso[j].P; p.q_frac = iso[j].q_frac; p.molmass = iso[j].molmass;
-        p.Q_T = iso[j].Q_T; p.Q_296 = iso[j].Q_296;
-        p.range_min = grid[j].range_min; p.resolution = grid[j].resolution;
-        p.log_t0_over_T = std::log(296.0 / iso[j].T);
-        p.P_over_p0 = iso[j].P / p0;
-        { const double m = iso[j].molmass / 1000.0 / avo; p.ghw_factor = std::sqrt(2.0 * kB * iso[j].T / m / (cLight * cLight)); }
-        p.q_ratio = iso[j].Q_296 / iso[j].Q_T;
-        p.inv_T = 1.0 / iso[j].T; p.inv_res = 1.0 / grid[j].resolution; p.inv_res2 = p.inv_res * p.inv_res;
-        p.gauss_cut = ctx->accuracy ? 17179869184.0 : 18014398509481984.0;          // 2^34 : 2^54
-        p.n_lines = (int32_t)L->n;
+        const size_t base = line_off[l0(j)];                          // the job's record array
+        for (int l = l0(j); l < l1(j); ++l) {
+            const lbl_lines* L = lines[l];
+            PrepJob& p = hp[l];
+            memset(&p, 0, sizeof p);
+            p.nu = L->field(0); p.sw = L->field(1); p.elower = L->field(2); p.gamma_air = L->field(3);
+            p.gamma_self = L->field(4); p.n_air = L->field(5); p.delta_air = L->field(6);
+            const bool scattered = job_dest[j] != nullptr;            // several lists: every record goes to its merged position
+            const size_t off = scattered ? base : line_off[l];
+            p.hot = (HotRec*)ctx->recs.ptr + off;
+            p.cold = (ColdRec*)ctx->cold.ptr + off;
+            p.cidx = (int32_t*)ctx->cidx.ptr + off;
+            p.dest = scattered ? job_dest[j] + (line_off[l] - base) : nullptr;
+            p.weight = merge ? merge->weight[l] : 1.0;
+            p.block_counts = d_counts + (size_t)l * blocks_per_job * 3;
+            p.T = iso[l].T; p.P = iso[l].P; p.q_frac = iso[l].q_frac; p.molmass = iso[l].molmass;
+            p.Q_T = iso[l].Q_T; p.Q_296 = iso[l].Q_296;
+            p.range_min = grid[j].range_min; p.resolution = grid[j].resolution;
+            p.log_t0_over_T = std::log(296.0 / iso[l].T);
+            p.P_over_p0 = iso[l].P / p0;
+            { const double m = iso[l].molmass / 1000.0 / avo; p.ghw_factor = std::sqrt(2.0 * kB * iso[l].T / m / (cLight * cLight)); }
+            p.q_ratio = iso[l].Q_296 / iso[l].Q_T;
+            p.inv_T = 1.0 / iso[l].T; p.inv_res = 1.0 / grid[j].resolution; p.inv_res2 = p.inv_res * p.inv_res;
+            p.gauss_cut = ctx->accuracy ? 17179869184.0 : 18014398509481984.0;          // 2^34 : 2^54
+            p.n_lines = (int32_t)L->n;
+        }
     }
     const bool balanced = ctx->accum_variant == 4;
     // balanced variant scratch, per group: SpanRec[S] | counts u32[S] | prefix u64[S+1] | slab
@@ -1152,12 +1254,13 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         const long long tile_pts = accumulate_tile_points(g.R, g.LS, g.variant);
         for (int k = g.first; k < g.first + g.count; ++k) {
             const int j = order[k];
-            const PrepJob& p = hp[j];
             AccumJob& a = ha[k];
             memset(&a, 0, sizeof a);
-            a.hot = p.hot; a.cold = p.cold; a.cidx = p.cidx;
+            a.hot = (const HotRec*)ctx->recs.ptr + line_off[l0(j)];
+            a.cold = (const ColdRec*)ctx->cold.ptr + line_off[l0(j)];
+            a.cidx = (const int32_t*)ctx->cidx.ptr + line_off[l0(j)];
             a.out = needs_regrid(grid[j]) ? (double*)ctx->work.ptr + work_off[j] : out_dev[j];
-            a.n_lines = p.n_lines;
+            a.n_lines = (int32_t)job_lines[j];
             a.n_work = (int32_t)grid[j].n_work;
             a.H = (int32_t)std::max<long long>(grid[j].window - 2, 0);
             long long sf, sc;
@@ -1169,6 +1272,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             a.pad = ctx->tile_order;
             a.ablate = ctx->ablate;
             a.span_tab = g.tabs ? g.tabs + g.tab_off[(size_t)(k - g.first)] : nullptr;
+            a.out_scale = merge ? merge->out_scale[j] : 1.0;
             if (fuse && n_jobs == 1) {
                 a.chain_flags = CHAIN_MOL_FIRST | CHAIN_MOL_LAST;
                 a.conc = fuse_conc;
@@ -1223,13 +1327,54 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     PrepJob* dp = (PrepJob*)d_desc;
     AccumJob* da = (AccumJob*)(d_desc + prep_bytes);
     ctx->last_blocks_per_job = blocks_per_job;
-    ctx->last_job_lines.assign(n_jobs, 0);
-    for (int j = 0; j < n_jobs; ++j) ctx->last_job_lines[j] = (int)lines[j]->n;
+    ctx->last_job_lines.assign(n_lists, 0);
+    for (int l = 0; l < n_lists; ++l) ctx->last_job_lines[l] = (int)lines[l]->n;
+    // Merged layer jobs whose schedule is new: the merged position of every line, ahead of the line prep that scatters its
+    // records through them - each list's centre indices (K1's expression) into scratch, then one rank search per line and
+    // other list of its job.  Once per (line lists, grid); kept in the schedule's block.
+    for (Group& g : groups) {
+        lbl_ctx::Schedule* sc = g.sched;
+        if (!sc || !sc->merge_pending) continue;
+        TraceScope tr("merge ranks (enqueue)", (long long)g.count);
+        std::vector<MergeList> ml;
+        std::vector<size_t> tmp_off;
+        size_t tmp_lines = 0;
+        int ml_max = 0;
+        for (int k = g.first; k < g.first + g.count; ++k) {
+            const int j = order[k];
+            if (!job_dest[j]) continue;
+            const int jf = (int)ml.size();
+            for (int l = l0(j); l < l1(j); ++l) {
+                MergeList m;
+                memset(&m, 0, sizeof m);
+                m.nu = lines[l]->field(0);
+                tmp_off.push_back(tmp_lines);                             // (tmp_cidx is set once the scratch exists)
+                m.dest = const_cast<int32_t*>(job_dest[j]) + (line_off[l] - line_off[l0(j)]);
+                m.range_min = grid[j].range_min; m.resolution = grid[j].resolution;
+                m.n_lines = (int32_t)lines[l]->n;
+                m.job_first = jf; m.job_count = l1(j) - l0(j);
+                tmp_lines += (size_t)lines[l]->n;
+                ml_max = std::max(ml_max, m.n_lines);
+                ml.push_back(m);
+            }
+        }
+        const size_t list_bytes = (ml.size() * sizeof(MergeList) + 255) & ~(size_t)255;
+        if ((rc = arena_reserve(ctx, ctx->merge_tmp, list_bytes + std::max<size_t>(tmp_lines, 1) * sizeof(int32_t)))) return rc;
+        int32_t* tmp_base = (int32_t*)((char*)ctx->merge_tmp.ptr + list_bytes);
+        for (size_t i = 0; i < ml.size(); ++i) ml[i].tmp_cidx = tmp_base + tmp_off[i];
+        void* pinned = nullptr;
+        if ((rc = stage_alloc(ctx, list_bytes, &pinned))) return rc;
+        memcpy(pinned, ml.data(), ml.size() * sizeof(MergeList));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->merge_tmp.ptr, pinned, ml.size() * sizeof(MergeList), hipMemcpyHostToDevice, ctx->stream));
+        launch_merge_ranks((const MergeList*)ctx->merge_tmp.ptr, (int)ml.size(), ml_max, ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+        sc->merge_pending = false;
+    }
     hipEvent_t ev = prof_begin(ctx, PROF_PREP);
-    launch_line_prep(dp, n_jobs, max_lines, ctx->stream);
+    launch_line_prep(dp, n_lists, max_lines, ctx->stream);
     prof_end(ctx, PROF_PREP, ev);
     HIP_TRY(ctx, hipGetLastError());
-    ctx->last_jobs = n_jobs;
+    ctx->last_jobs = n_lists;
     ctx->last_prep_desc = dp;
     if (prep_only) return LBL_OK;
     // schedules that have not been built yet: span tables from the centre indices K1 has just written, tile costs and
@@ -1456,7 +1601,7 @@ extern "C" int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* x
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (n_iso < 0 || n_iso > kMaxIso || n_mol < 0 || n_mol > kMaxIso) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d isotopologues per sweep", kMaxIso);
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
-    if (first < 0 || count < 0 || first + count > n) return fail(ctx, LBL_ERR_BAD_ARG, "swept range outside [0, n)");
+    if (first < 0 || count < 0 || count > n - first) return fail(ctx, LBL_ERR_BAD_ARG, "swept range outside [0, n)");
     if (count == 0) { first = 0; count = n; }
     if (n_iso > 0 && (!xsec || !iso_mol)) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     if (n_mol > 0 && !conc) return fail(ctx, LBL_ERR_BAD_ARG, "conc is NULL");
@@ -1554,13 +1699,203 @@ extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lin
                                grid->range_max, n, whole ? 0 : sf, whole ? 0 : sc, I_in, surface_T, abs_coef, trans, I_out);
 } LBL_GUARD_END(ctx)
 
+// ---- merged layer jobs: north_star's "shared wavenumber-grid absorption-coefficient array" -------------------------------
+// The reference's layer result is Layer.absCoef = sum over molecules of Molecule.absCoef = (sum over isotopologues of
+// crossSection) * concentration * P / 1E4 / k / T (pyradClasses.py:707-712, 581-583, 566-571).  Here every line of every
+// list of the layer accumulates straight into that sum: K1 multiplies each list's amplitudes by its molecule's factor
+// f_m = conc_m P / 1E4 / k / T (evaluated on the host in the reference's order) and writes all records into ONE array in
+// centre-index order; K2 runs ONE job over it.  The per-isotopologue cross sections are not materialised (the reference
+// computes them lazily too, progressCrossSection, pyradClasses.py:32-88: lbl_xsec_accumulate_dev produces any of them on
+// demand).  So that K2's intermediate magnitudes stay those of a cross section (the running fraction's range analysis), the
+// weights are f_m / 2^e with 2^e the power of two just above the largest |f_m|, and every sum is multiplied by 2^e on its way
+// out: both scalings are exact.
+static void merged_weights(int n_iso, const int32_t* iso_mol, const double* conc, double P, double T, double* weight,
+                           double* out_scale) {
+    double fmax = 0.0;
+    bool finite = true;
+    for (int i = 0; i < n_iso; ++i) {
+        weight[i] = budget_factor(conc[iso_mol[i]], P, T);
+        finite = finite && std::isfinite(weight[i]);
+        fmax = std::max(fmax, std::fabs(weight[i]));
+    }
+    int e = 0;
+    if (finite && fmax > 0.0) (void)std::frexp(fmax, &e);       // fmax = m 2^e, m in [0.5, 1)
+    if (e > 1000 || e < -1000) e = 0;                            // (absurd inputs: leave the magnitudes alone)
+    *out_scale = std::ldexp(1.0, e);
+    for (int i = 0; i < n_iso; ++i) weight[i] = std::ldexp(weight[i], -e);
+}
+
+static int check_layer_lists(lbl_ctx* ctx, int n_iso, const lbl_iso_params* iso, const int32_t* iso_mol, int n_mol, int layer) {
+    for (int i = 0; i < n_iso; ++i) {
+        if (iso_mol[i] < 0 || iso_mol[i] >= n_mol || (i > 0 && iso_mol[i] < iso_mol[i - 1]))
+            return fail(ctx, LBL_ERR_BAD_ARG, "layer %d: iso_mol must be non-decreasing and < n_mol", layer);
+        if (iso[i].T != iso[0].T || iso[i].P != iso[0].P)
+            return fail(ctx, LBL_ERR_BAD_ARG, "layer %d, line list %d: T and P must be the layer's (those of its first line list)", layer, i);
+    }
+    return LBL_OK;
+}
+
+extern "C" int lbl_layer_merged_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lines, const lbl_iso_params* iso,
+                                         const lbl_grid* grid, const int32_t* iso_mol, int n_mol, const double* conc,
+                                         double depth, lbl_buffer* I_in, double surface_T, lbl_buffer* abs_coef,
+                                         lbl_buffer* trans, lbl_buffer* I_out) try {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (n_iso < 1 || n_iso > kMaxIso || n_mol < 1 || n_mol > kMaxIso) return fail(ctx, LBL_ERR_BAD_ARG, "1..%d line lists and molecules per layer step", kMaxIso);
+    if (!lines || !iso || !grid || !iso_mol || !conc) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    int rc;
+    if ((rc = check_grid(ctx, grid))) return rc;
+    if ((rc = check_layer_lists(ctx, n_iso, iso, iso_mol, n_mol, 0))) return rc;
+    const int64_t n = grid->n_base;
+    if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
+    if ((rc = check_buf(ctx, abs_coef, n, "abs_coef", false))) return rc;
+    if ((rc = check_buf(ctx, trans, n, "trans", false))) return rc;
+    if ((rc = check_buf(ctx, I_out, n, "I_out", false))) return rc;
+    if (I_out && !I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "I_out needs I_in or surface_T > 0");
+    if (!abs_coef && !trans && !I_out) return fail(ctx, LBL_ERR_BAD_ARG, "no output array");
+    std::vector<double> weight((size_t)n_iso);
+    double out_scale = 1.0;
+    merged_weights(n_iso, iso_mol, conc, iso[0].P, iso[0].T, weight.data(), &out_scale);
+    const int first[2] = {0, n_iso};
+    MergeSpec ms{first, weight.data(), &out_scale};
+    FusedSweep f;
+    memset(&f, 0, sizeof f);
+    f.P = iso[0].P; f.T = iso[0].T; f.depth = depth;
+    f.rT = uniform_rcp(f.T); f.r_surface_T = uniform_rcp(surface_T);
+    f.start = grid->range_min; f.stop = grid->range_max; f.step = axis_step(grid->range_min, grid->range_max, n);
+    planck_constants(&f.pa, &f.pb);
+    f.surface_T = surface_T;
+    f.I_in = I_in ? I_in->d : nullptr;
+    f.abs_coef = abs_coef ? abs_coef->d : nullptr;
+    f.trans = trans ? trans->d : nullptr;
+    f.I_out = I_out ? I_out->d : nullptr;
+    f.n = n; f.on = 2;
+    f.budget = 1; f.factor = 1.0;                  // (merged jobs exist in the sweeps' default arithmetic only)
+    f.pbkT = budget_pbkT(f.T); f.pbk_surface = budget_pbkT(surface_T);
+    if (!needs_regrid(*grid)) {
+        double* out = nullptr;
+        if (!trans && !I_out) {
+            // only the absorption coefficient is wanted: the kernel's plain store, no sweep arithmetic
+            out = abs_coef->d;
+            return enqueue_accumulate(ctx, 1, lines, iso, grid, &out, false, nullptr, 0.0, &ms);
+        }
+        return enqueue_accumulate(ctx, 1, lines, iso, grid, &out, false, &f, 0.0, &ms);
+    }
+    // a coarser work grid (dynamic resolution, pyradClasses.py:659-662, 401-405): k on the work grid, np.interp onto the base
+    // grid (linear, like the sum it is applied to), then the sweep of that one array
+    double* kdst = abs_coef ? abs_coef->d : nullptr;
+    if (!kdst) {
+        if ((rc = arena_reserve(ctx, ctx->ktmp, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
+        kdst = (double*)ctx->ktmp.ptr;
+    }
+    if ((rc = enqueue_accumulate(ctx, 1, lines, iso, grid, &kdst, false, nullptr, 0.0, &ms))) return rc;
+    if (!trans && !I_out) return LBL_OK;
+    SweepArgs a;
+    memset(&a, 0, sizeof a);
+    a.xsec[0] = kdst; a.term_conc[0] = 1.0; a.term_factor[0] = 1.0; a.term_flags[0] = TERM_LAST_MOL;
+    a.budget = 1; a.pbkT = f.pbkT; a.pbk_surface = f.pbk_surface;
+    a.n_iso = 1; a.n_mol = 1; a.P = f.P; a.T = f.T; a.depth = depth;
+    a.variant = 0;                                   // (k is read here and again by the caller: no streaming hints)
+    a.rT = f.rT; a.r_surface_T = f.r_surface_T;
+    a.start = f.start; a.stop = f.stop; a.step = f.step; a.pa = f.pa; a.pb = f.pb;
+    a.surface_T = surface_T;
+    a.I_in = f.I_in; a.abs_coef = nullptr; a.trans = f.trans; a.I_out = f.I_out;
+    a.n = n; a.first = 0; a.count = n;
+    hipEvent_t ev = prof_begin(ctx, PROF_SWEEP);
+    launch_layer_sweep(a, ctx->stream);
+    prof_end(ctx, PROF_SWEEP, ev);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBL_OK;
+} LBL_GUARD_END(ctx)
+
+extern "C" int lbl_layers_merged_accumulate_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_iso, lbl_lines* const* lines,
+                                                const lbl_iso_params* iso, const lbl_grid* grid, const int32_t* iso_mol,
+                                                const int32_t* n_mol, const double* conc, lbl_buffer* const* abs_coef) try {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (n_layers < 0 || n_layers > LBL_MAX_JOBS) return fail(ctx, LBL_ERR_BAD_ARG, "0..%d layers per batch", LBL_MAX_JOBS);
+    if (n_layers == 0) return LBL_OK;
+    if (!n_iso || !lines || !iso || !grid || !iso_mol || !n_mol || !conc || !abs_coef) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    std::vector<int> first((size_t)n_layers + 1, 0);
+    std::vector<double> out_scale((size_t)n_layers, 1.0);
+    std::vector<double*> outs((size_t)n_layers);
+    long long total = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (n_iso[l] < 1 || n_iso[l] > kMaxIso || n_mol[l] < 1 || n_mol[l] > kMaxIso)
+            return fail(ctx, LBL_ERR_BAD_ARG, "layer %d: 1..%d line lists and molecules per layer", l, kMaxIso);
+        total += n_iso[l];
+        if (total > LBL_MAX_JOBS) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d line lists per batch", LBL_MAX_JOBS);
+        first[(size_t)l + 1] = (int)total;
+    }
+    std::vector<double> weight((size_t)total);
+    int rc, mol0 = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int i0 = first[(size_t)l];
+        if ((rc = check_grid(ctx, &grid[l]))) return rc;
+        if ((rc = check_layer_lists(ctx, n_iso[l], iso + i0, iso_mol + i0, n_mol[l], l))) return rc;
+        if ((rc = check_buf(ctx, abs_coef[l], grid[l].n_base, "abs_coef", true))) return rc;
+        merged_weights(n_iso[l], iso_mol + i0, conc + mol0, iso[i0].P, iso[i0].T, weight.data() + i0, &out_scale[(size_t)l]);
+        outs[(size_t)l] = abs_coef[l]->d;
+        mol0 += n_mol[l];
+    }
+    MergeSpec ms{first.data(), weight.data(), out_scale.data()};
+    return enqueue_accumulate(ctx, n_layers, lines, iso, grid, outs.data(), false, nullptr, 0.0, &ms);
+} LBL_GUARD_END(ctx)
+
+extern "C" int lbl_column_fold_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const* abs_coef, const double* T,
+                                   const double* depth, double range_min, double range_max, int64_t n, int64_t first,
+                                   int64_t count, lbl_buffer* I_in, double surface_T, lbl_buffer* const* trans,
+                                   lbl_buffer* I_out) try {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (n_layers < 0 || n_layers > kMaxLayers) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d layers", kMaxLayers);
+    if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
+    if (first < 0 || count < 0 || count > n - first) return fail(ctx, LBL_ERR_BAD_ARG, "swept range outside [0, n)");
+    if (count == 0) { first = 0; count = n; }
+    if (n_layers > 0 && (!abs_coef || !T || !depth)) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    int rc;
+    if ((rc = check_buf(ctx, I_out, n, "I_out", true))) return rc;
+    if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
+    if (!I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "need I_in or surface_T > 0");
+    std::vector<char> blk(sizeof(ColumnStepArgs), 0);
+    ColumnStepArgs* a = (ColumnStepArgs*)blk.data();
+    for (int l = 0; l < n_layers; ++l) {
+        if ((rc = check_buf(ctx, abs_coef[l], n, "abs_coef", true))) return rc;
+        if (!(T[l] > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "layer %d: T must be > 0", l);
+        // one term per layer: the "cross section" is the layer's absorption coefficient, its factor 1
+        a->xsec[l] = abs_coef[l]->d;
+        a->term_conc[l] = 1.0; a->term_factor[l] = 1.0;
+        a->term_flags[l] = TERM_LAST_MOL | TERM_LAST_LAYER;
+        a->term_P[l] = 0.0; a->term_T[l] = T[l]; a->term_depth[l] = depth[l];
+        a->term_rT[l] = uniform_rcp(T[l]);
+        a->term_pbkT[l] = budget_pbkT(T[l]);
+        if (trans && trans[l]) { if ((rc = check_buf(ctx, trans[l], n, "trans", true))) return rc; a->trans[l] = trans[l]->d; a->layer_arrays = 1; }
+    }
+    a->n_terms = n_layers;
+    a->ablate = ctx->ablate;
+    a->n_layers = n_layers;
+    a->start = range_min; a->stop = range_max; a->step = axis_step(range_min, range_max, n);
+    planck_constants(&a->pa, &a->pb);
+    a->surface_T = surface_T;
+    a->r_surface_T = uniform_rcp(surface_T);
+    a->pbk_surface = budget_pbkT(surface_T);
+    a->I_in = I_in ? I_in->d : nullptr;
+    a->I_out = I_out->d;
+    a->n = n; a->first = first; a->count = count;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void* d_args = nullptr;
+    if ((rc = device_args(ctx, a, sizeof(ColumnStepArgs), &d_args))) return rc;
+    hipEvent_t ev = prof_begin(ctx, PROF_COLUMN);
+    launch_column_step((const ColumnStepArgs*)d_args, first, count, ctx->stream, 1);
+    prof_end(ctx, PROF_COLUMN, ev);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBL_OK;
+} LBL_GUARD_END(ctx)
+
 extern "C" int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const* trans, const double* layer_T,
                                     double range_min, double range_max, int64_t n, int64_t first, int64_t count,
                                     lbl_buffer* I_in, double surface_T, lbl_buffer* I_out) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (n_layers < 0 || n_layers > kMaxLayers) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d layers", kMaxLayers);
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
-    if (first < 0 || count < 0 || first + count > n) return fail(ctx, LBL_ERR_BAD_ARG, "swept range outside [0, n)");
+    if (first < 0 || count < 0 || count > n - first) return fail(ctx, LBL_ERR_BAD_ARG, "swept range outside [0, n)");
     if (count == 0) { first = 0; count = n; }
     if (n_layers > 0 && (!trans || !layer_T)) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     int rc;
@@ -1604,7 +1939,7 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (n_layers < 0 || n_layers > kMaxLayers) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d layers", kMaxLayers);
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
-    if (first < 0 || count < 0 || first + count > n) return fail(ctx, LBL_ERR_BAD_ARG, "swept range outside [0, n)");
+    if (first < 0 || count < 0 || count > n - first) return fail(ctx, LBL_ERR_BAD_ARG, "swept range outside [0, n)");
     if (count == 0) { first = 0; count = n; }
     if (n_layers > 0 && (!n_iso || !n_mol || !P || !T || !depth)) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     int rc;

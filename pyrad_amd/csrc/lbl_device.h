@@ -58,7 +58,9 @@ struct FusedSweep {
     const double* I_in;
     double* abs_coef; double* trans; double* I_out;
     long long n;
-    int32_t on, budget;             // budget: the sweeps' default arithmetic ("sweep_ieee_divisions" 0; see lbl_kernels.hip)
+    int32_t on, budget;             // on: 1 the job's sum is a cross section (fold with `factor` / the IEEE chain first); 2 (merged layer job,
+                                    // lbl_layer_merged_step_dev) it IS the absorption coefficient.  budget: the sweeps' default arithmetic
+                                    // ("sweep_ieee_divisions" 0; see lbl_kernels.hip)
     double factor, pbkT, pbk_surface;   // for it: conc * P / 1E4 / k / T; 100 h c / k / T; 100 h c / k / surface_T
 };
 
@@ -66,7 +68,7 @@ struct AccumJob {
     const HotRec* hot;
     const ColdRec* cold;
     const int32_t* cidx;   // centre indices, non-decreasing
-    double* out;           // work grid, n_work doubles
+    double* out;           // work grid, n_work doubles (NULL: not stored - a merged layer job whose sweep is fused in)
     int32_t n_lines;
     int32_t n_work;
     int32_t H;             // wing support in points = max(window-2, 0)
@@ -86,7 +88,10 @@ struct AccumJob {
     int32_t chain_flags;
     int32_t ablate;        // LBL_DIAG builds only (lbl_set_option debug_ablate, scripts/ablate.sh): timing-only runs skip parts of the kernel; else 0 and never read
     double conc;
-    FusedSweep fuse;       // fuse.on: sweep every point right after its cross section is final
+    // Every sum leaves the kernel multiplied by out_scale: 1.0 for a line list's cross section (x * 1.0 is exact), and the
+    // power of two 2^e that a merged layer job's record weights were divided by (exact as well), see PrepJob.weight.
+    double out_scale;
+    FusedSweep fuse;       // fuse.on: sweep every point right after its sum is final
 };
 enum : int32_t { CHAIN_MOL_FIRST = 1, CHAIN_MOL_LAST = 2 };
 
@@ -112,7 +117,29 @@ struct PrepJob {
                             // the line's sum; budget mode 2^34: until it is below 2^-34 (5.8e-11) of the line's own Lorentz term
     int32_t n_lines;
     int32_t pad;
+    // Merged layer job (lbl_layer_merged_step_dev, lbl_layers_merged_accumulate_dev): the records of ALL line lists of a layer go
+    // into ONE array in centre-index order (hot / cold / cidx then point at the layer's array, and line i of this list is
+    // written at dest[i]), each list's amplitudes KL, KG pre-multiplied by weight = conc P / 1E4 / k / T of its molecule
+    // (pyradClasses.py:583) over a power of two common to the layer, so that the accumulate kernel's sum is the layer's
+    // absorption coefficient sum_m f_m sum_iso xs_iso (pyradClasses.py:707-712, 566-571) up to that exact factor.
+    // dest == NULL: the list's own array, record i at i; weight 1.0 leaves every bit as it was (x * 1.0).
+    const int32_t* dest;
+    double weight;
 };
+
+// Merge of a layer's sorted centre-index lists (once per window, beside the schedule build): list `a` of a job holds lines
+// whose centre indices (tmp_cidx, written by centre_index_kernel with K1's own expression) are non-decreasing; line i of it
+// goes to  i + sum_{b < a} #{c_b <= c} + sum_{b > a} #{c_b < c}  - the stable merge, ties by list order.
+struct MergeList {
+    const double* nu;
+    int32_t* tmp_cidx;     // this list's centre indices (scratch)
+    int32_t* dest;         // out: merged position of every line (kept with the schedule)
+    double range_min, resolution;
+    int32_t n_lines;
+    int32_t job_first, job_count;     // the lists [job_first, job_first + job_count) of the MergeList array form this list's job
+    int32_t pad;
+};
+void launch_merge_ranks(const MergeList* d_lists, int n_lists, int max_lines, hipStream_t s);
 
 // Device-side schedule build (lbl_kernels.hip "Schedule of a launch group"): one per job of the group
 struct SchedJob {

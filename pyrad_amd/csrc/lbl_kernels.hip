@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
     int regime = -1;
     if (i < J.n_lines) {
         const LinePhysics L = line_physics(J, i);
-        const double lhw = L.lhw, ghw = L.ghw, ratio = L.ratio, A = L.A;
+        // (merged layer job: the molecule's conc P / 1E4 / k / T over a power of two rides on the intensity; 1.0 otherwise: exact)
+        const double lhw = L.lhw, ghw = L.ghw, ratio = L.ratio, A = L.A * J.weight;
         long long idx = (long long)L.fidx;
         if (idx > 2000000000LL) idx = 2000000000LL;
         if (idx < -2000000000LL) idx = -2000000000LL;
@@ -312,9 +313,10 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
         // (no Lorentz part to be negligible against: their term counts until it underflows) keep the 4-point pass.
         if (rc.b <= 1.0 && KL != 0.0) r.flags |= REC_LONG_RUN;
         rc.KLd = r.KL;
-        J.hot[i] = r;
-        J.cold[i] = rc;
-        J.cidx[i] = (int32_t)idx;
+        const int o = J.dest ? J.dest[i] : i;           // merged layer job: this line's place in the layer's centre-index order
+        J.hot[o] = r;
+        J.cold[o] = rc;
+        J.cidx[o] = (int32_t)idx;
     }
     // regime counters (pyradClasses.py:368-370, 406).  One plain store per block: thousands of
     // atomics on one cache line cost ~12 ns each and made this kernel 3x longer than its arithmetic.
@@ -340,9 +342,51 @@ __global__ __launch_bounds__(256) void line_quantities_kernel(const PrepJob* __r
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= J.n_lines) return;
     const LinePhysics L = line_physics(J, i);
-    index[i] = (long long)J.cidx[i];
+    index[i] = (long long)J.cidx[J.dest ? J.dest[i] : i];
     lhw[i] = L.lhw; ghw[i] = L.ghw; intensity[i] = L.A;
     regime[i] = line_regime(L.ratio);
+}
+
+// Merged layer jobs: where every line of every list of a layer goes in the layer's one record array (centre-index order,
+// ties by list).  Built once per (line lists, grid) beside the dispatch schedule and kept with it; K1 then scatters its
+// records through `dest` in every step.  centre_index_kernel evaluates K1's own expression (line_physics / line_prep_kernel:
+// (nu - range_min) / resolution, truncated, clamped), so the order is the order of the very indices K1 will write.
+__global__ __launch_bounds__(256) void centre_index_kernel(const MergeList* __restrict__ lists) {
+    const MergeList& M = lists[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M.n_lines) return;
+    long long idx = (long long)((M.nu[i] - M.range_min) / M.resolution);
+    if (idx > 2000000000LL) idx = 2000000000LL;
+    if (idx < -2000000000LL) idx = -2000000000LL;
+    M.tmp_cidx[i] = (int32_t)idx;
+}
+
+__global__ __launch_bounds__(256) void merge_rank_kernel(const MergeList* __restrict__ lists) {
+    const MergeList& M = lists[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M.n_lines) return;
+    const long long c = M.tmp_cidx[i];
+    int pos = i;
+    for (int b = M.job_first; b < M.job_first + M.job_count; ++b) {
+        if (b == (int)blockIdx.y) continue;
+        const MergeList& O = lists[b];
+        // lists ahead of this one win ties (count their lines with c_b <= c), lists behind lose them (c_b < c)
+        int lo = 0, hi = O.n_lines;
+        const long long target = b < (int)blockIdx.y ? c + 1 : c;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((long long)O.tmp_cidx[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        pos += lo;
+    }
+    M.dest[i] = pos;
+}
+
+void launch_merge_ranks(const MergeList* d_lists, int n_lists, int max_lines, hipStream_t s) {
+    if (n_lists <= 0 || max_lines <= 0) return;
+    dim3 grid((max_lines + 255) / 256, n_lists);
+    hipLaunchKernelGGL(centre_index_kernel, grid, dim3(256), 0, s, d_lists);
+    hipLaunchKernelGGL(merge_rank_kernel, grid, dim3(256), 0, s, d_lists);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1268,6 +1312,23 @@ __device__ __forceinline__ void fused_finish(const FusedSweep& A, long long j, d
     }
 }
 
+// What leaves an accumulate job for grid point j: the sum times the job's exact output scale (1.0 for a line list's cross
+// section; 2^e for a merged layer job, whose records K1 weighted by conc P / 1E4 / k / T / 2^e: the absorption coefficient),
+// stored if the job has an output array, and the sweep of the point when it is fused in.
+__device__ __forceinline__ void output_point(const AccumJob& J, double* __restrict__ out, long long j, double sum) {
+    const double t = sum * J.out_scale;
+    if (out) out[j] = t;
+    if (J.fuse.on == 2) {
+        // merged layer job (lbl_layer_merged_step_dev): t is the layer's absorption coefficient (pyradClasses.py:707-712)
+        fused_finish(J.fuse, j, t);
+    } else if (J.fuse.on) {
+        // a layer with ONE line list: the sweep of a point right here, its cross section is in a register
+        double xs_m = 0.0, kk = 0.0;
+        fused_fold(J.fuse, J, t, xs_m, kk);
+        fused_finish(J.fuse, j, kk);
+    }
+}
+
 
 template <int R, int LS, int NT = 0>                                                     // NT: far-field series terms (0: every pair direct)
 __global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), ((R >= 4 && LS <= 4) ? 4 : 1))     // HIP: min waves per SIMD
@@ -1411,15 +1472,7 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
             const int o = i * 64 + lane;
             double t = s_stage[w0][span_slot(o)];
             for (int q = 1; q < LS; ++q) t += s_stage[w0 + q][span_slot(o)];
-            if (wlo + o < n_end) {
-                out[wlo + o] = t;
-                if (J.fuse.on) {
-                    // a layer with ONE line list: the sweep of a point right here, its cross section is in a register
-                    double xs_m = 0.0, kk = 0.0;
-                    fused_fold(J.fuse, J, t, xs_m, kk);
-                    fused_finish(J.fuse, wlo + o, kk);
-                }
-            }
+            if (wlo + o < n_end) output_point(J, out, wlo + o, t);
         }
     }
 }
@@ -1617,14 +1670,7 @@ __global__ __launch_bounds__(256, 4) void xsec_accumulate_skew_kernel(const Accu
     for (int i = 0; i < R; ++i) {
         const int o = i * 64 + lane;
         const double t = mine[span_slot(o)];
-        if (wlo + o < n_end) {
-            out[wlo + o] = t;
-            if (J.fuse.on) {
-                double xs_m = 0.0, kk = 0.0;
-                fused_fold(J.fuse, J, t, xs_m, kk);
-                fused_finish(J.fuse, wlo + o, kk);
-            }
-        }
+        if (wlo + o < n_end) output_point(J, out, wlo + o, t);
     }
 }
 

@@ -337,11 +337,19 @@ class ResidentLayer:
                                  abs_coef=self.abs_coef, trans=self.trans,
                                  I_out=self.I_out if want_I else None, first=first, count=count)
 
-    def enqueue(self, surface_T=288.0, I_in=None, fused=True):
-        """One layer step: line prep, accumulate, sweep.  ``fused`` (default): the sweep rides in the
-        accumulate kernel's output stage (lbl_layer_step_dev, any number of line lists); False: the
+    def enqueue(self, surface_T=288.0, I_in=None, fused=True, merged=False):
+        """One layer step: line prep, accumulate, sweep.  ``merged``: ONE accumulate job over the layer's merged,
+        factor-weighted line lists with the sweep in its output stage (lbl_layer_merged_step_dev): the absorption
+        coefficient is accumulated directly and the per-line-list cross sections are not written (``enqueue_xsec``
+        produces them on demand).  Otherwise one job per line list: ``fused`` (default) through lbl_layer_step_dev
+        (the sweep rides in the accumulate kernel's output stage when the layer has one line list); False: the
         accumulate launch followed by the separate sweep launch (bit-identical, kept for A/B tests)."""
         if self.empty:
+            return
+        if merged and self.jobs:
+            self.ctx.layer_merged_step_dev([j[0] for j in self.jobs], [j[1] for j in self.jobs], self.grid_native,
+                                           self.iso_mol, self.conc, self.depth, I_in=I_in, surface_T=surface_T,
+                                           abs_coef=self.abs_coef, trans=self.trans, I_out=self.I_out)
             return
         if fused and self.jobs:
             self.ctx.layer_step_dev([j[0] for j in self.jobs], [j[1] for j in self.jobs], self.grid_native,
@@ -471,14 +479,26 @@ class ResidentColumn:
         self.n_lines = sum(L.n_lines for L in self.layers)
         self.pairs = {k: sum(L.pairs[k] for L in self.layers) for k in self.layers[0].pairs}
 
-    def enqueue(self, layer_arrays=True, fused=True):
-        """One column step.  ``fused``: a single pass over all cross sections (lbl_column_step_dev)
-        instead of one sweep per layer plus the fold; ``layer_arrays`` False skips writing the
-        per-layer absorption coefficient / transmittance arrays (only the outgoing spectrum)."""
+    def enqueue(self, layer_arrays=True, fused=True, merged=False):
+        """One column step.  ``merged``: one accumulate job per LAYER over its merged, factor-weighted line lists
+        (lbl_layers_merged_accumulate_dev: 30 absorption-coefficient arrays instead of 90 cross sections), then the
+        fold over them (lbl_column_fold_dev; ``layer_arrays`` also writes the transmittances).  Otherwise one job per
+        line list and, ``fused``: a single pass over all cross sections (lbl_column_step_dev) instead of one sweep per
+        layer plus the fold; ``layer_arrays`` False skips writing the per-layer absorption coefficient /
+        transmittance arrays (only the outgoing spectrum)."""
         if self.empty:
             return
-        self.ctx.xsec_accumulate_dev(self.jobs)
         first, count = (0, 0) if self.plan is None else (self.first, self.count)
+        if merged and all(L.jobs for L in self.layers):
+            self.ctx.layers_merged_accumulate_dev(
+                [dict(lines=[j[0] for j in L.jobs], iso=[j[1] for j in L.jobs], grid=L.grid_native, iso_mol=L.iso_mol,
+                      conc=L.conc, abs_coef=L.abs_coef) for L in self.layers])
+            self.ctx.column_fold_dev([L.abs_coef for L in self.layers], [L.T for L in self.layers],
+                                     [L.depth for L in self.layers], self.layers[0].range_min, self.layers[0].range_max,
+                                     self.n, self.I_toa, surface_T=self.surface_T,
+                                     trans=[L.trans for L in self.layers] if layer_arrays else None, first=first, count=count)
+            return
+        self.ctx.xsec_accumulate_dev(self.jobs)
         if fused:
             desc = [dict(xsec=[j[3] for j in L.jobs], iso_mol=L.iso_mol, conc=L.conc, P=L.P, T=L.T, depth=L.depth,
                          trans=L.trans if layer_arrays else None, abs_coef=L.abs_coef if layer_arrays else None)

@@ -99,6 +99,7 @@ def resetCrossSection(obj):
             type(obj).crossSection.defer(obj, lambda n=n: np.zeros(n))      # the zeros of cls:41, made when read
             if isinstance(obj, Isotope):
                 obj._host_array_assigned("_crossSection_host")
+                obj._inputs_version += 1             # (a merged layer step computed from this isotopologue is stale too)
             obj.progressCrossSection = False
     if isinstance(obj, Isotope):
         return                      # its children are Lines (the reference walks them and skips each one)
@@ -368,6 +369,7 @@ def _mark_computed(ctx, isotopes, n):
     for iso in isotopes:
         iso._xs_version += 1
         iso._dev_xsec_valid = True
+        iso._xs_deferred = False
         Isotope.crossSection.defer(iso, (lambda b=iso._dev_xsec, n=n: b.download(n, pinned=True)))
         iso._regime_counts = None
         iso.progressCrossSection = True
@@ -380,7 +382,7 @@ def _compute_cross_sections(isotopes):
     """Batched Isotope.createCrossSection (cls:361-407) for every dirty isotopologue in the
     list: one prep launch + one accumulate launch for all of them.  The cross sections stay on
     the device; ``iso.crossSection`` downloads on first read."""
-    dirty = [i for i in isotopes if not i.progressCrossSection and not i.exotic]
+    dirty = [i for i in isotopes if (not i.progressCrossSection or i._xs_deferred) and not i.exotic]
     if not dirty:
         return
     ctx = _ctx()
@@ -422,6 +424,30 @@ class _OpticalMixin:
         dirty = [i for i in lbl if not i.progressCrossSection]
         fusable = (dirty and len(dirty) == len(flat) and g["resolution"] == g["base_resolution"]
                    and g["n_work"] == n and len(flat) <= 48)
+        if self._merged_step_applies(flat, lbl):
+            # A LAYER whose line lists are due (any of them dirty): ONE accumulate job over the merged, factor-weighted
+            # line lists - the absorption coefficient sum_m f_m sum_iso xs_iso (cls:707-712, 581-583, 566-571) accumulated
+            # directly, the transmittance in the kernel's output stage.  No isotopologue cross section is written, and none
+            # is marked computed: getCrossSection(isotope | molecule) produces it when asked (the reference's lazy
+            # protocol, cls:32-88), and the layer's arrays are found again through the key below until an input changes.
+            key = self._merged_key(flat, conc, layer, g)
+            if st.key != key and isinstance(st.key, tuple) and st.key[:-1] == key[:-1]:
+                # only the depth changed (changeDepth resets nothing, cls:754-755): the absorption coefficient stands,
+                # the transmittance exp(-k depth) (cls:714-716) is redone from it
+                ctx.column_fold_dev([st.bufs["abs_coef"]], [layer.T], [layer.depth], layer.rangeMin, layer.rangeMax, n,
+                                    st.buf(ctx, "tmp"), surface_T=float(layer.T), trans=[st.buf(ctx, "trans")])
+                st.key = key
+            elif st.key != key:
+                _check_window(g)
+                iso_mol = [m for m, isos in enumerate(members) for _ in isos]
+                ctx.layer_merged_step_dev([i._device_lines(ctx) for i in flat], [_iso_params(i) for i in flat],
+                                          _engine.native_grid(g), iso_mol, conc, layer.depth,
+                                          abs_coef=st.buf(ctx, "abs_coef"), trans=st.buf(ctx, "trans"))
+                st.key = key
+            for iso in flat:
+                iso._defer_cross_section()
+            self._members_ready()
+            return st, n
         if fusable:
             _check_window(g)
             iso_mol = [m for m, isos in enumerate(members) for _ in isos]
@@ -441,6 +467,14 @@ class _OpticalMixin:
                 st.key = self._sweep_key(flat, conc, layer, g)
         self._members_ready()
         return st, n
+
+    def _merged_step_applies(self, flat, lbl):
+        return False                    # (Layer overrides: isotopologues and molecules keep the per-line-list path)
+
+    @staticmethod
+    def _merged_key(flat, conc, layer, g):
+        return ("merged", tuple((id(i), i._inputs_version) for i in flat), tuple(float(c) for c in conc), layer.P, layer.T,
+                layer.rangeMin, layer.rangeMax, g["n_base"], g["resolution"], settings.ACCURACY, layer.depth)     # (depth last)
 
     @staticmethod
     def _sweep_key(flat, conc, layer, g):
@@ -550,6 +584,8 @@ class Isotope(_OpticalMixin, list):
         self._dev_xsec = None
         self._dev_xsec_valid = False
         self._xs_version = 0
+        self._xs_deferred = False        # marked computed by a merged layer step: the array itself is made when somebody reads it
+        self._inputs_version = 0         # bumped by everything that marks the cross section dirty (resetCrossSection, new lines)
         self._regime_counts = (0, 0, 0)
         _copy_of_layer_cross_section(Isotope.crossSection, self, self.layer)
         self.exotic = molecule.exotic
@@ -627,11 +663,32 @@ class Isotope(_OpticalMixin, list):
             self._dev_lines.free()
             self._dev_lines = None
         self.progressCrossSection = False
+        self._inputs_version += 1
 
     def _host_array_assigned(self, which):
         if which == "_crossSection_host":           # somebody installed a host array: the device copy is stale
             self._dev_xsec_valid = False
+            self._xs_deferred = False
             self._xs_version += 1
+
+    def _defer_cross_section(self):
+        """A merged layer step (one accumulate job over all the layer's line lists, settings.LAYER_STEP) has just produced
+        the layer's absorption coefficient WITHOUT this isotopologue's cross-section array.  The reference's protocol
+        (cls:32-88) says the cross section is now computed: progressCrossSection is set as createCrossSection would, and
+        the array is made by the per-line-list path when somebody reads ``crossSection`` (or a device-side consumer asks
+        for it): getCrossSection(isotope), the molecule sums and the per-molecule getters all go through here."""
+        if self.exotic or (self.progressCrossSection and not self._xs_deferred):
+            return                                  # a computed, current array exists
+        self._xs_deferred = True
+        self._dev_xsec_valid = False
+        self._xs_version += 1
+        self._regime_counts = None
+        self.progressCrossSection = True
+        Isotope.crossSection.defer(self, self._materialise_cross_section)
+
+    def _materialise_cross_section(self):
+        _compute_cross_sections([self])             # K1 + K2 for this line list; leaves the download deferred
+        return self.crossSection
 
     @property
     def regimeCounts(self):
@@ -666,6 +723,8 @@ class Isotope(_OpticalMixin, list):
 
     def _device_xsec_current(self, ctx, n):
         """Device copy of self.crossSection (uploaded if a host array was installed since)."""
+        if self._xs_deferred:
+            _compute_cross_sections([self])         # promised by a merged layer step: made now, on the device
         if (self._dev_xsec_valid and self._dev_xsec is not None and self._dev_xsec.h is not None
                 and self._dev_xsec.ctx is ctx):
             return self._dev_xsec
@@ -1007,6 +1066,13 @@ class Layer(_OpticalMixin, list):
         for m in self:
             m._mark_sum_ready()
 
+    def _merged_step_applies(self, flat, lbl):
+        """settings.LAYER_STEP "merged" (default): the layer's property chain comes from one merged accumulate job when
+        any of its line lists is due (all of them line-by-line: a measured cross-section table has no lines to merge).
+        With every cross section current (somebody asked for each of them) the sweep kernel over those arrays is cheaper."""
+        return (settings.LAYER_STEP == "merged" and bool(lbl) and len(lbl) == len(flat) and len(flat) <= 48
+                and any(not i.progressCrossSection or i._xs_deferred for i in lbl))
+
     def createCrossSection(self):
         """cls:684-689: sum of the molecule cross sections.  One fused layer step brings every dirty
         line list up to date (and leaves absorption coefficient and transmittance resident for the
@@ -1146,6 +1212,11 @@ class Atmosphere(list):
                 raise ValueError("all layers of a column must share one wavenumber range")
         ctx = _ctx()
         n = int((first.rangeMax - first.rangeMin) / utils.BASE_RESOLUTION)
+        if surfaceSpectrum is None and surfaceTemperature is None:
+            raise ValueError("give surfaceSpectrum or surfaceTemperature")
+        merged = self._transmission_merged(ctx, layers, n, surfaceSpectrum, surfaceTemperature)
+        if merged is not None:
+            return merged
         _compute_cross_sections([iso for L in layers for m in L for iso in m])
         for L in layers:
             L._members_ready()
@@ -1165,10 +1236,58 @@ class Atmosphere(list):
             if surfaceSpectrum is not None:
                 I_in = ctx.buffer(max(n, 1)).upload(np.ascontiguousarray(surfaceSpectrum, dtype=np.float64))
                 tmp.append(I_in)
-            elif surfaceTemperature is None:
-                raise ValueError("give surfaceSpectrum or surfaceTemperature")
             ctx.column_step_dev(desc, first.rangeMin, first.rangeMax, n, out, I_in=I_in,
                                 surface_T=float(surfaceTemperature or 0.0))
+            return out.download(n, pinned=True)
+        finally:
+            for b in tmp:
+                b.free()
+
+
+    def _transmission_merged(self, ctx, layers, n, surfaceSpectrum, surfaceTemperature):
+        """settings.LAYER_STEP "merged": every layer whose inputs changed gets ONE accumulate job over its merged,
+        factor-weighted line lists, all of them in one launch sequence (lbl_layers_merged_accumulate_dev: the layers'
+        absorption coefficients, cls:707-712), then one pass folds transmittance and emission bottom to top over those
+        arrays (lbl_column_fold_dev, cls:714-716, 784-787) and leaves every layer's transmittance resident for its own
+        getters.  None when a layer cannot take that route (no line list, or a measured cross-section table among its
+        molecules): the caller then goes through the per-line-list cross sections."""
+        if settings.LAYER_STEP != "merged":
+            return None
+        plan = []
+        for L in layers:
+            members, conc = L._sweep_members()
+            flat = [iso for isos in members for iso in isos]
+            if not flat or any(i.exotic for i in flat) or len(flat) > 48:
+                return None
+            g = L._grid()
+            _check_window(g)
+            st = L.__dict__.get("_sweep_state")
+            if st is None:
+                st = L.__dict__["_sweep_state"] = _SweepState(L)
+            st.reserve(ctx, n)
+            plan.append((L, st, g, members, flat, conc, L._merged_key(flat, conc, L, g)))
+        todo = [p for p in plan if p[1].key != p[6]]
+        ctx.layers_merged_accumulate_dev(
+            [dict(lines=[i._device_lines(ctx) for i in flat], iso=[_iso_params(i) for i in flat],
+                  grid=_engine.native_grid(g), iso_mol=[m for m, isos in enumerate(members) for _ in isos], conc=conc,
+                  abs_coef=st.buf(ctx, "abs_coef")) for (L, st, g, members, flat, conc, key) in todo])
+        tmp = []
+        try:
+            out = ctx.buffer(max(n, 1)); tmp.append(out)
+            I_in = None
+            if surfaceSpectrum is not None:
+                I_in = ctx.buffer(max(n, 1)).upload(np.ascontiguousarray(surfaceSpectrum, dtype=np.float64))
+                tmp.append(I_in)
+            stale = {id(p[0]) for p in todo}
+            first = layers[0]
+            ctx.column_fold_dev([p[1].bufs["abs_coef"] for p in plan], [p[0].T for p in plan], [p[0].depth for p in plan],
+                                first.rangeMin, first.rangeMax, n, out, I_in=I_in, surface_T=float(surfaceTemperature or 0.0),
+                                trans=[p[1].buf(ctx, "trans") if id(p[0]) in stale else None for p in plan])
+            for (L, st, g, members, flat, conc, key) in todo:
+                st.key = key
+                for iso in flat:
+                    iso._defer_cross_section()
+                L._members_ready()
             return out.download(n, pinned=True)
         finally:
             for b in tmp:

@@ -30,3 +30,20 @@ def set_accuracy(mode):
     from . import engine
     if engine._engine is not None and engine._engine.ctx.h is not None:
         engine._engine.ctx.set_option("accuracy", 1 if mode == "budget" else 0)
+
+
+LAYER_STEP = "merged"   # how a Layer's absorption coefficient / transmittance are computed when its line lists are due:
+                        # "merged": ONE accumulate job over the layer's merged, factor-weighted line lists, the absorption
+                        #   coefficient sum_m f_m sum_iso xs_iso (cls:707-712) accumulated directly (lbl_layer_merged_step_dev;
+                        #   Atmosphere.transmission: lbl_layers_merged_accumulate_dev + lbl_column_fold_dev).  Isotope / Molecule
+                        #   cross sections are then produced when somebody asks for them (the reference's own lazy protocol,
+                        #   progressCrossSection, cls:32-88);
+                        # "per-list": one job and one cross-section array per line list, then the sweep over them
+                        #   (lbl_layer_step_dev / lbl_column_step_dev)
+
+
+def set_layer_step(mode):
+    global LAYER_STEP
+    if mode not in ("merged", "per-list"):
+        raise ValueError("layer step must be 'merged' or 'per-list'")
+    LAYER_STEP = mode

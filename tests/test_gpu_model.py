@@ -392,3 +392,113 @@ def test_g11_plot_and_plot_spectrum_like_the_reference(pyrad):
             key = "plot.%s.y%d" % (kind, i)
             if key in z.files:
                 assert rel_err(got["y"][i], z[key]) <= (0.0 if kind == "line survey" else RTOL), key
+
+
+def test_merged_layer_step_is_lazy_about_cross_sections(pyrad):
+    """settings.LAYER_STEP "merged" (the default): getAbsCoef(layer) runs ONE accumulate job over the layer's merged,
+    factor-weighted line lists and writes no isotopologue cross section; the reference's protocol flags
+    (progressCrossSection, cls:32-88) read as if it had, and getCrossSection(isotope | molecule | layer) produces the
+    arrays on demand through the per-line-list path - bit for bit what a per-list layer computes - in either order,
+    also after mutators."""
+    from pyrad_amd import settings
+    z = load_golden("G6_composition")
+    src = dict(co2=unpack_lines(z, "co2.lines"), co2_636=unpack_lines(z, "co2_636.lines"),
+               h2o=unpack_lines(z, "h2o.lines"), ch4=unpack_lines(z, "ch4.lines"))
+    source(**src)
+
+    def build():
+        pyrad.Layer.hasAtmosphere = False
+        layer = pyrad.Layer(float(z["depth"]), int(z["T"]), float(z["P"]), 1000, 1040)
+        layer.addMolecule('co2', isotopeDepth=2, ppm=400)
+        layer.addMolecule('h2o', **{'%': 1.5})
+        layer.addMolecule(6, ppb=1800)
+        return layer
+
+    assert settings.LAYER_STEP == "merged"
+    settings.set_layer_step("per-list")
+    try:
+        ref = build()
+        k_ref = np.array(pyrad.getAbsCoef(ref))
+        xs_ref = [[np.array(pyrad.getCrossSection(iso)) for iso in m] for m in ref]
+        mol_ref = [np.array(pyrad.getCrossSection(m)) for m in ref]
+        ref.changeTemperature(250)
+        k_ref250 = np.array(pyrad.getAbsCoef(ref))
+        xs_ref250 = np.array(pyrad.getCrossSection(ref[0][1]))
+    finally:
+        settings.set_layer_step("merged")
+    assert rel_err(k_ref, z["abs_coef"]) <= RTOL
+
+    # layer first, cross sections afterwards
+    layer = build()
+    k = np.array(pyrad.getAbsCoef(layer))
+    assert rel_err(k, z["abs_coef"]) <= RTOL and rel_err(k, k_ref) <= 1e-13
+    assert all(m.progressCrossSection for m in layer)                       # as after the reference's Layer.absCoef
+    assert all(iso.progressCrossSection and iso._xs_deferred and not iso._dev_xsec_valid for m in layer for iso in m)
+    assert np.array_equal(pyrad.getCrossSection(layer[0][1]), xs_ref[0][1])      # made now, by the per-list path
+    assert not layer[0][1]._xs_deferred and layer[0][0]._xs_deferred
+    assert np.array_equal(pyrad.getAbsCoef(layer), k)                       # nothing changed: the merged arrays stand
+    for m, want, isos in zip(layer, mol_ref, xs_ref):
+        assert np.array_equal(pyrad.getCrossSection(m), want)
+        for iso, w in zip(m, isos):
+            assert np.array_equal(iso.crossSection, w)
+    assert rel_err(pyrad.getCrossSection(layer), z["co2.xsec"] + z["h2o.xsec"] + z["ch4.xsec"]) <= 1e-13
+    # every cross section is current now: the layer's chain may come from the sweep over them (per-list arithmetic)
+    assert np.array_equal(pyrad.getAbsCoef(layer), k_ref)
+    # per-molecule getters keep the per-list path
+    for m, name in zip(layer, ("co2", "h2o", "ch4")):
+        assert rel_err(pyrad.getAbsCoef(m), z[name + ".abs_coef"]) <= RTOL
+
+    # cross sections first, then a mutator, then the layer
+    layer = build()
+    assert np.array_equal(pyrad.getCrossSection(layer[0][1]), xs_ref[0][1])
+    layer.changeTemperature(250)
+    assert not layer[0][1].progressCrossSection
+    k250 = np.array(pyrad.getAbsCoef(layer))
+    assert rel_err(k250, k_ref250) <= 1e-13 and layer[0][1]._xs_deferred
+    assert np.array_equal(pyrad.getCrossSection(layer[0][1]), xs_ref250)
+    # a depth change redoes the transmittance from the resident absorption coefficient (no accumulate job)
+    t1 = np.array(pyrad.getTransmittance(layer))
+    layer.changeDepth(2.0 * layer.depth)
+    t2 = np.array(pyrad.getTransmittance(layer))
+    assert rel_err(t2, t1 ** 2, floor=1e-300) <= 1e-9 and np.array_equal(pyrad.getAbsCoef(layer), k250)
+
+
+def test_atmosphere_transmission_merged_equals_per_list(pyrad):
+    """Atmosphere.transmission through one merged accumulate job per layer + the fold over the absorption coefficients
+    against the per-line-list route; layers' own getters afterwards find their arrays resident."""
+    from pyrad_amd import settings
+    lines = dict(co2=synthetic.make_lines(51, 800, 580, 720), h2o=synthetic.make_lines(52, 500, 580, 720))
+    source(**lines)
+
+    def build():
+        pyrad.Layer.hasAtmosphere = False
+        atm = pyrad.Atmosphere("col")
+        for depth, T, P in ((1e4, 288, 1013.25), (2e4, 270, 700.0), (5e4, 240, 300.0), (1e5, 220, 80.0)):
+            L = atm.addLayer(depth, T, P, 600, 700)
+            L.addMolecule('co2', ppm=400)
+            L.addMolecule('h2o', percentage=0.5)
+        return atm
+
+    settings.set_layer_step("per-list")
+    try:
+        ref_atm = build()
+        ref = np.array(ref_atm.transmission(surfaceTemperature=288))
+        ref_k = [np.array(pyrad.getAbsCoef(L)) for L in ref_atm]
+    finally:
+        settings.set_layer_step("merged")
+    atm = build()
+    got = np.array(atm.transmission(surfaceTemperature=288))
+    assert rel_err(got, ref) <= 1e-12
+    for L, k in zip(atm, ref_k):
+        assert rel_err(pyrad.getAbsCoef(L), k) <= 1e-13
+        assert rel_err(pyrad.getTransmittance(L), np.exp(-k * L.depth), floor=1e-300) <= 1e-9
+    surf = atm[0].planck(300)
+    assert rel_err(atm.transmission(surfaceSpectrum=surf), ref_atm.transmission(surfaceSpectrum=surf)) <= 1e-12
+    atm[2].changeTemperature(250)                      # one layer due: only its job runs, the fold covers all
+    ref_atm[2].changeTemperature(250)
+    settings.set_layer_step("per-list")
+    try:
+        ref2 = np.array(ref_atm.transmission(surfaceTemperature=288))
+    finally:
+        settings.set_layer_step("merged")
+    assert rel_err(atm.transmission(surfaceTemperature=288), ref2) <= 1e-12

@@ -119,17 +119,31 @@ def test_whole_spectrum_cell_vs_c_oracle(ctx, workload, mode):
             xs_planck = orc.transmission(tr, orc.planckWavenumber(xa, 288), orc.planckWavenumber(xa, cfg["T"]))
             e = np.abs(r["transmission"] - xs_planck)
             assert np.all(e <= ((tol * k_ref * cfg["depth"] + 4e-16) * tr + 2e-15) * np.maximum(orc.planckWavenumber(xa, 288), xs_planck))
+            # the same cell through ONE merged accumulate job (lbl_layer_merged_step_dev): the absorption coefficient
+            # sum_m f_m sum_iso xs_iso accumulated directly, no cross-section array written (the outputs are poisoned first)
+            for b in (L.abs_coef, L.trans, L.I_out):
+                b.fill(float("nan"))
+            L.enqueue(surface_T=288, merged=True)
+            r = L.results()
+            worst("%s %s variant %d MERGED abs_coef" % (workload, mode, variant), r["abs_coef"], k_ref, tol)
+            e = np.abs(r["transmittance"] - tr)
+            assert np.all(e <= (tol * k_ref * cfg["depth"] + 4e-16) * tr + 1e-300)
+            e = np.abs(r["transmission"] - xs_planck)
+            assert np.all(e <= ((tol * k_ref * cfg["depth"] + 4e-16) * tr + 2e-15) * np.maximum(orc.planckWavenumber(xa, 288), xs_planck))
         finally:
             ctx.set_option("accum_variant", 5)
             ctx.set_option("accuracy", 0)
     L.free()
 
 
+@pytest.mark.parametrize("step", ["per-list", "merged"])
 @pytest.mark.parametrize("mode", ["exact", "budget"])
-def test_whole_spectrum_column_all_layers_and_toa_vs_c_oracle(ctx, mode):
+def test_whole_spectrum_column_all_layers_and_toa_vs_c_oracle(ctx, mode, step):
     """C5 at full size: the cross sections and the absorption coefficient of ALL 30 layers (windows from 5000 points
     down to 50: far-field kernel, the layers either side of the routing boundary at 640 points, skewed-range kernel)
     and the top-of-atmosphere radiance (the fold of pyradClasses.py:784-787 over the layers) at EVERY grid point.
+    step "merged": one accumulate job per LAYER over its merged, factor-weighted line lists and the fold over the 30
+    absorption coefficients (lbl_layers_merged_accumulate_dev + lbl_column_fold_dev); no cross section exists to compare.
     90 oracle jobs on a thread pool (ctypes releases the GIL).  The radiance is compared with an error bound
     propagated through the fold: an error tol k depth T of a layer's transmittance moves I by at most that times
     |I_in - B|, and T times what came in."""
@@ -142,7 +156,7 @@ def test_whole_spectrum_column_all_layers_and_toa_vs_c_oracle(ctx, mode):
     column = engine.ResidentColumn(ctx, cfgs, col["surface_T"])
     ctx.set_option("accuracy", MODES[mode][0])
     try:
-        column.enqueue(layer_arrays=True)
+        column.enqueue(layer_arrays=True, merged=(step == "merged"))
         ctx.sync()
     finally:
         ctx.set_option("accuracy", 0)
@@ -167,10 +181,12 @@ def test_whole_spectrum_column_all_layers_and_toa_vs_c_oracle(ctx, mode):
             assert Lr.evals == sum(r[2] for r in ref)
             k_ref = np.zeros(g["n_base"])
             for i, m in enumerate(c["molecules"]):
-                worst_all = max(worst_all, worst("C5 %s layer %d (W = %d) %s xsec" % (mode, li, g["W"], m["species"]),
-                                                 Lr.jobs[i][3].download(column.n), ref[i][0], tol))
+                if step != "merged":
+                    worst_all = max(worst_all, worst("C5 %s layer %d (W = %d) %s xsec" % (mode, li, g["W"], m["species"]),
+                                                     Lr.jobs[i][3].download(column.n), ref[i][0], tol))
                 k_ref = k_ref + orc.abs_coef(np.zeros(g["n_base"]) + ref[i][0], m["conc"], c["P"], c["T"])
-            worst_all = max(worst_all, worst("C5 %s layer %d abs_coef" % (mode, li), Lr.abs_coef.download(column.n), k_ref, tol))
+            worst_all = max(worst_all, worst("C5 %s %s layer %d (W = %d) abs_coef" % (mode, step, li, g["W"]),
+                                             Lr.abs_coef.download(column.n), k_ref, tol))
             tr = orc.transmittance(k_ref, c["depth"])
             B = orc.planckWavenumber(xa, c["T"])
             d_tr = (tol * k_ref * c["depth"] + 4e-16) * tr
@@ -184,7 +200,7 @@ def test_whole_spectrum_column_all_layers_and_toa_vs_c_oracle(ctx, mode):
     toa = column.results()["toa"]
     e = np.abs(toa - I_ref)
     i = int(np.argmax(e / I_bound))
-    print("C5 " + mode + " top-of-atmosphere radiance, every point: max rel err %.3e (point %d, bound there %.1e relative); "
+    print("C5 " + mode + " " + step + " top-of-atmosphere radiance, every point: max rel err %.3e (point %d, bound there %.1e relative); "
           "worst cross section / absorption coefficient of the 30 layers %.3e"
           % (float(np.max(e / I_ref)), i, float(I_bound[i] / I_ref[i]), worst_all))
     assert np.all(e <= I_bound), (float((e / I_bound).max()), i)
@@ -218,4 +234,7 @@ def test_whole_spectrum_windows_at_the_kernel_routing_boundary(ctx, W):
     for i, m in enumerate(mols):
         worst("W = %d (%s kernel) %s xsec" % (W, "skewed-range" if skew else "far-field", m["species"]), L.xsec_host(i), ref[i][0], tol)
     worst("W = %d abs_coef" % W, L.results()["abs_coef"], k_ref, tol)
+    L.abs_coef.fill(float("nan"))
+    L.enqueue(surface_T=288, merged=True)              # the same window through one merged accumulate job
+    worst("W = %d MERGED abs_coef" % W, L.results()["abs_coef"], k_ref, tol)
     L.free()
