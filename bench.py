@@ -449,7 +449,7 @@ class _Batch:
             b.free()
 
 
-def in_flight_leg(cfg, n_flight=3, steps=200, chained=False):
+def in_flight_leg(cfg, n_flight=3, steps=200, chained=False, merged=True):
     """Throughput of the same resident cell with n_flight independent steps in flight, each on a context (HIP
     stream) of its own, dealt round-robin: an extra leg for cells whose accumulate launch is a partial round
     of workgroups.  Same kernels, same results; not the line's `value`."""
@@ -464,7 +464,7 @@ def in_flight_leg(cfg, n_flight=3, steps=200, chained=False):
 
     def run(n):
         for k in range(n):
-            layers[k % n_flight].enqueue(surface_T=288.0)
+            layers[k % n_flight].enqueue(surface_T=288.0, merged=merged)
         for c in ctxs:
             c.sync()
     run(n_flight)
@@ -878,6 +878,39 @@ def main():
                               "2^-34; tests hold it to 1e-9 relative on the absorption coefficient at every grid point): %d steps between barriers, then %d steps with every "
                               "kernel class bracketed by events; not the line's value" % (n_bl, n_extra)}
 
+    # the per-line-list step (one job and one cross-section array per line list, then the sweep over them) on the same
+    # resident inputs, untimed legs like the budget leg's: the line's value is the merged step, this is what it replaced
+    per_list_leg = None
+    if merged and args.variant in (None, 5) and not args.no_direct_pass:
+        step_kwargs["merged"] = False
+        for _ in range(3):
+            step()
+        barrier()
+        n_pl = max(10, min(40, args.steps))
+        t_p0 = time.perf_counter()
+        for _ in range(n_pl):
+            step()
+        barrier()
+        t_pl = (time.perf_counter() - t_p0) / n_pl
+        ctx.profile_enable(["line_prep", "xsec_accumulate", "layer_sweep", "column_sweep"])
+        ctx.profile_reset()
+        for _ in range(n_extra):
+            step(timed_kernels=True)
+        barrier()
+        pp = ctx.profile_read()
+        ctx.profile_enable(False)
+        step_kwargs["merged"] = True
+        for _ in range(2):
+            step()
+        barrier()
+        per_list_leg = {"ms_per_step": t_pl * 1e3, "evals_per_s": float(layer.evals) / t_pl,
+                        "kernel_ms_per_step": {k_: pp[k_][1] / n_extra for k_ in ("line_prep", "xsec_accumulate", "layer_sweep", "column_sweep")},
+                        "xsec_accumulate_launches_per_step": pp["xsec_accumulate"][0] / n_extra,
+                        "what": "the same resident inputs through the per-line-list step (--step per-list: lbl_layer_step_dev / "
+                                "lbl_xsec_accumulate_dev + lbl_column_step_dev - one accumulate job and one cross-section array per line "
+                                "list, then the sweep kernel over them; the step of rounds 1-4): %d steps between barriers, then %d steps "
+                                "with every kernel class bracketed by events; same evals_per_step; not the line's value" % (n_pl, n_extra)}
+
     # With a communicator: where the sharded step's time goes, in two short untimed passes (every rank runs
     # them in lockstep): the kernels of a step without the all-gather, and the all-gather alone, in stream.
     # The pipelined step of the timed region cannot be faster than the longer of the two.
@@ -1048,6 +1081,8 @@ def main():
             n_sw, ms_sw = prof["column_sweep"]
             n_layers = len(layer.layers)
             balg_sw = 8.0 * pts * (n_arrays * n_layers + 1 + (2 * n_layers if args.column_layer_arrays else 0))
+            if merged:      # one absorption coefficient per layer read, the outgoing spectrum written (+ the layers' transmittances)
+                balg_sw = 8.0 * pts * (n_layers + 1 + (n_layers if args.column_layer_arrays else 0))
             sweep_kernel = "column_step_kernel"
         t_sw = (ms_sw / max(n_sw, 1)) * 1e-3
         # committed PMC passes: of the whole cell, or - for a rank of a G-way sharded run - of one shard of G
@@ -1064,6 +1099,15 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "grid_points_per_gpu": int(pts), "lines_per_gpu": int(layer.n_lines),
                        "window_W": int(g["W"]), "evals_per_step": evals_total, "parallelism": "grid-range x%d" % world,
+                       "step": ("merged: ONE accumulate job per layer over its merged, factor-weighted line lists - every line's amplitude "
+                                "times its molecule's conc P / 1E4 / k / T, all records of the layer in one centre-index-ordered array - so that "
+                                "the kernel accumulates the layer's absorption coefficient sum_m f_m sum_iso xs_iso (pyradClasses.py:707-712, "
+                                "581-583, 566-571) directly, with transmittance and radiance in its output stage (a column: the fold over the "
+                                "layers' absorption coefficients); every (line, grid point) contribution is evaluated (evals_per_step unchanged); "
+                                "no per-line-list cross-section array is written - lbl_xsec_accumulate_dev produces one on demand, as the "
+                                "reference's lazy getters do (cls:32-88); the per-list step is the per_list_leg"
+                                if merged else
+                                "per-list: one accumulate job and one cross-section array per line list, then the sweep over them"),
                        "accuracy": args.accuracy, "gathered": args.gather, "device": info["name"], "preconditioning_s": args.precondition_seconds,
                        "shard_bounds": (None if layer.plan is None else [list(b) for b in layer.plan.bounds]),
                        "shards": shard_choice,
@@ -1096,12 +1140,14 @@ def main():
                          "sweep_fused_in": bool(fused_sweep),
                          "launches_overlap": n_flight > 1,
                          "note": "compulsory traffic only (56 B/line + 8 B/grid point per array written: one cross section "
-                                 "per line list, + k, transmittance and radiance when the layer sweep is fused in). This "
+                                 "per line list - none in the merged step, one absorption coefficient per layer in a merged column - "
+                                 "+ k, transmittance and radiance when the layer sweep is fused in). This "
                                  "kernel is fp64-VALU bound by construction (SURVEY.md §8d): valu_f64.busy_frac is its "
                                  "real utilisation figure"},
             "valu_f64": valu_block(evals_local, t_acc_step, direct_ms, args.variant, pmc, launches_per_step,
                                    n_flight, elapsed_max / args.steps),
-            "roofline_sweep": {"fused_into": "xsec_accumulate_lds_kernel (lbl_layer_step_dev)"} if n_sw == 0 and not is_column else
+            "roofline_sweep": {"fused_into": "xsec_accumulate_lds_kernel (%s)" % ("lbl_layer_merged_step_dev" if merged else "lbl_layer_step_dev")}
+                              if n_sw == 0 and not is_column else
                               {"bound": "hbm", "kernel": sweep_kernel,
                                "achieved": balg_sw / t_sw / 1e9 if t_sw > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": (balg_sw / t_sw / 1e9 / HBM_PEAK_GBS) if t_sw > 0 else 0.0,
@@ -1134,6 +1180,8 @@ def main():
             result["direct_frac"] = vb.get("direct_frac")
         if budget_leg is not None:
             result["budget_leg"] = budget_leg
+        if per_list_leg is not None:
+            result["per_list_leg"] = per_list_leg
         if ablated:
             result["ablated"] = True
             result["invalid"] = "a debug_* option was set: parts of the kernels are switched off, results are wrong, timing experiment only"
@@ -1165,9 +1213,9 @@ def main():
     elif want_api:
         result["api_path"] = api_path(cfg)
         if small_cell and n_flight == 1:
-            result["in_flight_leg"] = in_flight_leg(cfg)
+            result["in_flight_leg"] = in_flight_leg(cfg, merged=merged)
         elif n_flight == 1:
-            result["in_flight_leg"] = in_flight_leg(cfg, n_flight=2, steps=60)     # so that ratios can be formed in either mode
+            result["in_flight_leg"] = in_flight_leg(cfg, n_flight=2, steps=60, merged=merged)     # so that ratios can be formed in either mode
     if rank == 0:
         print(json.dumps(result))
 

@@ -107,12 +107,14 @@ int lbl_ctx_chain_accumulate(lbl_ctx* ctx, lbl_ctx* predecessor);
 int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 
 /* Tuning knobs for A/B parity runs and benchmarking (no reference counterpart):
- *   "accum_variant"          0 IEEE divide + exp per pair | 1 running fraction | 2 + Gaussian recurrence
- *                            (0-2 fetch line records through the scalar cache) |
- *                            3 = 2 with wave-private LDS staging of the records (every pair direct) |
- *                            4 = 3 with a balanced single-round partition of (span, line) pairs |
+ *   "accum_variant"          0 the literal form: IEEE divide + exp per (line, grid point) pair, line records through
+ *                            the scalar cache (slow; the on-device cross-check of the others) |
+ *                            3 running fraction + Gaussian recurrence with wave-private LDS staging of the
+ *                            records, every pair evaluated directly |
  *                            5 (default) = 3 with the fp64-exact far-field series for Lorentz lines
- *                            more than 4 half-spans away from a span of 64*R points
+ *                            more than 4 half-spans away from a span of 64*R points.
+ *                            (1, 2 and 4 - superseded comparison kernels - exist in diagnostic builds of the
+ *                            library only, make EXTRA=-DLBL_DIAG; the production library answers LBL_ERR_BAD_ARG)
  *   "accum_points_per_lane"  0 (auto) | 1 | 2 | 4 | 8
  *   "accum_line_split"       0 (auto) | 1 | 2 | 4 | 8 waves of a workgroup share one span of points
  *                            and split its lines (variants 3 and 5)
@@ -127,7 +129,7 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *                            100-2500 cm^-1 cell at the same kernel time
  *   "accum_tile_order"       positional order only: 1 (default) natural | 0 one contiguous run of
  *                            tiles per XCD | 2 golden-ratio stride
- *   "accum_blocks_per_cu"    variant 4 only: resident workgroups per CU, 0 = ask the runtime
+ *   "accum_blocks_per_cu"    variant 4 (diagnostic builds) only: resident workgroups per CU, 0 = ask the runtime
  *   "accum_skew"             1 (default) line lists whose window has no far line (narrower than 640 points) go
  *                            through the skewed-range kernel when they fill the chip | 0 the span kernel
  *                            (all-direct instantiation) | 2 EVERY job through the skewed-range kernel (parity tests)

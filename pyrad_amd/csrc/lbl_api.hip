@@ -60,7 +60,7 @@ struct lbl_ctx {
     std::vector<char> desc_build;
     int last_jobs = 0;
     int last_blocks_per_job = 0;
-    std::vector<int> last_job_lines;
+    std::vector<int> last_list_blocks;   // blocks of 256 (lines, or merged positions of its job) each list of the last batch was counted in
     // tuning knobs (lbl_set_option)
     int accum_variant = 5;   // 0: IEEE divide + exp per pair; 1: running fraction; 2: + Gaussian recurrence
                              // (0-2 fetch records through the scalar cache); 3: 2 with wave-private LDS
@@ -82,10 +82,11 @@ struct lbl_ctx {
         long long far_reach = 0;
         double cost_near = 0, cost_edge = 0, cost_far = 0, cost_fixed = 0;
         std::vector<int32_t> span_first, tile_first;
-        // merged layer jobs (several line lists in one record array): the merged position of every line, built on the
-        // device by the first batch that uses the schedule (launch_merge_ranks), ahead of its line prep
-        int32_t* d_dest = nullptr;
-        std::vector<size_t> dest_off;         // per job of the group: first entry of its lists' positions in d_dest (SIZE_MAX: one list, no merge)
+        // merged layer jobs (several line lists in one record array): which line of which list belongs at every merged
+        // position (the inverse of the stable merge of the lists' centre indices), built on the device by the first batch
+        // that uses the schedule (launch_merge_ranks), ahead of its line prep, which runs in that order
+        int32_t* d_src = nullptr;
+        std::vector<size_t> src_off;         // per job of the group: first entry of its lists' positions in d_src (SIZE_MAX: one list, no merge)
         bool merge_pending = false;
     };
     std::vector<std::unique_ptr<Schedule>> schedules;
@@ -493,7 +494,12 @@ extern "C" int lbl_set_option(lbl_ctx* ctx, const char* key, int value) try {
 
 static int set_option_value(lbl_ctx* ctx, const char* key, int value) {
     if (!strcmp(key, "accum_variant")) {
+#ifdef LBL_DIAG
         if (value < 0 || value > 5) return fail(ctx, LBL_ERR_BAD_ARG, "accum_variant must be 0..5");
+#else
+        if (!(value == 0 || value == 3 || value == 5))
+            return fail(ctx, LBL_ERR_BAD_ARG, "accum_variant must be 0, 3 or 5 (1, 2 and 4 are superseded comparison kernels: diagnostic builds only)");
+#endif
         ctx->accum_variant = value;
     } else if (!strcmp(key, "accum_points_per_lane")) {
         if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8))
@@ -873,15 +879,15 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
             ctx->schedules.erase(ctx->schedules.begin());
         }
     };
-    auto one_block = [&](size_t n_items, size_t n_tab_ints, int2** d_list, int32_t** d_tabs, size_t n_dest = 0,
-                         int32_t** d_dest = nullptr) -> void* {
+    auto one_block = [&](size_t n_items, size_t n_tab_ints, int2** d_list, int32_t** d_tabs, size_t n_src = 0,
+                         int32_t** d_src = nullptr) -> void* {
         const size_t list_bytes = (std::max<size_t>(n_items, 1) * sizeof(int2) + 255) & ~(size_t)255;
         const size_t tab_bytes = (std::max<size_t>(n_tab_ints, 8) * sizeof(int32_t) + 255) & ~(size_t)255;
         void* blk = nullptr;
-        if (hipMalloc(&blk, list_bytes + tab_bytes + n_dest * sizeof(int32_t)) != hipSuccess) return nullptr;
+        if (hipMalloc(&blk, list_bytes + tab_bytes + n_src * sizeof(int32_t)) != hipSuccess) return nullptr;
         *d_list = (int2*)blk;
         *d_tabs = (int32_t*)((char*)blk + list_bytes);
-        if (d_dest) *d_dest = n_dest ? (int32_t*)((char*)blk + list_bytes + tab_bytes) : nullptr;
+        if (d_src) *d_src = n_src ? (int32_t*)((char*)blk + list_bytes + tab_bytes) : nullptr;
         return blk;
     };
     {
@@ -913,17 +919,17 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
                 tile_run += (int32_t)((sc + tile_pts - 1) / tile_pts);
             }
             S->total_spans = span_run; S->total = tile_run;
-            size_t n_dest = 0;
+            size_t n_src = 0;
             for (int j : jobs_in_group) {
                 size_t n = 0;
                 for (int l = l0(j); l < l1(j); ++l) n += (size_t)lines[l]->n;
-                S->dest_off.push_back(l1(j) - l0(j) > 1 ? n_dest : SIZE_MAX);
-                if (l1(j) - l0(j) > 1) n_dest += n;
+                S->src_off.push_back(l1(j) - l0(j) > 1 ? n_src : SIZE_MAX);
+                if (l1(j) - l0(j) > 1) n_src += n;
             }
-            S->d_block = one_block((size_t)tile_run, (size_t)span_run * 8, &S->d_list, &S->d_tabs, n_dest, &S->d_dest);
+            S->d_block = one_block((size_t)tile_run, (size_t)span_run * 8, &S->d_list, &S->d_tabs, n_src, &S->d_src);
             if (!S->d_block) return nullptr;
             S->pending = true;
-            S->merge_pending = n_dest > 0;
+            S->merge_pending = n_src > 0;
             evict_oldest();
             ctx->schedules.push_back(std::move(S));
             return ctx->schedules.back().get();
@@ -1116,6 +1122,11 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             max_lines = std::max<int>(max_lines, (int)lines[l]->n);
         }
         if (job_lines[j] > 2000000000ull) return fail(ctx, LBL_ERR_BAD_ARG, "job %d: too many lines for int32 indexing", j);
+        if (l1(j) - l0(j) > 1) {                 // merged-order map: list within the job in 6 bits, line within the list in 26
+            if (l1(j) - l0(j) > 64) return fail(ctx, LBL_ERR_BAD_ARG, "job %d: at most 64 line lists per merged job", j);
+            for (int l = l0(j); l < l1(j); ++l)
+                if (lines[l]->n >= (1LL << 26)) return fail(ctx, LBL_ERR_BAD_ARG, "line list %d: at most 2^26 - 1 lines per list of a merged job", l);
+        }
         work_off[j] = tot_work;
         if (needs_regrid(grid[j])) tot_work += (size_t)grid[j].n_work;
         min_H = std::min<long long>(min_H, std::max<long long>(grid[j].window - 2, 0));
@@ -1126,8 +1137,14 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     if ((rc = arena_reserve(ctx, ctx->cidx, std::max<size_t>(tot_lines, 1) * sizeof(int32_t)))) return rc;
     if ((rc = arena_reserve(ctx, ctx->work, std::max<size_t>(tot_work, 1) * sizeof(double)))) return rc;
     // per-block regime counts (3 x u32 per block of 256 lines), summed on the host on demand
-    const int blocks_per_job = (max_lines + 255) / 256;
-    const size_t prep_bytes = (size_t)n_lists * sizeof(PrepJob), acc_bytes = (size_t)n_jobs * sizeof(AccumJob);
+    // (a list of a merged job is counted per block of 256 MERGED positions of its job)
+    int n_merged_jobs = 0;
+    size_t max_job_lines = 0;
+    for (int j = 0; j < n_jobs; ++j)
+        if (l1(j) - l0(j) > 1) { ++n_merged_jobs; max_job_lines = std::max(max_job_lines, job_lines[j]); }
+    const int blocks_per_job = (int)((std::max<size_t>((size_t)max_lines, max_job_lines) + 255) / 256);
+    const size_t prep_bytes = (((size_t)n_lists * sizeof(PrepJob) + (size_t)n_merged_jobs * sizeof(MergedPrep)) + 15) & ~(size_t)15;
+    const size_t acc_bytes = (size_t)n_jobs * sizeof(AccumJob);
     const size_t cnt_bytes = (size_t)n_lists * std::max(blocks_per_job, 1) * 3 * sizeof(unsigned int);
     if ((rc = arena_reserve(ctx, ctx->counts, cnt_bytes))) return rc;
     // descriptors are built in pageable host memory first: a batch that repeats (the usual case:
@@ -1210,28 +1227,40 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         groups.push_back(g);
         k = e;
     }
-    // where the group's schedule keeps the merged positions of job order[k]'s lines (NULL: a job of one list)
-    std::vector<const int32_t*> job_dest(n_jobs, nullptr);
+    // where the group's schedule keeps the merged-order map of job order[k] (NULL: a job of one list)
+    std::vector<const int32_t*> job_src(n_jobs, nullptr);
     for (const Group& g : groups)
         for (int k = g.first; k < g.first + g.count; ++k)
-            if (g.sched && g.sched->d_dest && g.sched->dest_off[(size_t)(k - g.first)] != SIZE_MAX)
-                job_dest[order[k]] = g.sched->d_dest + g.sched->dest_off[(size_t)(k - g.first)];
+            if (g.sched && g.sched->d_src && g.sched->src_off[(size_t)(k - g.first)] != SIZE_MAX)
+                job_src[order[k]] = g.sched->d_src + g.sched->src_off[(size_t)(k - g.first)];
     PrepJob* hp = (PrepJob*)stage;
+    MergedPrep* hm = (MergedPrep*)((char*)stage + (size_t)n_lists * sizeof(PrepJob));
     AccumJob* ha = (AccumJob*)((char*)stage + prep_bytes);
+    ctx->last_list_blocks.assign(n_lists, 0);
+    int mj = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const size_t base = line_off[l0(j)];                          // the job's record array
+        if (job_src[j]) {
+            MergedPrep& m = hm[mj++];
+            memset(&m, 0, sizeof m);
+            m.src = job_src[j];
+            m.hot = (HotRec*)ctx->recs.ptr + base; m.cold = (ColdRec*)ctx->cold.ptr + base; m.cidx = (int32_t*)ctx->cidx.ptr + base;
+            m.first_list = l0(j); m.n_lists = l1(j) - l0(j);
+            m.n_total = (int32_t)job_lines[j]; m.blocks = (int32_t)((job_lines[j] + 255) / 256);
+        }
         for (int l = l0(j); l < l1(j); ++l) {
+            ctx->last_list_blocks[l] = job_src[j] ? (int)((job_lines[j] + 255) / 256) : (int)((lines[l]->n + 255) / 256);
             const lbl_lines* L = lines[l];
             PrepJob& p = hp[l];
             memset(&p, 0, sizeof p);
             p.nu = L->field(0); p.sw = L->field(1); p.elower = L->field(2); p.gamma_air = L->field(3);
             p.gamma_self = L->field(4); p.n_air = L->field(5); p.delta_air = L->field(6);
-            const bool scattered = job_dest[j] != nullptr;            // several lists: every record goes to its merged position
+            const bool scattered = job_src[j] != nullptr;            // several lists: prepared in merged order into the job's arrays
             const size_t off = scattered ? base : line_off[l];
             p.hot = (HotRec*)ctx->recs.ptr + off;
             p.cold = (ColdRec*)ctx->cold.ptr + off;
             p.cidx = (int32_t*)ctx->cidx.ptr + off;
-            p.dest = scattered ? job_dest[j] + (line_off[l] - base) : nullptr;
+            p.merged = scattered ? 1 : 0;
             p.weight = merge ? merge->weight[l] : 1.0;
             p.block_counts = d_counts + (size_t)l * blocks_per_job * 3;
             p.T = iso[l].T; p.P = iso[l].P; p.q_frac = iso[l].q_frac; p.molmass = iso[l].molmass;
@@ -1327,11 +1356,9 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     PrepJob* dp = (PrepJob*)d_desc;
     AccumJob* da = (AccumJob*)(d_desc + prep_bytes);
     ctx->last_blocks_per_job = blocks_per_job;
-    ctx->last_job_lines.assign(n_lists, 0);
-    for (int l = 0; l < n_lists; ++l) ctx->last_job_lines[l] = (int)lines[l]->n;
-    // Merged layer jobs whose schedule is new: the merged position of every line, ahead of the line prep that scatters its
-    // records through them - each list's centre indices (K1's expression) into scratch, then one rank search per line and
-    // other list of its job.  Once per (line lists, grid); kept in the schedule's block.
+    // Merged layer jobs whose schedule is new: the merged-order map, ahead of the line prep that runs in that order - each
+    // list's centre indices (K1's expression) into scratch, then one rank search per line and other list of its job.
+    // Once per (line lists, grid); kept in the schedule's block.
     for (Group& g : groups) {
         lbl_ctx::Schedule* sc = g.sched;
         if (!sc || !sc->merge_pending) continue;
@@ -1342,14 +1369,14 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         int ml_max = 0;
         for (int k = g.first; k < g.first + g.count; ++k) {
             const int j = order[k];
-            if (!job_dest[j]) continue;
+            if (!job_src[j]) continue;
             const int jf = (int)ml.size();
             for (int l = l0(j); l < l1(j); ++l) {
                 MergeList m;
                 memset(&m, 0, sizeof m);
                 m.nu = lines[l]->field(0);
                 tmp_off.push_back(tmp_lines);                             // (tmp_cidx is set once the scratch exists)
-                m.dest = const_cast<int32_t*>(job_dest[j]) + (line_off[l] - line_off[l0(j)]);
+                m.src_of_job = const_cast<int32_t*>(job_src[j]);
                 m.range_min = grid[j].range_min; m.resolution = grid[j].resolution;
                 m.n_lines = (int32_t)lines[l]->n;
                 m.job_first = jf; m.job_count = l1(j) - l0(j);
@@ -1371,7 +1398,9 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         sc->merge_pending = false;
     }
     hipEvent_t ev = prof_begin(ctx, PROF_PREP);
-    launch_line_prep(dp, n_lists, max_lines, ctx->stream);
+    if (n_merged_jobs < n_jobs) launch_line_prep(dp, n_lists, max_lines, ctx->stream);      // (lists of merged jobs return at once)
+    if (n_merged_jobs > 0)
+        launch_line_prep_merged(dp, (const MergedPrep*)(d_desc + (size_t)n_lists * sizeof(PrepJob)), n_merged_jobs, (int)max_job_lines, ctx->stream);
     prof_end(ctx, PROF_PREP, ev);
     HIP_TRY(ctx, hipGetLastError());
     ctx->last_jobs = n_lists;
@@ -1489,7 +1518,7 @@ extern "C" int lbl_last_regime_counts(lbl_ctx* ctx, int n_jobs, int64_t* counts)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int j = 0; j < n_jobs; ++j) {
         int64_t c[3] = {0, 0, 0};
-        const int nb = (ctx->last_job_lines[j] + 255) / 256;        // blocks past the job's lines never ran
+        const int nb = ctx->last_list_blocks[j];                    // blocks past the list's (or its merged job's) lines never ran
         for (int b = 0; b < nb; ++b)
             for (int k = 0; k < 3; ++k) c[k] += host[((size_t)j * bpj + b) * 3 + k];
         counts[3 * j] = c[0]; counts[3 * j + 1] = c[1]; counts[3 * j + 2] = c[2];

@@ -118,22 +118,34 @@ struct PrepJob {
     int32_t n_lines;
     int32_t pad;
     // Merged layer job (lbl_layer_merged_step_dev, lbl_layers_merged_accumulate_dev): the records of ALL line lists of a layer go
-    // into ONE array in centre-index order (hot / cold / cidx then point at the layer's array, and line i of this list is
-    // written at dest[i]), each list's amplitudes KL, KG pre-multiplied by weight = conc P / 1E4 / k / T of its molecule
-    // (pyradClasses.py:583) over a power of two common to the layer, so that the accumulate kernel's sum is the layer's
-    // absorption coefficient sum_m f_m sum_iso xs_iso (pyradClasses.py:707-712, 566-571) up to that exact factor.
-    // dest == NULL: the list's own array, record i at i; weight 1.0 leaves every bit as it was (x * 1.0).
-    const int32_t* dest;
+    // into ONE array in centre-index order, each list's amplitudes KL, KG pre-multiplied by weight = conc P / 1E4 / k / T of
+    // its molecule (pyradClasses.py:583) over a power of two common to the layer, so that the accumulate kernel's sum is the
+    // layer's absorption coefficient sum_m f_m sum_iso xs_iso (pyradClasses.py:707-712, 566-571) up to that exact factor.
+    // merged != 0: the list belongs to a job of several lists and is prepared by that job's merged-order launch
+    // (line_prep_merged_kernel), which only reads this block's constants and field pointers; weight 1.0 leaves every bit as
+    // it was (x * 1.0).
+    int32_t merged;
+    int32_t pad2;
     double weight;
 };
 
+// K1 in merged order: one per accumulate job of several line lists
+struct MergedPrep {
+    const int32_t* src;        // merged position -> (list within the job << 26) | line within the list
+    HotRec* hot; ColdRec* cold; int32_t* cidx;       // the job's record arrays
+    int32_t first_list, n_lists;                     // the job's lists in the PrepJob array
+    int32_t n_total, blocks;                         // lines of all its lists; ceil(n_total / 256)
+};
+void launch_line_prep_merged(const PrepJob* d_lists, const MergedPrep* d_jobs, int n_jobs, int max_total, hipStream_t s);
+
 // Merge of a layer's sorted centre-index lists (once per window, beside the schedule build): list `a` of a job holds lines
 // whose centre indices (tmp_cidx, written by centre_index_kernel with K1's own expression) are non-decreasing; line i of it
-// goes to  i + sum_{b < a} #{c_b <= c} + sum_{b > a} #{c_b < c}  - the stable merge, ties by list order.
+// goes to  i + sum_{b < a} #{c_b <= c} + sum_{b > a} #{c_b < c}  - the stable merge, ties by list order - and what is kept is
+// the inverse map of the job: src_of_job[position] = (list within the job << 26) | line.
 struct MergeList {
     const double* nu;
     int32_t* tmp_cidx;     // this list's centre indices (scratch)
-    int32_t* dest;         // out: merged position of every line (kept with the schedule)
+    int32_t* src_of_job;   // out: the job's inverse map (kept with the schedule); the same pointer in all lists of a job
     double range_min, resolution;
     int32_t n_lines;
     int32_t job_first, job_count;     // the lists [job_first, job_first + job_count) of the MergeList array form this list's job

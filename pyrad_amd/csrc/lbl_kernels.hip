@@ -19,10 +19,11 @@
 // with a plain coalesced store.  No atomics, and a fixed summation order per grid point, so two
 // runs are bit-identical.
 //
-// K2 variants (lbl_set_option "accum_variant"):
-//   0-2  xsec_accumulate_kernel      line records through the scalar cache (the first version)
+// K2 variants (lbl_set_option "accum_variant"; 1, 2 and 4 exist in diagnostic builds only, -DLBL_DIAG):
+//   0    xsec_accumulate_kernel      the literal form: IEEE divide + exp per pair, records through the scalar cache (on-device cross-check)
+//   1-2  xsec_accumulate_kernel      running fraction / + Gaussian recurrence through the scalar cache (superseded)
 //   3    xsec_accumulate_lds_kernel  records streamed through wave-private LDS, every pair direct
-//   4    ..._balanced_kernel         3 with an exactly balanced partition of (span, line) pairs
+//   4    ..._balanced_kernel         3 with an exactly balanced partition of (span, line) pairs (superseded)
 //   5    xsec_accumulate_lds_kernel<.., FF = true>  (default) 3 + far-field series for distant
 //        Lorentz lines; optionally the layer sweep of a single-line-list layer in the output stage;
 //        round 3: its edge lines (support ends inside the span) take the skewed walk (skew_edges), and
@@ -224,99 +225,106 @@ __device__ __forceinline__ int line_regime(double ratio) {          // pyradClas
     return ratio < .01 ? 0 : (ratio > 100.0 ? 1 : 2);
 }
 
+// One line's records (hot, cold), centre index and regime from its list's job constants: shared by the per-list K1 and
+// the merged-order K1 below.
+__device__ __forceinline__ void prep_one_line(const PrepJob& J, int i, HotRec& r, ColdRec& rc, long long& idx, int& regime) {
+    const LinePhysics L = line_physics(J, i);
+    // (merged layer job: the molecule's conc P / 1E4 / k / T over a power of two rides on the intensity; 1.0 otherwise: exact)
+    const double lhw = L.lhw, ghw = L.ghw, ratio = L.ratio, A = L.A * J.weight;
+    idx = (long long)L.fidx;
+    if (idx > 2000000000LL) idx = 2000000000LL;
+    if (idx < -2000000000LL) idx = -2000000000LL;
+
+    double hw, KL, KG;
+    if (ratio < .01) {                // Gaussian only (pyradClasses.py:379-381)
+        regime = 0;
+        hw = ghw;
+        KL = 0.0;
+        KG = A / hw * kInvSqrtPi;                                     // pyradLineshape.py:39 (/ sqrt(pi) as a product)
+    } else if (ratio > 100.0) {       // Lorentz only (pyradClasses.py:382-384)
+        regime = 1;
+        hw = lhw;
+        KL = A * (hw * kInvPi);                                       // pyradLineshape.py:52 (/ pi as a product)
+        KG = 0.0;
+    } else {                          // pseudo-Voigt (pyradClasses.py:385-387, pyradLineshape.py:58-76)
+        regime = 2;
+        const double g = 2.0 * ghw, l = 2.0 * lhw;
+        const double g2 = g * g, l2 = l * l;
+        const double f5 = g2 * g2 * g + 2.69269 * g2 * g2 * l + 2.42843 * g2 * g * l2 +
+                          4.47163 * g2 * l2 * l + .07842 * g * l2 * l2 + l2 * l2 * l;
+        const double f = exp(.2 * log(f5));                                 // f5 ** .2
+        const double x = l / f;
+        const double eta = 1.36603 * x - .47719 * x * x + .11116 * x * x * x;
+        hw = f / 2.0;
+        KL = eta * (A * (hw * kInvPi));
+        KG = (1.0 - eta) * (A / hw * kInvSqrtPi);
+    }
+    const double a = hw * J.inv_res;
+    r.cf = (double)idx;
+    r.a2 = a * a;
+    r.KL = KL * J.inv_res2;
+    rc.KG = KG;
+    rc.b = 1.0 / r.a2;
+    r.flags = 0;
+    // running-fraction accumulation multiplies up to 32 denominators d*d + a2 with
+    // |d| <= H + 512 <= 4e4 (else 16, see AccumJob.flush_every): keep a2 in [1e-9, 1e8] so
+    // the product stays within 1e-288 .. 1e296; anything else takes the plain-divide path
+    if (!(r.a2 > 1e-9 && r.a2 < 1e8)) r.flags |= REC_DIRECT_DIV;
+    // Gaussian term: where can it still change the fp64 value of the line's sum?
+    double dg = 0.0;
+    if (KG != 0.0) {
+        const double u2_under = 745.2;           // exp(-745.2) == 0 in fp64
+        double u2 = u2_under;
+        if (KL != 0.0) {
+            // ratio Gauss/Lorentz at offset u = d/a:  C (1+u^2) exp(-u^2);  solve = 2^-54 (budget mode: 2^-34) for u^2 = v + 1,
+            // v = ln C + ln(1 + v).  The cut-off only has to err on the far side, so single precision
+            // with a margin does: ln C from the exponent and a hardware log2 of the mantissa, three
+            // fixed-point steps (each contracts by 1/(1+v)), +0.01 for the float roundings and the
+            // remaining contraction (4 double-precision logs were a fifth of this kernel's instructions).
+            const double C = fabs(KG / (r.KL * rc.b)) * J.gauss_cut;        // 2^54 (exact mode) or 2^34 (budget mode)
+            if (C <= 1.0) {
+                u2 = 0.0;
+            } else {
+                int ex;
+                const float mant = (float)frexp(C, &ex);                               // C = mant 2^ex, mant in [0.5, 1)
+                const float lnC = ((float)ex + __log2f(mant)) * 0.69314718f;
+                float v = lnC;
+                for (int it = 0; it < 3; ++it) v = lnC + __log2f(1.0f + v) * 0.69314718f;
+                u2 = fmin((double)(v * 1.00001f + 1.01f), u2_under);
+            }
+        }
+        dg = (u2 > 0.0) ? (double)(__fsqrt_rn((float)u2) * 1.000001f) * a + 2.0 : 0.0;
+    }
+    r.dgi = (dg < 2.0e9) ? (int32_t)dg : 2000000000;
+    // Gaussian recurrence along a lane's consecutive points: only for b <= 4 (see gauss_term);
+    // narrower profiles take one exp per point
+    rc.q2 = (rc.b <= 4.0) ? exp(-2.0 * rc.b) : -1.0;
+    if (!(rc.b <= 4.0)) r.flags |= REC_NO_RECUR;
+    // 16-point runs (gauss_runs16): a lane walks 15 steps from its first point, possibly TOWARDS the centre.
+    // If its seed KG exp(-b d0^2) has underflowed (b d0^2 > T, T = 745 - ln(1/KG) >= ~600 for any KG down
+    // to 1e-60) the run's values stay 0; that is harmless as long as no point of the run can matter: the
+    // nearest one has b d^2 > b (sqrt(T/b) - 15)^2, which exceeds the 45 beyond which the term is below
+    // 2^-54 of the line's Lorentz part whenever sqrt(b) < (sqrt(600) - sqrt(45)) / 15 = 1.19.  b <= 1
+    // (profiles at least one grid point wide) keeps a margin.  (Seeds that are tiny but normal keep the
+    // recurrence exact; a clamped r only lowers a value that is negligible anyway.)  Pure-Gaussian lines
+    // (no Lorentz part to be negligible against: their term counts until it underflows) keep the 4-point pass.
+    if (rc.b <= 1.0 && KL != 0.0) r.flags |= REC_LONG_RUN;
+    rc.KLd = r.KL;
+}
+
 __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restrict__ jobs) {
     const PrepJob& J = jobs[blockIdx.y];
+    if (J.merged) return;                       // (its job's merged-order launch prepares this list)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int regime = -1;
     if (i < J.n_lines) {
-        const LinePhysics L = line_physics(J, i);
-        // (merged layer job: the molecule's conc P / 1E4 / k / T over a power of two rides on the intensity; 1.0 otherwise: exact)
-        const double lhw = L.lhw, ghw = L.ghw, ratio = L.ratio, A = L.A * J.weight;
-        long long idx = (long long)L.fidx;
-        if (idx > 2000000000LL) idx = 2000000000LL;
-        if (idx < -2000000000LL) idx = -2000000000LL;
-
-        double hw, KL, KG;
-        if (ratio < .01) {                // Gaussian only (pyradClasses.py:379-381)
-            regime = 0;
-            hw = ghw;
-            KL = 0.0;
-            KG = A / hw * kInvSqrtPi;                                     // pyradLineshape.py:39 (/ sqrt(pi) as a product)
-        } else if (ratio > 100.0) {       // Lorentz only (pyradClasses.py:382-384)
-            regime = 1;
-            hw = lhw;
-            KL = A * (hw * kInvPi);                                       // pyradLineshape.py:52 (/ pi as a product)
-            KG = 0.0;
-        } else {                          // pseudo-Voigt (pyradClasses.py:385-387, pyradLineshape.py:58-76)
-            regime = 2;
-            const double g = 2.0 * ghw, l = 2.0 * lhw;
-            const double g2 = g * g, l2 = l * l;
-            const double f5 = g2 * g2 * g + 2.69269 * g2 * g2 * l + 2.42843 * g2 * g * l2 +
-                              4.47163 * g2 * l2 * l + .07842 * g * l2 * l2 + l2 * l2 * l;
-            const double f = exp(.2 * log(f5));                                 // f5 ** .2
-            const double x = l / f;
-            const double eta = 1.36603 * x - .47719 * x * x + .11116 * x * x * x;
-            hw = f / 2.0;
-            KL = eta * (A * (hw * kInvPi));
-            KG = (1.0 - eta) * (A / hw * kInvSqrtPi);
-        }
-        const double a = hw * J.inv_res;
         HotRec r;
         ColdRec rc;
-        r.cf = (double)idx;
-        r.a2 = a * a;
-        r.KL = KL * J.inv_res2;
-        rc.KG = KG;
-        rc.b = 1.0 / r.a2;
-        r.flags = 0;
-        // running-fraction accumulation multiplies up to 32 denominators d*d + a2 with
-        // |d| <= H + 512 <= 4e4 (else 16, see AccumJob.flush_every): keep a2 in [1e-9, 1e8] so
-        // the product stays within 1e-288 .. 1e296; anything else takes the plain-divide path
-        if (!(r.a2 > 1e-9 && r.a2 < 1e8)) r.flags |= REC_DIRECT_DIV;
-        // Gaussian term: where can it still change the fp64 value of the line's sum?
-        double dg = 0.0;
-        if (KG != 0.0) {
-            const double u2_under = 745.2;           // exp(-745.2) == 0 in fp64
-            double u2 = u2_under;
-            if (KL != 0.0) {
-                // ratio Gauss/Lorentz at offset u = d/a:  C (1+u^2) exp(-u^2);  solve = 2^-54 (budget mode: 2^-34) for u^2 = v + 1,
-                // v = ln C + ln(1 + v).  The cut-off only has to err on the far side, so single precision
-                // with a margin does: ln C from the exponent and a hardware log2 of the mantissa, three
-                // fixed-point steps (each contracts by 1/(1+v)), +0.01 for the float roundings and the
-                // remaining contraction (4 double-precision logs were a fifth of this kernel's instructions).
-                const double C = fabs(KG / (r.KL * rc.b)) * J.gauss_cut;        // 2^54 (exact mode) or 2^34 (budget mode)
-                if (C <= 1.0) {
-                    u2 = 0.0;
-                } else {
-                    int ex;
-                    const float mant = (float)frexp(C, &ex);                               // C = mant 2^ex, mant in [0.5, 1)
-                    const float lnC = ((float)ex + __log2f(mant)) * 0.69314718f;
-                    float v = lnC;
-                    for (int it = 0; it < 3; ++it) v = lnC + __log2f(1.0f + v) * 0.69314718f;
-                    u2 = fmin((double)(v * 1.00001f + 1.01f), u2_under);
-                }
-            }
-            dg = (u2 > 0.0) ? (double)(__fsqrt_rn((float)u2) * 1.000001f) * a + 2.0 : 0.0;
-        }
-        r.dgi = (dg < 2.0e9) ? (int32_t)dg : 2000000000;
-        // Gaussian recurrence along a lane's consecutive points: only for b <= 4 (see gauss_term);
-        // narrower profiles take one exp per point
-        rc.q2 = (rc.b <= 4.0) ? exp(-2.0 * rc.b) : -1.0;
-        if (!(rc.b <= 4.0)) r.flags |= REC_NO_RECUR;
-        // 16-point runs (gauss_runs16): a lane walks 15 steps from its first point, possibly TOWARDS the centre.
-        // If its seed KG exp(-b d0^2) has underflowed (b d0^2 > T, T = 745 - ln(1/KG) >= ~600 for any KG down
-        // to 1e-60) the run's values stay 0; that is harmless as long as no point of the run can matter: the
-        // nearest one has b d^2 > b (sqrt(T/b) - 15)^2, which exceeds the 45 beyond which the term is below
-        // 2^-54 of the line's Lorentz part whenever sqrt(b) < (sqrt(600) - sqrt(45)) / 15 = 1.19.  b <= 1
-        // (profiles at least one grid point wide) keeps a margin.  (Seeds that are tiny but normal keep the
-        // recurrence exact; a clamped r only lowers a value that is negligible anyway.)  Pure-Gaussian lines
-        // (no Lorentz part to be negligible against: their term counts until it underflows) keep the 4-point pass.
-        if (rc.b <= 1.0 && KL != 0.0) r.flags |= REC_LONG_RUN;
-        rc.KLd = r.KL;
-        const int o = J.dest ? J.dest[i] : i;           // merged layer job: this line's place in the layer's centre-index order
-        J.hot[o] = r;
-        J.cold[o] = rc;
-        J.cidx[o] = (int32_t)idx;
+        long long idx;
+        prep_one_line(J, i, r, rc, idx, regime);
+        J.hot[i] = r;
+        J.cold[i] = rc;
+        J.cidx[i] = (int32_t)idx;
     }
     // regime counters (pyradClasses.py:368-370, 406).  One plain store per block: thousands of
     // atomics on one cache line cost ~12 ns each and made this kernel 3x longer than its arithmetic.
@@ -332,6 +340,43 @@ __global__ __launch_bounds__(256) void line_prep_kernel(const PrepJob* __restric
             s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
 }
 
+// K1 of a merged layer job, in MERGED order: thread t prepares the line that belongs at position t of the layer's record
+// array (src[t] = list within the job << 26 | line within the list, built once per window by merge_rank_kernel), so the
+// records are written with coalesced stores; the seven HITRAN fields are gathered from the job's lists, each of which
+// is walked in increasing order.  (The first version had every list scatter its records through the inverse map: the
+// interleaved 32-byte stores of 90 lists made K1 of the 30-layer column twice as long, 0.39 against 0.20 ms.)
+__global__ __launch_bounds__(256) void line_prep_merged_kernel(const PrepJob* __restrict__ lists, const MergedPrep* __restrict__ jobs) {
+    const MergedPrep& M = jobs[blockIdx.y];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)blockIdx.x >= M.blocks) return;
+    int regime = -1, list = -1;
+    if (t < M.n_total) {
+        const int s = M.src[t];
+        list = (int)((unsigned int)s >> 26);
+        const PrepJob& J = lists[M.first_list + list];
+        HotRec r;
+        ColdRec rc;
+        long long idx;
+        prep_one_line(J, s & ((1 << 26) - 1), r, rc, idx, regime);
+        M.hot[t] = r;
+        M.cold[t] = rc;
+        M.cidx[t] = (int32_t)idx;
+    }
+    // regime counters per list and block of 256 merged positions
+    __shared__ unsigned int s_cnt[4][kMaxIso][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int l = 0; l < M.n_lists; ++l)
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long m = __ballot(list == l && regime == k);
+            if (lane == 0) s_cnt[wave][l][k] = (unsigned int)__popcll(m);
+        }
+    __syncthreads();
+    for (int q = threadIdx.x; q < M.n_lists * 3; q += blockDim.x) {
+        const int l = q / 3, k = q % 3;
+        lists[M.first_list + l].block_counts[blockIdx.x * 3 + k] = s_cnt[0][l][k] + s_cnt[1][l][k] + s_cnt[2][l][k] + s_cnt[3][l][k];
+    }
+}
+
 // lbl_line_quantities: the per-line numbers of the reference (Line.lorentzHW / gaussianHW, the corrected intensity,
 // the regime) from the same expressions K1 evaluates, and the centre index K1 itself wrote (the one K2 works
 // from; K1 clamps it to +-2e9).  Never part of a step.
@@ -342,14 +387,14 @@ __global__ __launch_bounds__(256) void line_quantities_kernel(const PrepJob* __r
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= J.n_lines) return;
     const LinePhysics L = line_physics(J, i);
-    index[i] = (long long)J.cidx[J.dest ? J.dest[i] : i];
+    index[i] = (long long)J.cidx[i];
     lhw[i] = L.lhw; ghw[i] = L.ghw; intensity[i] = L.A;
     regime[i] = line_regime(L.ratio);
 }
 
-// Merged layer jobs: where every line of every list of a layer goes in the layer's one record array (centre-index order,
-// ties by list).  Built once per (line lists, grid) beside the dispatch schedule and kept with it; K1 then scatters its
-// records through `dest` in every step.  centre_index_kernel evaluates K1's own expression (line_physics / line_prep_kernel:
+// Merged layer jobs: which line of which list belongs at every position of the layer's one record array (centre-index
+// order, ties by list).  Built once per (line lists, grid) beside the dispatch schedule and kept with it; K1 then runs in
+// merged order (line_prep_merged_kernel) in every step.  centre_index_kernel evaluates K1's own expression (line_physics / line_prep_kernel:
 // (nu - range_min) / resolution, truncated, clamped), so the order is the order of the very indices K1 will write.
 __global__ __launch_bounds__(256) void centre_index_kernel(const MergeList* __restrict__ lists) {
     const MergeList& M = lists[blockIdx.y];
@@ -379,7 +424,7 @@ __global__ __launch_bounds__(256) void merge_rank_kernel(const MergeList* __rest
         }
         pos += lo;
     }
-    M.dest[i] = pos;
+    M.src_of_job[pos] = (int32_t)(((unsigned int)((int)blockIdx.y - M.job_first) << 26) | (unsigned int)i);
 }
 
 void launch_merge_ranks(const MergeList* d_lists, int n_lists, int max_lines, hipStream_t s) {
@@ -1674,6 +1719,7 @@ __global__ __launch_bounds__(256, 4) void xsec_accumulate_skew_kernel(const Accu
     }
 }
 
+#ifdef LBL_DIAG      // variant 4 (measured: no faster than 3): diagnostic builds only (make EXTRA=-DLBL_DIAG)
 // ---- variant 4: balanced single-round partition -----------------------------------------------
 // Small grids do not fill the chip evenly with one workgroup per span: C2 has 1.5-3 rounds of
 // workgroups of very different length (line density varies 7x) and ran with the VALU only 55-69 %
@@ -1707,6 +1753,8 @@ __global__ __launch_bounds__(256) void span_ranges_kernel(const AccumJob* __rest
     }
 }
 
+#endif
+
 // exclusive prefix sum of n counts into prefix[0..n] (single workgroup of 1024 threads)
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const unsigned int* __restrict__ counts, int n,
                                                            unsigned long long* __restrict__ prefix) {
@@ -1729,6 +1777,7 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const unsigned int* _
     if (t == 1023) prefix[n] = part[1023];
 }
 
+#ifdef LBL_DIAG
 // first index i in [0, n] with prefix[i] > key (prefix non-decreasing): 16-ary search by the
 // first 16 lanes' worth of probes replicated over the wave
 __device__ __forceinline__ int upper_bound_u64(const unsigned long long* __restrict__ a, int n, unsigned long long key,
@@ -1898,6 +1947,12 @@ void launch_accumulate_balanced(const AccumJob* d_jobs, int n_jobs, int total_sp
     }
 }
 
+#else
+// (the production library carries no balanced kernel: lbl_set_option refuses accum_variant 4)
+int balanced_workers(int, int) { return 0; }
+void launch_accumulate_balanced(const AccumJob*, int, int, int, int, SpanRec*, unsigned int*, unsigned long long*, double*, hipStream_t) {}
+#endif
+
 // ----------------------------------------------------------------------------------------
 // Schedule of a launch group, built on the device (time to first spectrum: a pressure or range change
 // re-windows the layer, pyradClasses.py:734-752 -> resetData cls:45-56, and the next getter recomputes)
@@ -2042,6 +2097,30 @@ __global__ __launch_bounds__(1024) void sched_order_xcd_kernel(const unsigned lo
     }
 }
 
+// minimum over the 64 lanes, the same value in every lane: four DPP butterfly steps inside the rows of 16 (always-valid
+// sources), then the four row minima through scalar registers.  (The packing loop below runs this once per item: with
+// __shfl_xor - six ds_bpermute round trips of ~100 cycles - it took 0.6 ms for 879 items, round 4.)
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)v, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(v >> 32), CTRL, 0xf, 0xf, false);
+    const unsigned long long o = ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    v = dpp_min_u64<0xB1>(v);        // quad_perm [1,0,3,2]
+    v = dpp_min_u64<0x4E>(v);        // quad_perm [2,3,0,1]
+    v = dpp_min_u64<0x141>(v);       // row_half_mirror
+    v = dpp_min_u64<0x140>(v);       // row_mirror: every lane of a row holds the row's minimum
+    auto row = [&](int l) {
+        return ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), l) << 32) |
+               (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, l);
+    };
+    const unsigned long long a = row(0), b = row(16), c = row(32), d = row(48);
+    const unsigned long long ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
 // Launches of one round (every workgroup resident from the first cycle, nothing dispatched dynamically: the kernel
 // lasts as long as the busiest CU): items sorted longest-first, each to the least loaded of the n_cu bins that still
 // has a free slot, emitted bin-interleaved so that the dispatcher's round robin over the CUs rebuilds the bins.
@@ -2072,11 +2151,7 @@ __global__ __launch_bounds__(256) void sched_order_pack_kernel(const unsigned in
                 const unsigned long long cand = (bin < n_cu && cnt[b] < slots) ? ((load[b] << 10) | (unsigned long long)bin) : ~0ull;
                 best = cand < best ? cand : best;
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned long long other = __shfl_xor(best, o, 64);
-                best = other < best ? other : best;
-            }
+            best = wave_min_u64(best);
             const int bin = (int)(best & 1023ull);
             if ((bin & 63) == lane) {
 #pragma unroll
@@ -2481,6 +2556,12 @@ void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStrea
     hipLaunchKernelGGL(line_prep_kernel, grid, dim3(256), 0, s, d_jobs);
 }
 
+void launch_line_prep_merged(const PrepJob* d_lists, const MergedPrep* d_jobs, int n_jobs, int max_total, hipStream_t s) {
+    if (n_jobs <= 0 || max_total <= 0) return;
+    dim3 grid((max_total + 255) / 256, n_jobs);
+    hipLaunchKernelGGL(line_prep_merged_kernel, grid, dim3(256), 0, s, d_lists, d_jobs);
+}
+
 void launch_line_quantities(const PrepJob* d_job, int n_lines, long long* index, double* lhw, double* ghw, double* intensity,
                             int32_t* regime, hipStream_t s) {
     if (n_lines <= 0) return;
@@ -2491,9 +2572,11 @@ template <int R>
 static void launch_accum_scalar(const AccumJob* d_jobs, int n_jobs, int max_tiles, int variant, hipStream_t s) {
     dim3 grid(((max_tiles + 7) / 8) * 8, n_jobs);
     switch (variant) {
-        case 0: hipLaunchKernelGGL((xsec_accumulate_kernel<R, 0, 0>), grid, dim3(256), 0, s, d_jobs); break;
+#ifdef LBL_DIAG      // (1: running fraction, 2: + Gaussian recurrence, both through the scalar cache: superseded comparison kernels)
         case 1: hipLaunchKernelGGL((xsec_accumulate_kernel<R, 2, 0>), grid, dim3(256), 0, s, d_jobs); break;
-        default: hipLaunchKernelGGL((xsec_accumulate_kernel<R, 2, 1>), grid, dim3(256), 0, s, d_jobs); break;
+        case 2: hipLaunchKernelGGL((xsec_accumulate_kernel<R, 2, 1>), grid, dim3(256), 0, s, d_jobs); break;
+#endif
+        default: hipLaunchKernelGGL((xsec_accumulate_kernel<R, 0, 0>), grid, dim3(256), 0, s, d_jobs); break;   // 0: IEEE divide + exp per pair
     }
 }
 

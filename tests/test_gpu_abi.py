@@ -358,6 +358,13 @@ def test_production_library_has_no_ablation_option(ctx):
     with pytest.raises(nat.LblError) as e:
         ctx.set_option("debug_ablate", 1)
     assert e.value.code == -1 and "unknown option" in str(e.value)
+    # round 5: the superseded comparison kernels (variants 1, 2, 4) ship in diagnostic builds only
+    for v in (1, 2, 4):
+        with pytest.raises(nat.LblError) as e:
+            ctx.set_option("accum_variant", v)
+        assert e.value.code == -1 and "diagnostic builds only" in str(e.value)
+    for v in (0, 3, 5):
+        ctx.set_option("accum_variant", v)
 
 
 def test_line_view_bounds_cannot_overflow(ctx):

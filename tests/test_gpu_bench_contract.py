@@ -44,11 +44,16 @@ def test_default_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e5 and "sample" in c
     assert c["vectorised_value"] > c["value"]
-    assert r["sweep_fused_in"] is False and "traffic_stale" in r and "busy_frac" in d["valu_f64"]
-    # K2 of the three-molecule cell: 56 B per line read, one cross section per line list written
+    # round 5: the step is ONE merged accumulate job per layer with the sweep in its output stage; the per-list step is a leg
+    assert d["config"]["step"].startswith("merged") and "evals_per_step unchanged" in d["config"]["step"]
+    assert d["config"]["evals_per_step"] == 3925123383.0
+    assert r["sweep_fused_in"] is True and "traffic_stale" in r and "busy_frac" in d["valu_f64"]
+    # K2 of the merged three-molecule cell: 56 B per line read; k, transmittance and radiance written, no cross section
     assert r["algorithmic_bytes_per_launch"] == 56.0 * d["config"]["lines_per_gpu"] + 8.0 * 2400000 * 3
-    sw = d["roofline_sweep"]
-    assert sw["kernel"] == "layer_sweep_kernel" and sw["algorithmic_bytes_per_launch"] == 8.0 * 2400000 * 6 and sw["frac"] > 0.2
+    assert d["roofline_sweep"] == {"fused_into": "xsec_accumulate_lds_kernel (lbl_layer_merged_step_dev)"}
+    assert d["kernel_ms_per_step"]["layer_sweep"] == 0.0
+    pl = d["per_list_leg"]
+    assert pl["ms_per_step"] > d["ms_per_step"] and pl["kernel_ms_per_step"]["layer_sweep"] > 0 and pl["xsec_accumulate_launches_per_step"] == 1
     assert "api_path" in d and d["api_path"]["ms_per_call"] > 0
     # round 4: re-windowing legs (the getter AFTER changePressure / changeRange; schedules are built on the device), the
     # steady state in blocks, where each kernel figure comes from, the accuracy mode and the other mode's leg

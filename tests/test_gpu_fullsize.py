@@ -62,7 +62,7 @@ def test_c2_full_size_sampled_parity_and_properties(ctx):
     # bit-identical rerun; every kernel variant agrees to rounding
     xs2, _, _, _ = accumulate(ctx, lines, "co2", 4e-4, cfg)
     assert np.array_equal(xs, xs2)
-    for v in (2, 3, 4):
+    for v in (0, 3):                      # the literal form (IEEE divide + exp per pair) and the all-direct kernel
         xv, _, _, _ = accumulate(ctx, lines, "co2", 4e-4, cfg, variant=v)
         assert rel_err(xv, xs) <= 1e-12
         if v == 3:                        # the all-direct kernel against the oracle as well

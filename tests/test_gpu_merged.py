@@ -149,7 +149,7 @@ def test_merged_entry_points_refuse_bad_arguments(ctx):
     with pytest.raises(nat.LblError) as e:
         ctx.layer_merged_step_dev(lines, iso, L.grid_native, L.iso_mol, L.conc, L.depth, abs_coef=short)
     assert e.value.code == -1
-    ctx.set_option("accum_variant", 2)              # scalar-cache kernels have no merged form
+    ctx.set_option("accum_variant", 0)              # the scalar-cache kernel has no merged form
     try:
         with pytest.raises(nat.LblError) as e:
             ctx.layer_merged_step_dev(lines, iso, L.grid_native, L.iso_mol, L.conc, L.depth, abs_coef=L.abs_coef)

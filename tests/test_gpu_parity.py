@@ -87,7 +87,7 @@ def test_g1_line_quantities_bit_exact_index(ctx, T):
     L.free()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 3, 5])
 @pytest.mark.parametrize("T", [296, 250])
 def test_g1_cell_all_variants(ctx, T, variant):
     z = load_golden("G1_c1_cell")
@@ -98,7 +98,7 @@ def test_g1_cell_all_variants(ctx, T, variant):
 
 
 @pytest.mark.parametrize("R", [1, 2, 4, 8])
-@pytest.mark.parametrize("variant,LS", [(2, None), (3, 1), (3, 2), (3, 4), (3, 8), (4, None), (5, 1), (5, 2), (5, 4), (5, 8)])
+@pytest.mark.parametrize("variant,LS", [(0, None), (3, 1), (3, 2), (3, 4), (3, 8), (5, 1), (5, 2), (5, 4), (5, 8)])
 def test_g1_points_per_lane_and_line_split(ctx, R, variant, LS):
     z = load_golden("G1_c1_cell")
     xs, _, _, _, _ = device_xsec(ctx, unpack_lines(z, "lines"), "co2", 4e-4, 296, 1013.25, 600, 700, .01, True,
@@ -116,7 +116,7 @@ def test_g0_single_line_known_answer(ctx):
     assert xs[5000] == pytest.approx(4.5462648814858876e-20, rel=1e-14)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 3, 5])
 def test_g2_edges(ctx, variant):
     z = load_golden("G2_edges")
     lines = unpack_lines(z, "lines")
@@ -130,7 +130,7 @@ def test_g2_edges(ctx, variant):
         check(x1, ref)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 3, 5])
 def test_g3_pressure_ladder_with_regrid(ctx, variant):
     z = load_golden("G3_pressure_ladder")
     for j, P in enumerate(z["P_list"]):
@@ -141,7 +141,7 @@ def test_g3_pressure_ladder_with_regrid(ctx, variant):
         check(xs, z[p + "xsec"])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 3, 5])
 def test_g4_regimes(ctx, variant):
     z = load_golden("G4_regimes")
     xs, counts, _, _, _ = device_xsec(ctx, unpack_lines(z, "a.lines"), "co2", 4e-4, 296, 1013.25, 645, 655, .01, True, variant)
@@ -156,7 +156,7 @@ def test_g4_regimes(ctx, variant):
 
 
 @pytest.mark.parametrize("tag,dyn", [("native", False), ("dynamic", True)])
-@pytest.mark.parametrize("variant", [0, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 3, 5])
 def test_g5_native_0p001_and_interp(ctx, tag, dyn, variant):
     z = load_golden("G5_native_0p001")
     xs, _, g, _, _ = device_xsec(ctx, unpack_lines(z, "lines"), "co2", 4e-4, 296, 1013.25, 650, 660, .001, dyn, variant)
@@ -267,10 +267,10 @@ def test_oracle_vs_device_c2_slice_and_determinism(ctx, orc):
     for R, LS in ((8, 4), (8, 1), (4, 2), (2, 1)):
         xs3, _, _, _, _ = device_xsec(ctx, mol["lines"], "co2", 4e-4, 296, 1013.25, 640, 700, .001, False, 3, R, LS)
         check(xs3, ref)
-    for R in (1, 2, 4, 8):          # balanced partition: spans split across waves, slab reduction
-        xs4, _, _, _, _ = device_xsec(ctx, mol["lines"], "co2", 4e-4, 296, 1013.25, 640, 700, .001, False, 4, R)
+    for R in (1, 2, 4, 8):          # the far-field kernel at every span size, rerun bit for bit
+        xs4, _, _, _, _ = device_xsec(ctx, mol["lines"], "co2", 4e-4, 296, 1013.25, 640, 700, .001, False, 5, R)
         check(xs4, ref)
-        xs5, _, _, _, _ = device_xsec(ctx, mol["lines"], "co2", 4e-4, 296, 1013.25, 640, 700, .001, False, 4, R)
+        xs5, _, _, _, _ = device_xsec(ctx, mol["lines"], "co2", 4e-4, 296, 1013.25, 640, 700, .001, False, 5, R)
         assert np.array_equal(xs4, xs5)
 
 

@@ -161,3 +161,116 @@ def test_file_rendezvous_two_ranks(tmp_path):
     assert p.exitcode == 0
     r0.cleanup()
     assert not os.path.isdir(r0.dir)
+
+
+def _worker_eight(rank, world, port, out_dir):
+    """World size 8 (the node the driver scales to) over gloo, on the MERGED step's arrays: every rank computes the
+    layer's absorption coefficient sum_m f_m xs_m (what lbl_layer_merged_step_dev accumulates directly) on its own
+    shard from the lines its halo keeps, and the three gather layouts of bench.py / engine.py move it:
+    equal shards in place, cost-balanced shards through the padded out-of-place gather, and B steps batched into
+    ONE collective (rank r, step b at [(r B + b) S, +S))."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    from pyrad_amd import synthetic, engine
+    from pyrad_amd import dist as pdist
+    from oracle import pyrad_oracle as orc
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        base = synthetic.config_c2(n_lines=10, range_min=640, range_max=660, seed=31)
+        species = (("co2", 4e-4, 31), ("h2o", 1e-2, 32), ("ch4", 1.8e-6, 33))
+        grid = orc.layer_grid(base["P"], base["range_min"], base["range_max"], base["base_resolution"], False)
+        mols = []
+        for sp_name, conc, seed in species:
+            lines = synthetic.make_lines(seed, 260, grid["eff_min"], grid["eff_max"])
+            if sp_name == "co2":        # a dense cluster in the first quarter: equal-width shards are unbalanced
+                lines["nu"] = np.sort(np.concatenate([lines["nu"][:60], 641.0 + 3.0 * np.random.default_rng(7).random(200)]))
+            sp = synthetic.SPECIES[sp_name]
+            mols.append(dict(conc=conc, species=sp_name, isotopologues=[dict(lines=lines, molmass=sp["molmass"], q_T=1.0, q296=1.0)]))
+
+        def layer_k(T, first, count):
+            """the merged step's array on points [first, first + count) (zeros elsewhere), from the halo'd line lists"""
+            k = np.zeros(grid["n_work"])
+            for m in mols:
+                iso = m["isotopologues"][0]
+                sp = synthetic.SPECIES[m["species"]]
+                sel = orc.select_window(iso["lines"], grid["eff_min"], grid["eff_max"])
+                mine = pdist.halo_select(sel, grid["range_min"], grid["resolution"], grid["W"], first, count)
+                xs, _ = orc.create_cross_section(mine, T, base["P"], m["conc"], sp["molmass"], synthetic.q_value(m["species"], T),
+                                                 sp["q296"], grid, regrid=False)
+                k = k + orc.abs_coef(xs, m["conc"], base["P"], T)
+            out = np.zeros(grid["n_work"])
+            out[first:first + count] = k[first:first + count]
+            return out
+
+        out = {}
+        # (1) equal shards: in place on a buffer padded to world * S
+        eq = engine.equal_plan(grid["n_work"], world, rank)
+        assert eq.in_place and eq.S * world >= grid["n_work"] and eq.bounds[rank] == (eq.first, eq.count)
+        buf = np.zeros(eq.S * world)
+        buf[:grid["n_work"]] = layer_k(296, eq.first, eq.count)
+        recv = [torch.zeros(eq.S, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(recv, torch.from_numpy(buf[rank * eq.S:(rank + 1) * eq.S].copy()))
+        out["equal"] = np.concatenate([t.numpy() for t in recv])[:grid["n_work"]]
+        # (2) cost-balanced shards: every rank sends S (the longest shard) doubles from its own first point
+        cfgs = [dict(base, molecules=mols)]
+        bal = engine.balanced_shards(cfgs, world, rank)
+        assert bal.world == world and sum(c for _, c in bal.bounds) == grid["n_work"] and len({c for _, c in bal.bounds}) > 1
+        assert all(f % 1024 == 0 for f, _ in bal.bounds)
+        kb = np.zeros(grid["n_work"] + bal.S)
+        kb[:grid["n_work"]] = layer_k(296, bal.first, bal.count)
+        recv = [torch.zeros(bal.S, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(recv, torch.from_numpy(kb[bal.first:bal.first + bal.S].copy()))
+        out["balanced"] = bal.assemble(np.concatenate([t.numpy() for t in recv]))
+        # (3) B = 3 steps (three temperatures) staged side by side and sent as ONE collective of B * S doubles per rank
+        B, temps = 3, (296, 250, 310)
+        stage = np.zeros(world * B * eq.S)
+        for b, T in enumerate(temps):
+            kT = np.zeros(eq.S * world)
+            kT[:grid["n_work"]] = layer_k(T, eq.first, eq.count)
+            stage[(rank * B + b) * eq.S:(rank * B + b + 1) * eq.S] = kT[rank * eq.S:(rank + 1) * eq.S]
+        recv = [torch.zeros(B * eq.S, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(recv, torch.from_numpy(stage[rank * B * eq.S:(rank + 1) * B * eq.S].copy()))
+        g = np.concatenate([t.numpy() for t in recv]).reshape(world, B, eq.S)
+        for b in range(B):
+            out["batch%d" % b] = g[:, b, :].reshape(-1)[:grid["n_work"]]
+        # the choice bench.py makes by default, and the timing / eval reductions
+        plan, why = engine.choose_shards(cfgs, world, rank, "auto")
+        assert plan.world == world and ("equal" in why or "balanced" in why)
+        ev = torch.tensor([float(sum(engine.eval_count(pdist.halo_select(orc.select_window(m["isotopologues"][0]["lines"], grid["eff_min"], grid["eff_max"]),
+                                                                          grid["range_min"], grid["resolution"], grid["W"], eq.first, eq.count)["nu"],
+                                                       grid["range_min"], grid["resolution"], grid["W"], grid["n_work"], (eq.first, eq.count))
+                                     for m in mols))], dtype=torch.float64)
+        dist.all_reduce(ev)
+        t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            assert float(t[0]) == 0.008
+            ref = {("ref%d" % T): layer_k(T, 0, grid["n_work"]) for T in temps}
+            e_ref = sum(engine.eval_count(orc.select_window(m["isotopologues"][0]["lines"], grid["eff_min"], grid["eff_max"])["nu"],
+                                          grid["range_min"], grid["resolution"], grid["W"], grid["n_work"]) for m in mols)
+            np.savez(os.path.join(out_dir, "eight.npz"), evals=ev.numpy(), evals_ref=float(e_ref),
+                     bounds=np.array(bal.bounds), **out, **ref)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_gather_layouts_on_the_merged_step(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker_eight, args=(r, 8, port, str(tmp_path))) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    z = np.load(tmp_path / "eight.npz")
+    assert np.any(z["ref296"] > 0)
+    assert np.array_equal(z["equal"], z["ref296"]) and np.array_equal(z["balanced"], z["ref296"])
+    for b, T in enumerate((296, 250, 310)):
+        assert np.array_equal(z["batch%d" % b], z["ref%d" % T])
+    assert float(z["evals"][0]) == float(z["evals_ref"])
+    assert z["bounds"][:, 1].sum() == z["equal"].size
