@@ -1273,6 +1273,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             p.inv_T = 1.0 / iso[l].T; p.inv_res = 1.0 / grid[j].resolution; p.inv_res2 = p.inv_res * p.inv_res;
             p.gauss_cut = ctx->accuracy ? 17179869184.0 : 18014398509481984.0;          // 2^34 : 2^54
             p.n_lines = (int32_t)L->n;
+            p.pad = ctx->ablate;                 // (LBL_DIAG builds: debug_ablate 1024 drops every Gaussian part; else 0, never read)
         }
     }
     const bool balanced = ctx->accum_variant == 4;

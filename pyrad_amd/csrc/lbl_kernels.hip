@@ -296,6 +296,9 @@ __device__ __forceinline__ void prep_one_line(const PrepJob& J, int i, HotRec& r
         dg = (u2 > 0.0) ? (double)(__fsqrt_rn((float)u2) * 1.000001f) * a + 2.0 : 0.0;
     }
     r.dgi = (dg < 2.0e9) ? (int32_t)dg : 2000000000;
+#ifdef LBL_DIAG
+    if (J.pad & 1024) r.dgi = 0;               // (timing only, debug_ablate 1024: no Gaussian part anywhere)
+#endif
     // Gaussian recurrence along a lane's consecutive points: only for b <= 4 (see gauss_term);
     // narrower profiles take one exp per point
     rc.q2 = (rc.b <= 4.0) ? exp(-2.0 * rc.b) : -1.0;
@@ -1270,16 +1273,20 @@ __device__ __forceinline__ void skew_lorentz(const double* __restrict__ lh, int 
 // 0-2 lines that cover only some).  14 unmasked iterations for all lanes instead of 28 masked ones.
 // Rounds with a record whose Gaussian part reaches the span, or whose denominator needs the plain divide,
 // take the masked span path (accumulate_lines); K1's cut-off makes that rare for windows this wide.
+// (Rounds that need the masked span path are only MARKED here - bit r of `odd` for round r < 64, everything from round 64
+// on wholesale - and run afterwards through one accumulate_lines call site of the kernel (edge_rounds_masked): inlined into
+// every edge routine the rare path cost them registers and the kernel a third of its code size.)
 template <int R>
 __device__ __forceinline__ void skew_edges(const HotRec* hot, const ColdRec* cold, int iA, int iB, int iC, int iD, int wlo,
                                            int whi, int H, double x0, double Hf, double* lh, double* lc,
-                                           unsigned int* cntL, unsigned int* cntR, int lane, WaveAcc<R>& S) {
+                                           unsigned int* cntL, unsigned int* cntR, int lane, WaveAcc<R>& S, unsigned long long& odd) {
     typedef double v2f64 __attribute__((ext_vector_type(2)));
     typedef const v2f64 __attribute__((address_space(1)))* GlobalF64x2;
     const GlobalF64x2 gh = (GlobalF64x2)(unsigned long long)hot;
     constexpr int SENT = 128;                             // records 0..63: left-edge, 64..127: right-edge, 128: the sentinel
     auto slot = [&](int c, int base) { const int i = c - base + 1; return i < 0 ? 0 : (i > 64 * R + 1 ? 64 * R + 1 : i); };
-    for (int cL = iA, cR = iC; cL < iB || cR < iD; cL += 64, cR += 64) {
+    int round = 0;
+    for (int cL = iA, cR = iC; (cL < iB || cR < iD) && round < 64; cL += 64, cR += 64, ++round) {
         const int nL = max(min(iB - cL, 64), 0), nR = max(min(iD - cR, 64), 0);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1295,12 +1302,7 @@ __device__ __forceinline__ void skew_edges(const HotRec* hot, const ColdRec* col
         // running-fraction range, sends this round through the masked span path
         const bool oddL = vL && (max(0, max(ciL - whi, wlo - ciL)) < __double2loint(l1.y) || (__double2hiint(l1.y) & REC_DIRECT_DIV));
         const bool oddR = vR && (max(0, max(ciR - whi, wlo - ciR)) < __double2loint(r1.y) || (__double2hiint(r1.y) & REC_DIRECT_DIV));
-        if (__any(oddL || oddR)) {
-            double unused[16];                             // (no 16-point Gaussian runs on this path: 4-point passes into the sums)
-            if (nL > 0) accumulate_lines<R, 0>(hot, cold, cL, cL + nL, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, unused, 64, 1, 0);
-            if (nR > 0) accumulate_lines<R, 0>(hot, cold, cR, cR + nR, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, unused, 64, 1, 0);
-            continue;
-        }
+        if (__any(oddL || oddR)) { odd |= 1ull << round; continue; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (vL) {
@@ -1323,6 +1325,130 @@ __device__ __forceinline__ void skew_edges(const HotRec* hot, const ColdRec* col
         skew_lorentz<R, false, true>(lh, SENT, a_full, nL - a_full, 64, b_full, x0, Hf, S, it);
         skew_lorentz<R, true, true>(lh, SENT, a_part, a_full - a_part, 64 + b_full, b_part - b_full, x0, Hf, S, it);
         S.cnt = it;
+    }
+}
+
+// Round 5: the edge lines through the far-field series.  An edge line is 4-39 half-spans from the span centre, so over the
+// points it covers its Lorentz term is the same smooth function the series of far_field_lines expands - but it covers only
+// part of the span.  Left-edge lines are sorted by where their support ends, right-edge lines by where it starts: the lines
+// that cover ALL R points of a lane are a SUFFIX of the left-edge list and a PREFIX of the right-edge list, at positions the
+// threshold counts of the skewed walk already give (a_full, b_full).  So one lane takes one line, computes its series
+// coefficients q_n (three instructions per term, as for a far line), a wave prefix sum over the lanes (left-edge lines loaded
+// in reverse order, so that the prefix IS the suffix; all terms positive: no cancellation, fixed tree) turns q_n into "sum
+// over the first j lines" for every j at once, and every lane picks the one partial sum that belongs to its points
+// (ds_bpermute) and adds it to ITS coefficient C_n of the edge lines' polynomial, evaluated by Horner at its R points at
+// the end.  ~52 instructions per term and 64 + 64 lines instead of 21 per line and lane: the 84 edge lines of a merged
+// 100-2500 cm^-1 span cost ~900 wave-instructions instead of ~1,900 (14 % of the kernel, PMC).  The 0-2 lines per lane
+// that cover only some of its points keep the masked walk; rounds with a Gaussian part that reaches the span or a
+// denominator outside the running-fraction range keep the masked span path, as before.  Like the skewed walk it runs BEFORE
+// the far lines' series phase, so that its NTE coefficients and that phase's NT are never live together.
+// NTE terms: by the distance of the job's nearest edge line, H - 32 R points (FarTerms classes: 20 / 15 / 12 from 8 / 16 / 32
+// half-spans on, exact to half an ulp); nearer than 8 half-spans 30 terms would cost what the walk costs: the walk stays.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_rows_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum over the 64 lanes (lanes without a source add 0); fixed summation tree
+__device__ __forceinline__ double wave_prefix_sum_f64(double v) {
+    v += dpp_move_rows_f64<0x111, 0xf>(v);      // row_shr:1
+    v += dpp_move_rows_f64<0x112, 0xf>(v);      // row_shr:2
+    v += dpp_move_rows_f64<0x114, 0xf>(v);      // row_shr:4
+    v += dpp_move_rows_f64<0x118, 0xf>(v);      // row_shr:8
+    v += dpp_move_rows_f64<0x142, 0xa>(v);      // row_bcast:15 -> rows 1, 3
+    v += dpp_move_rows_f64<0x143, 0xc>(v);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+template <int R, int NTE>
+__device__ __forceinline__ void series_edges(const HotRec* hot, const ColdRec* cold, int iA, int iB, int iC, int iD, int wlo,
+                                             int whi, int H, double x0, double Hf, double xc, double* lh, double* lc,
+                                             unsigned int* cntL, unsigned int* cntR, int lane, WaveAcc<R>& S, unsigned long long& odd) {
+    double C[NTE];                                       // this lane's coefficients of the edge lines' polynomial
+#pragma unroll
+    for (int n = 0; n < NTE; ++n) C[n] = 0.0;
+    typedef double v2f64 __attribute__((ext_vector_type(2)));
+    typedef const v2f64 __attribute__((address_space(1)))* GlobalF64x2;
+    const GlobalF64x2 gh = (GlobalF64x2)(unsigned long long)hot;
+    constexpr int SENT = 128;                             // records 0..63: left-edge, 64..127: right-edge, 128: the sentinel
+    constexpr double hh = 32.0 * R;
+    auto slot = [&](int c, int base) { const int i = c - base + 1; return i < 0 ? 0 : (i > 64 * R + 1 ? 64 * R + 1 : i); };
+    int round = 0;
+    for (int cL = iA, cR = iC; (cL < iB || cR < iD) && round < 64; cL += 64, cR += 64, ++round) {
+        const int nL = max(min(iB - cL, 64), 0), nR = max(min(iD - cR, 64), 0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < R; ++k) { cntL[lane * R + k] = 0u; cntR[lane * R + k] = 0u; }
+        if (lane < 8) { cntL[64 * R + lane] = 0u; cntR[64 * R + lane] = 0u; }
+        if (lane == 0) { lh[SENT * 4] = (double)wlo; lh[SENT * 4 + 1] = 1.0; lh[SENT * 4 + 2] = 0.0; lh[SENT * 4 + 3] = 0.0; }
+        v2f64 l0 = {0, 1}, l1 = {0, 0}, r0 = {0, 1}, r1 = {0, 0};
+        const bool vL = lane < nL, vR = lane < nR;
+        const int oL = nL - 1 - lane;                    // left-edge lines in REVERSE order over the lanes: prefix sums = suffix sums
+        if (vL) { const long long g = (long long)(cL + oL) * 2; l0 = gh[g]; l1 = gh[g + 1]; }
+        if (vR) { const long long g = (long long)(cR + lane) * 2; r0 = gh[g]; r1 = gh[g + 1]; }
+        const int ciL = (int)l0.x, ciR = (int)r0.x;
+        const bool oddL = vL && (max(0, max(ciL - whi, wlo - ciL)) < __double2loint(l1.y) || (__double2hiint(l1.y) & REC_DIRECT_DIV));
+        const bool oddR = vR && (max(0, max(ciR - whi, wlo - ciR)) < __double2loint(r1.y) || (__double2hiint(r1.y) & REC_DIRECT_DIV));
+        if (__any(oddL || oddR)) { odd |= 1ull << round; continue; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (vL) {
+            reinterpret_cast<v2f64*>(lh)[oL * 2] = l0;
+            reinterpret_cast<v2f64*>(lh)[oL * 2 + 1] = l1;
+            atomicMax(&cntL[slot(ciL, wlo - H)], (unsigned int)(oL + 1));                // A', A
+        }
+        if (vR) {
+            reinterpret_cast<v2f64*>(lh)[(64 + lane) * 2] = r0;
+            reinterpret_cast<v2f64*>(lh)[(64 + lane) * 2 + 1] = r1;
+            atomicMax(&cntR[slot(ciR, wlo + H + 1)], (unsigned int)(lane + 1));          // B, B'
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int a_part, a_full, b_full, b_part;
+        skew_counts<R>(cntL, lane, a_part, a_full);
+        skew_counts<R>(cntR, lane, b_full, b_part);
+        // lines covering all of the lane's points: left-edge [a_full, nL) = the lanes 0 .. nL-1-a_full of the reversed
+        // order, right-edge [0, b_full) = the lanes 0 .. b_full-1.  One side after the other (registers).
+        auto side = [&](double cf, double a2, double K, int g) {
+            const bool has = g >= 0;
+            const int src = has ? g : 0;
+            const double dl = cf - xc, sq = fma(dl, dl, a2);
+            double be = __builtin_amdgcn_rcp(sq);
+            be = fma(fma(-sq, be, 1.0), be, be);
+            be = fma(fma(-sq, be, 1.0), be, be);
+            const double al = (dl * (2.0 * hh)) * be, bp = (hh * hh) * be;
+            double qa = K * be, qb = al * qa;
+            auto deposit = [&](double q, double& Cn) {
+                const double p = __shfl(wave_prefix_sum_f64(q), src, 64);
+                Cn += has ? p : 0.0;
+                // (the scheduler may not run the whole chain of q_n ahead of the scans: NTE more live values, spilled)
+                asm volatile("" : "+v"(Cn));
+            };
+            deposit(qa, C[0]);
+            deposit(qb, C[1]);
+#pragma unroll
+            for (int n = 2; n < NTE; ++n) {
+                const double qn = fma(al, qb, -(bp * qa));
+                deposit(qn, C[n]);
+                qa = qb; qb = qn;
+            }
+        };
+        side(l0.x, l0.y, vL ? l1.x : 0.0, nL - 1 - a_full);
+        side(r0.x, r0.y, vR ? r1.x : 0.0, b_full - 1);
+        // the 0-2 lines per lane that cover only some of its points: the masked walk, folded in at once
+        int it = 0;
+        skew_lorentz<R, true, true>(lh, SENT, a_part, a_full - a_part, 64 + b_full, b_part - b_full, x0, Hf, S, it);
+        S.flush();
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const double tau = ((x0 + (double)k) - xc) * (1.0 / (32.0 * R));
+        double v = C[NTE - 1];
+#pragma unroll
+        for (int n = NTE - 2; n >= 0; --n) v = fma(v, tau, C[n]);
+        S.acc[k] += v;
     }
 }
 
@@ -1374,6 +1500,29 @@ __device__ __forceinline__ void output_point(const AccumJob& J, double* __restri
     }
 }
 
+
+// The edge rounds the skewed walk / the edge series left out (a record whose Gaussian part reaches the span or whose
+// denominator needs the plain divide; everything beyond 64 rounds): the masked span path, one call site.
+template <int R>
+__device__ __forceinline__ void edge_rounds_masked(const HotRec* hot, const ColdRec* cold, int iA, int iB, int iC, int iD, int wlo,
+                                                   int whi, double x0, double Hf, double* lh, double* lc, int lane, WaveAcc<R>& S,
+                                                   unsigned long long odd) {
+    double unused[16];                                 // (no 16-point Gaussian runs on this path: 4-point passes into the sums)
+    while (odd) {
+        const int r = __builtin_ctzll(odd);
+        odd &= odd - 1;
+        // (one call over [lo, hi): left- and right-edge records alike are "masked" records for accumulate_lines)
+        for (int side = 0; side < 2; ++side) {
+            const int lo = (side ? iC : iA) + 64 * r, end = side ? iD : iB;
+            const int hi = min(lo + 64, end);
+            if (lo < hi) accumulate_lines<R, 0>(hot, cold, lo, hi, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, unused, 64, 1, 0);
+        }
+    }
+    for (int side = 0; side < 2; ++side) {             // beyond 64 rounds of 64 lines per side: wholesale
+        const int lo = (side ? iC : iA) + 64 * 64, end = side ? iD : iB;
+        if (lo < end) accumulate_lines<R, 0>(hot, cold, lo, end, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, unused, 64, 1, 0);
+    }
+}
 
 template <int R, int LS, int NT = 0>                                                     // NT: far-field series terms (0: every pair direct)
 __global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), ((R >= 4 && LS <= 4) ? 4 : 1))     // HIP: min waves per SIMD
@@ -1453,9 +1602,32 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         // (also on spans without any far line - windows just above the kernel's limit, grid ends: their interior lines
         // are all near, [iF1, iF2) = [iB, iC))
         const bool edges_done = EDGE_SKEW;
-        if (edges_done)
-            skew_edges<R>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, lh, lc, s_ecnt[EDGE_SKEW ? wave : 0][0],
-                          s_ecnt[EDGE_SKEW ? wave : 0][1], lane, S);
+#ifndef LBL_EDGE_SERIES
+#define LBL_EDGE_SERIES 1
+#endif
+        constexpr bool EDGE_SERIES = EDGE_SKEW && LBL_EDGE_SERIES;       // (0: the skewed walk of round 3 everywhere, for A/B builds)
+        if (edges_done) {
+            unsigned int* eL = s_ecnt[EDGE_SKEW ? wave : 0][0];
+            unsigned int* eR = s_ecnt[EDGE_SKEW ? wave : 0][1];
+            // the job's nearest edge line is H - 32 R points from the span centre (wave-uniform: the job's window)
+            typedef FarTerms<FF ? NT : FF_NT> FT;
+            const int dmin = H - 32 * R;
+            unsigned long long odd = 0ull;
+            // a round of the series costs ~52 wave-instructions per term + ~250 whatever it holds, the walk ~21 per line: the
+            // series from 42 / 49 / 62 edge lines per span on (a merged 100-2500 cm^-1 span has 84, one of its line lists 28:
+            // measured on the per-list step, series for everything: K2 +4.5 %)
+            const int n_edge = (iB - iA) + (iD - iC);
+            if (EDGE_SERIES && dmin >= 32 * 32 * R && n_edge * 21 >= 52 * FT::t32 + 250)
+                series_edges<R, FT::t32>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, xc, lh, lc, eL, eR, lane, S, odd);
+            else if (EDGE_SERIES && dmin >= 16 * 32 * R && dmin < 32 * 32 * R && n_edge * 21 >= 52 * FT::t16 + 250)
+                series_edges<R, FT::t16>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, xc, lh, lc, eL, eR, lane, S, odd);
+            else if (EDGE_SERIES && dmin >= 8 * 32 * R && dmin < 16 * 32 * R && n_edge * 21 >= 52 * FT::t8 + 250)
+                series_edges<R, FT::t8>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, xc, lh, lc, eL, eR, lane, S, odd);
+            else
+                skew_edges<R>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, lh, lc, eL, eR, lane, S, odd);
+            if (odd || iB - iA > 64 * 64 || iD - iC > 64 * 64)
+                edge_rounds_masked<R>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, x0, Hf, lh, lc, lane, S, odd);
+        }
         if (any_far) {
             // the running fraction of the edge lines is folded in first: N = 0, D = 1 are then constants through the series
             // phase instead of 16 live registers beside its 60 of coefficients (28 instructions per span)
