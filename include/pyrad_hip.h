@@ -134,6 +134,9 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *                            through the skewed-range kernel when they fill the chip | 0 the span kernel
  *                            (all-direct instantiation) | 2 EVERY job through the skewed-range kernel (parity tests)
  *   "accum_skew_points_per_lane"  1 | 2 | 4 | 8 (default)
+ *   "accum_skew_line_split"  0 (default: by the lines per grid point) | 1 | 2 | 4 waves of a workgroup share one span of the
+ *                            skewed-range kernel and deal its records (dense, merged line lists: a chunk of records
+ *                            then covers the span again)
  *   "accum_far_min_window"   windows below this many points take the skewed-range kernel even where the far-field
  *                            kernel could run them (0, the default: its own limit, 640; measured flat up to 1000)
  *   "debug_ablate"           ONLY in diagnostic builds of the library (make EXTRA=-DLBL_DIAG): timing experiments,

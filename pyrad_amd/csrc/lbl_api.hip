@@ -120,6 +120,7 @@ struct lbl_ctx {
     int skew = 1;            // line lists whose window has no far line (narrower than 5 half-spans of 128 points): 1 (default) the
                              // skewed-range kernel when they fill the chip; 0 the all-direct span kernel; 2 EVERY job through the
                              // skewed-range kernel whatever its window and the grid size (parity tests)
+    int skew_LS = 0;         // waves sharing a span in the skewed-range kernel: 0 (auto: by the lines per point), 1, 2, 4
     int skew_R = 8;          // points per lane of the skewed-range kernel (8: 118 VGPRs, 4 waves per SIMD; measured 7 % faster than 4 on the column)
     int far_min_H = 0;       // windows below this many points go to the skewed-range kernel even if they have far lines (0: the far-field kernel's own limit, 640)
     int ablate = 0;          // LBL_DIAG builds: AccumJob.ablate (always 0 in the production library)
@@ -475,7 +476,7 @@ void comm_prof_end(lbl_ctx* ctx, void* start) { prof_end(ctx, PROF_GATHER, (hipE
 // before (lbl_capture_end) would go on replaying the old ones.  A change of any option therefore bumps the context's epoch:
 // lbl_graph_launch reports the graph stale (LBL_ERR_STATE) and the caller captures again (engine.StepGraph does by itself).
 static uint64_t option_state(const lbl_ctx* c) {
-    const long long v[] = {c->accum_variant, c->accum_R, c->accum_LS, c->lpt, c->tile_order, c->skew, c->skew_R, c->far_min_H,
+    const long long v[] = {c->accum_variant, c->accum_R, c->accum_LS, c->lpt, c->tile_order, c->skew, c->skew_R, c->skew_LS, c->far_min_H,
                            c->ablate, c->accuracy, c->sweep_ieee, c->sched_build, c->no_fuse ? 1 : 0,
                            c->bal_workers[1], c->bal_workers[2], c->bal_workers[4], c->bal_workers[8]};
     uint64_t h = 1469598103934665603ull;
@@ -525,6 +526,10 @@ static int set_option_value(lbl_ctx* ctx, const char* key, int value) {
         if (!(value == 1 || value == 2 || value == 4 || value == 8))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_skew_points_per_lane must be 1, 2, 4 or 8");
         ctx->skew_R = value;
+    } else if (!strcmp(key, "accum_skew_line_split")) {
+        if (!(value == 0 || value == 1 || value == 2 || value == 4))
+            return fail(ctx, LBL_ERR_BAD_ARG, "accum_skew_line_split must be 0 (auto), 1, 2 or 4");
+        ctx->skew_LS = value;
     } else if (!strcmp(key, "accum_far_min_window")) {
         if (value < 0) return fail(ctx, LBL_ERR_BAD_ARG, "accum_far_min_window must be >= 0");
         ctx->far_min_H = value;
@@ -1207,6 +1212,10 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         Group g{k, e - k, 0, 0, 0, ctx->accum_variant, nullptr, 0, nullptr, {}, nullptr};
         if (is_skew(order[k])) {
             g.R = ctx->skew_R; g.LS = 1; g.variant = 6;
+            // dense (merged) line lists: a chunk of 80 records must cover about the span's 64 R points, else only part of
+            // the lanes has lines in it - the waves of a workgroup then share a span and deal its records (R = 8 only)
+            const double chunk_cover = pts > 0 ? 80.0 * (double)pts / std::max<double>((double)lns, 1.0) / (64.0 * g.R) : 1e9;
+            if (g.R == 8) g.LS = ctx->skew_LS ? ctx->skew_LS : (chunk_cover < 1.5 ? 4 : chunk_cover < 3.0 ? 2 : 1);
         } else {
             choose_shape(ctx, g.variant, pts, lns, mh, &g.R, &g.LS);
             // with the R actually chosen (a small grid may have shrunk it): does any job of the group have far lines?
@@ -1447,7 +1456,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             launch_accumulate_balanced(da + g.first, g.count, (int)S, g.R, group_workers[gi], spans, cnts, prefix, slab,
                                        ctx->stream);
         } else if (g.variant == 6) {
-            launch_accumulate_skew(da + g.first, g.count, g.max_tiles, g.R, g.worklist, g.total_tiles, ctx->stream);
+            launch_accumulate_skew(da + g.first, g.count, g.max_tiles, g.R, g.worklist, g.total_tiles, ctx->stream, g.LS);
         } else {
             launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, g.variant, g.worklist, g.total_tiles,
                               ctx->stream, ctx->accuracy);

@@ -236,7 +236,7 @@ void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R,
                        const int2* worklist, int total_tiles, hipStream_t s, int budget = 0);
 // narrow windows: every lane walks the lines that reach its own R points (skewed ranges); tiles of 256 R points
 void launch_accumulate_skew(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, const int2* worklist, int total_tiles,
-                            hipStream_t s);
+                            hipStream_t s, int LS = 1);      // LS 2 | 4: R = 8 only (waves of a workgroup share a span and deal its records)
 int accumulate_tile_points(int R, int LS, int variant);
 void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost, int budget = 0);
 // balanced variant (4): span ranges -> prefix sum -> equal shares of (span, line) pairs per wave -> slab reduce
