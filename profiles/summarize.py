@@ -65,6 +65,13 @@ def main():
     fetch, nf = counters(os.path.join(out, "pmc_fetch_" + wl))
     write, nw = counters(os.path.join(out, "pmc_write_" + wl))
     valu, nv = counters(os.path.join(out, "pmc_valu_" + wl))
+    for extra in ("pmc_sq2_", "pmc_sq3_"):           # round 5: the wave-cycle buckets and the instruction mix (same command, own passes)
+        more, nm = counters(os.path.join(out, extra + wl))
+        for k, c in more.items():
+            for name, total in c.items():
+                # (per-launch means like the first pass's: scaled to that pass's launch count)
+                valu[k][name] = total / max(nm.get(k, 1), 1) * max(nv.get(k, nm.get(k, 1)), 1)
+            nv.setdefault(k, nm.get(k, 1))
     pmc = {"units": "bytes per launch", "workload": wl, "note": __doc__.split("FETCH_SIZE / WRITE_SIZE")[1].strip(),
            "kernels": {}}
     for k in sorted(set(fetch) | set(write)):

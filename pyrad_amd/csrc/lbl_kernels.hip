@@ -352,11 +352,21 @@ __global__ __launch_bounds__(256) void line_prep_merged_kernel(const PrepJob* __
     const MergedPrep& M = jobs[blockIdx.y];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if ((int)blockIdx.x >= M.blocks) return;
+    // the job's per-list constants and field pointers, staged in LDS: every lane picks its own list's block (neighbouring
+    // merged positions belong to different lists), which as global loads were ~25 divergent fetches per line
+    __shared__ PrepJob s_lists[64];
+    {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(lists + M.first_list);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(s_lists);
+        const int words = M.n_lists * (int)(sizeof(PrepJob) / 8);
+        for (int w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
+        __syncthreads();
+    }
     int regime = -1, list = -1;
     if (t < M.n_total) {
         const int s = M.src[t];
         list = (int)((unsigned int)s >> 26);
-        const PrepJob& J = lists[M.first_list + list];
+        const PrepJob& J = s_lists[list];
         HotRec r;
         ColdRec rc;
         long long idx;

@@ -1,10 +1,14 @@
 #!/bin/bash
-# The round's whole profile set in one gpurun call, on whatever box comes up (no box is skipped or re-rolled):
-#   gpurun --timeout 1200 -- 'bash scripts/collect_all.sh r04'
+# The round's profile set on whatever box comes up (no box is skipped or re-rolled), in two gpurun calls (seven rocprofv3 /
+# bench passes per workload since round 5):
+#   gpurun --timeout 1200 -- 'bash scripts/collect_all.sh r05 a'      (C3 and its shards of 8, 4, 2)
+#   gpurun --timeout 1200 -- 'bash scripts/collect_all.sh r05 b'      (C5, C2, C1)
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r04}
+TAG=${1:-r05}
+PART=${2:-a}
 mkdir -p $R/gpurun_out
-for a in "C3" "C3 8,4" "C3 4,2" "C3 2,1" "C5" "C2" "C1"; do
+if [ "$PART" = a ]; then set -- "C3" "C3 8,4" "C3 4,2" "C3 2,1"; else set -- "C5" "C2" "C1"; fi
+for a in "$@"; do
   bash $R/profiles/collect.sh $TAG $a > $R/gpurun_out/collect_$(echo $a | tr ' ,' '__').log 2>&1
   echo "$a rc $?"
 done
