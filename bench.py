@@ -583,8 +583,11 @@ def main():
                     help="experiment on ONE GPU: run only shard r of a G-way sharding of the workload (no communicator): "
                          "what rank r of G would compute per step")
     ap.add_argument("--unfused", action="store_true", help="accumulate launch + separate sweep launch (A/B)")
-    ap.add_argument("--step", default="merged", choices=["merged", "per-list"],
-                    help="merged (default): ONE accumulate job per layer over its merged, factor-weighted line lists, the layer's "
+    ap.add_argument("--step", default="auto", choices=["auto", "merged", "per-list"],
+                    help="auto (default): merged, except for a cell of several line lists whose per-list accumulate launch is at most "
+                         "one round of workgroups (a shard of 8 of the 100-2500 cm^-1 cell: measured 0.057 per-list against 0.060 ms "
+                         "merged - the merged job's 4,688 waves are just more than the chip holds at once). "
+                         "merged: ONE accumulate job per layer over its merged, factor-weighted line lists, the layer's "
                          "absorption coefficient accumulated directly with the sweep in the kernel's output stage "
                          "(lbl_layer_merged_step_dev / lbl_layers_merged_accumulate_dev + lbl_column_fold_dev); per-list: one job and "
                          "one cross-section array per line list, then the sweep over them (lbl_layer_step_dev / lbl_column_step_dev). "
@@ -721,7 +724,8 @@ def main():
     # setup also builds the host-side schedule of every resident set (dispatch order + per-span line
     # ranges, cached by the library per line lists and grid): one priming pass each, outside the
     # timed region whatever --warmup is
-    merged = args.step == "merged" and not args.unfused and args.variant in (None, 3, 5)
+    merged = (args.step == "merged" or (args.step == "auto" and not (small_cell and n_lists > len(layer_cfgs)))) \
+        and not args.unfused and args.variant in (None, 3, 5)
     step_kwargs = (dict(layer_arrays=bool(args.column_layer_arrays), merged=merged) if args.workload == "C5"
                    else dict(surface_T=288.0, fused=not args.unfused, merged=merged))
 
@@ -881,8 +885,9 @@ def main():
     # the per-line-list step (one job and one cross-section array per line list, then the sweep over them) on the same
     # resident inputs, untimed legs like the budget leg's: the line's value is the merged step, this is what it replaced
     per_list_leg = None
-    if merged and args.variant in (None, 5) and not args.no_direct_pass:
-        step_kwargs["merged"] = False
+    other_ok = merged or (args.step == "auto" and not args.unfused)          # (auto chose per-list: the merged step is the leg)
+    if other_ok and args.variant in (None, 5) and not args.no_direct_pass:
+        step_kwargs["merged"] = not merged
         for _ in range(3):
             step()
         barrier()
@@ -899,17 +904,20 @@ def main():
         barrier()
         pp = ctx.profile_read()
         ctx.profile_enable(False)
-        step_kwargs["merged"] = True
+        step_kwargs["merged"] = merged
         for _ in range(2):
             step()
         barrier()
-        per_list_leg = {"ms_per_step": t_pl * 1e3, "evals_per_s": float(layer.evals) / t_pl,
+        per_list_leg = {"step": "per-list" if merged else "merged", "ms_per_step": t_pl * 1e3, "evals_per_s": float(layer.evals) / t_pl,
                         "kernel_ms_per_step": {k_: pp[k_][1] / n_extra for k_ in ("line_prep", "xsec_accumulate", "layer_sweep", "column_sweep")},
                         "xsec_accumulate_launches_per_step": pp["xsec_accumulate"][0] / n_extra,
-                        "what": "the same resident inputs through the per-line-list step (--step per-list: lbl_layer_step_dev / "
-                                "lbl_xsec_accumulate_dev + lbl_column_step_dev - one accumulate job and one cross-section array per line "
-                                "list, then the sweep kernel over them; the step of rounds 1-4): %d steps between barriers, then %d steps "
-                                "with every kernel class bracketed by events; same evals_per_step; not the line's value" % (n_pl, n_extra)}
+                        "what": ("the same resident inputs through the per-line-list step (--step per-list: lbl_layer_step_dev / "
+                                 "lbl_xsec_accumulate_dev + lbl_column_step_dev - one accumulate job and one cross-section array per line "
+                                 "list, then the sweep kernel over them; the step of rounds 1-4)" if merged else
+                                 "the same resident inputs through the merged step (--step merged: one accumulate job per layer over its "
+                                 "merged, factor-weighted line lists, sweep in its output stage)") +
+                                ": %d steps between barriers, then %d steps with every kernel class bracketed by events; same "
+                                "evals_per_step; not the line's value" % (n_pl, n_extra)}
 
     # With a communicator: where the sharded step's time goes, in two short untimed passes (every rank runs
     # them in lockstep): the kernels of a step without the all-gather, and the all-gather alone, in stream.
@@ -1107,7 +1115,9 @@ def main():
                                 "no per-line-list cross-section array is written - lbl_xsec_accumulate_dev produces one on demand, as the "
                                 "reference's lazy getters do (cls:32-88); the per-list step is the per_list_leg"
                                 if merged else
-                                "per-list: one accumulate job and one cross-section array per line list, then the sweep over them"),
+                                "per-list: one accumulate job and one cross-section array per line list, then the sweep over them" +
+                                ("" if args.step != "auto" else " (--step auto: this cell's per-list accumulate launch is at most one round of "
+                                 "workgroups, where the merged job measured slower; the merged step is the merged_leg)")),
                        "accuracy": args.accuracy, "gathered": args.gather, "device": info["name"], "preconditioning_s": args.precondition_seconds,
                        "shard_bounds": (None if layer.plan is None else [list(b) for b in layer.plan.bounds]),
                        "shards": shard_choice,
@@ -1181,7 +1191,7 @@ def main():
         if budget_leg is not None:
             result["budget_leg"] = budget_leg
         if per_list_leg is not None:
-            result["per_list_leg"] = per_list_leg
+            result["per_list_leg" if merged else "merged_leg"] = per_list_leg
         if ablated:
             result["ablated"] = True
             result["invalid"] = "a debug_* option was set: parts of the kernels are switched off, results are wrong, timing experiment only"

@@ -134,6 +134,8 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *                            through the skewed-range kernel when they fill the chip | 0 the span kernel
  *                            (all-direct instantiation) | 2 EVERY job through the skewed-range kernel (parity tests)
  *   "accum_skew_points_per_lane"  1 | 2 | 4 | 8 (default)
+ *   "accum_xcd_chunks"       XCD-partitioned order ("accum_longest_first" 4): contiguous chunks of the tile sequence per
+ *                            XCD, 0 (default: about 29 workgroups per chunk, 10..32 chunks) .. 64
  *   "accum_skew_line_split"  0 (default: by the lines per grid point) | 1 | 2 | 4 waves of a workgroup share one span of the
  *                            skewed-range kernel and deal its records (dense, merged line lists: a chunk of records
  *                            then covers the span again)

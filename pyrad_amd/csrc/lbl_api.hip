@@ -78,7 +78,7 @@ struct lbl_ctx {
         // device build (launch_schedule_build): enqueued by the first batch that uses the schedule, right after its
         // line prep; until then d_list / d_tabs are uninitialised
         bool pending = false;
-        int R = 0, spans_per_tile = 0, total_spans = 0;
+        int R = 0, spans_per_tile = 0, total_spans = 0, xcd_chunks = 32;
         long long far_reach = 0;
         double cost_near = 0, cost_edge = 0, cost_far = 0, cost_fixed = 0;
         std::vector<int32_t> span_first, tile_first;
@@ -120,6 +120,7 @@ struct lbl_ctx {
     int skew = 1;            // line lists whose window has no far line (narrower than 5 half-spans of 128 points): 1 (default) the
                              // skewed-range kernel when they fill the chip; 0 the all-direct span kernel; 2 EVERY job through the
                              // skewed-range kernel whatever its window and the grid size (parity tests)
+    int xcd_chunks = 0;      // XCD-partitioned worklist: contiguous chunks of the tile sequence per XCD (0: by the workgroup count, 10..32)
     int skew_LS = 0;         // waves sharing a span in the skewed-range kernel: 0 (auto: by the lines per point), 1, 2, 4
     int skew_R = 8;          // points per lane of the skewed-range kernel (8: 118 VGPRs, 4 waves per SIMD; measured 7 % faster than 4 on the column)
     int far_min_H = 0;       // windows below this many points go to the skewed-range kernel even if they have far lines (0: the far-field kernel's own limit, 640)
@@ -476,7 +477,7 @@ void comm_prof_end(lbl_ctx* ctx, void* start) { prof_end(ctx, PROF_GATHER, (hipE
 // before (lbl_capture_end) would go on replaying the old ones.  A change of any option therefore bumps the context's epoch:
 // lbl_graph_launch reports the graph stale (LBL_ERR_STATE) and the caller captures again (engine.StepGraph does by itself).
 static uint64_t option_state(const lbl_ctx* c) {
-    const long long v[] = {c->accum_variant, c->accum_R, c->accum_LS, c->lpt, c->tile_order, c->skew, c->skew_R, c->skew_LS, c->far_min_H,
+    const long long v[] = {c->accum_variant, c->accum_R, c->accum_LS, c->lpt, c->tile_order, c->skew, c->skew_R, c->skew_LS, c->xcd_chunks, c->far_min_H,
                            c->ablate, c->accuracy, c->sweep_ieee, c->sched_build, c->no_fuse ? 1 : 0,
                            c->bal_workers[1], c->bal_workers[2], c->bal_workers[4], c->bal_workers[8]};
     uint64_t h = 1469598103934665603ull;
@@ -526,6 +527,9 @@ static int set_option_value(lbl_ctx* ctx, const char* key, int value) {
         if (!(value == 1 || value == 2 || value == 4 || value == 8))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_skew_points_per_lane must be 1, 2, 4 or 8");
         ctx->skew_R = value;
+    } else if (!strcmp(key, "accum_xcd_chunks")) {
+        if (value < 0 || value > 64) return fail(ctx, LBL_ERR_BAD_ARG, "accum_xcd_chunks must be 0 (auto: 10..32 by the workgroup count) .. 64");
+        ctx->xcd_chunks = value;
     } else if (!strcmp(key, "accum_skew_line_split")) {
         if (!(value == 0 || value == 1 || value == 2 || value == 4))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_skew_line_split must be 0 (auto), 1, 2 or 4");
@@ -790,6 +794,8 @@ static void choose_shape(const lbl_ctx* ctx, int variant, long long total_points
             const double W = 600.0 + lps * (1.5 + 1.5 * r);
             double best_cost = 0.0;
             int ls_pick = 1;
+            // (measured and dropped: a three-wave workgroup per span, so that a merged shard of 8 fits the chip's 4,096 wave
+            //  slots - 0.0686 ms against 0.0589 with four waves, whose second, partial round costs less than the longer chains)
             for (int ls = 1; ls <= cap; ls <<= 1) {
                 const double cost = (double)spans * (W + (ls - 1) * 600.0) / std::max(simd_rate((double)spans * ls / (4.0 * cus)), 1e-3);
                 if (ls == 1 || cost < 0.97 * best_cost) { best_cost = cost; ls_pick = ls; }
@@ -857,7 +863,15 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
     for (int j : jobs_in_group) merged = merged || l1(j) - l0(j) > 1;
     // (a merged group's tables and merged positions only come from the device build, whatever the options say)
     const int build_bits = merged ? 1 : ctx->sched_build, lpt_bits = merged ? 4 : ctx->lpt;
-    key.push_back((uint64_t)R << 32 | (uint64_t)far_half_spans << 16 | (uint64_t)LS << 8 | (uint64_t)build_bits << 4 | (uint64_t)lpt_bits << 1 | (uint64_t)far_field);
+    // XCD-partitioned order: contiguous chunks of the tile sequence per XCD.  Every chunk drags the line halo of its ends into
+    // its XCD's L2, so few chunks mean little traffic, and many chunks even out what the cost model misjudges by spectral
+    // region: about 29 workgroups per chunk, between 10 and 32 chunks per XCD (round 2 measured 32 against 8 and 1 on the
+    // per-list 100-2500 cm^-1 cell, 7,031 workgroups; round 5 on its merged job, 2,344 workgroups: 10 chunks fetch 34 MB
+    // where 32 fetch 55, same kernel time; a merged shard of 8, 1,172 workgroups: 10.7 MB against 16.5, same time; 6: +8 %)
+    long long n_wg = 0;
+    for (int j : jobs_in_group) { long long sf, sc; shard_range(grid[j], &sf, &sc); n_wg += (sc + tile_pts - 1) / tile_pts; }
+    const int xcd_chunks = ctx->xcd_chunks > 0 ? ctx->xcd_chunks : (int)std::min<long long>(32, std::max<long long>(10, (n_wg + 116) / 232));
+    key.push_back((uint64_t)xcd_chunks << 40 | (uint64_t)R << 32 | (uint64_t)far_half_spans << 16 | (uint64_t)LS << 8 | (uint64_t)build_bits << 4 | (uint64_t)lpt_bits << 1 | (uint64_t)far_field);
     for (int j : jobs_in_group) {
         long long sf, sc;
         shard_range(grid[j], &sf, &sc);
@@ -913,6 +927,7 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
             S->key = key;
             S->R = R; S->spans_per_tile = (int)(tile_pts / (64LL * R));
             S->far_reach = far_field ? (long long)far_half_spans * 32 * R : 0;
+            S->xcd_chunks = xcd_chunks;
             S->cost_near = 5.0 * R + LBL_COST_GAUSS; S->cost_edge = 8.0 * R; S->cost_far = far_cost * 5.0 * R; S->cost_fixed = 600.0;
             int32_t span_run = 0, tile_run = 0;
             for (int j : jobs_in_group) {
@@ -1003,10 +1018,7 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
         // the whole spectrum - a bias of the cost estimate in one spectral region, e.g. the cheaper
         // pure-Lorentz lines at low wavenumbers, then loads all XCDs alike.  Measured on the 100-2500 cm^-1
         // cell: 1 chunk per XCD +6 % kernel time, 8 chunks +3 %, 32 chunks +-0 with 33 MB fetched instead of 110)
-#ifndef LBL_XCD_CHUNKS
-#define LBL_XCD_CHUNKS 32
-#endif
-        const int chunks = X * LBL_XCD_CHUNKS;
+        const int chunks = X * xcd_chunks;
         double total = 0.0;
         for (const Item& it : items) total += it.count;
         std::vector<std::vector<Item>> part(X);
@@ -1436,7 +1448,8 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         HIP_TRY(ctx, hipMemcpyAsync(ctx->sched.ptr, pinned, (size_t)g.count * sizeof(SchedJob), hipMemcpyHostToDevice, ctx->stream));
         launch_schedule_build((const SchedJob*)ctx->sched.ptr, g.count, sc->total_spans, sc->total, sc->R, sc->spans_per_tile,
                               sc->far_reach, sc->cost_near, sc->cost_edge, sc->cost_far, sc->cost_fixed,
-                              ctx->n_cu > 0 ? ctx->n_cu : 256, sc->d_tabs, (char*)ctx->sched.ptr + jobs_bytes, sc->d_list, ctx->stream);
+                              ctx->n_cu > 0 ? ctx->n_cu : 256, sc->d_tabs, (char*)ctx->sched.ptr + jobs_bytes, sc->d_list, ctx->stream,
+                              sc->xcd_chunks);
         HIP_TRY(ctx, hipGetLastError());
         sc->pending = false;
     }
@@ -1622,7 +1635,9 @@ static double uniform_rcp(double c) {
 // budget mode (lbl_set_option "accuracy" 1): the per-molecule factor of pyradClasses.py:583 and the Planck exponent's
 // per-layer factor of pyradPlanck.py:42, evaluated once on the host in the reference's left-to-right order
 static double budget_factor(double conc, double P, double T) { return conc * P / 1E4 / kB / T; }
-static double budget_pbkT(double T) { double pa, pb; pa = 0; pb = 100 * hPlanck * cLight; (void)pa; return T > 0 ? pb / kB / T : 0.0; }
+// (T = 0: +inf, so that B = a / (exp(inf) - 1) = 0 as in the reference; the entry points refuse T <= 0 for layers, a surface
+// temperature of 0 means "not given")
+static double budget_pbkT(double T) { const double pb = 100 * hPlanck * cLight; return pb / kB / T; }
 
 static double axis_step(double lo, double hi, int64_t n) { return n > 1 ? (hi - lo) / (double)(n - 1) : 0.0; }
 

@@ -165,7 +165,7 @@ bool sched_device_supported(int total_tiles, int n_cu);
 size_t sched_scratch_bytes(int total_tiles);
 void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, int total_tiles, int R, int spans_per_tile,
                            long long far_reach, double cost_near, double cost_edge, double cost_far, double cost_fixed,
-                           int n_cu, int32_t* tabs, void* scratch, int2* worklist, hipStream_t s);
+                           int n_cu, int32_t* tabs, void* scratch, int2* worklist, hipStream_t s, int xcd_chunks = 32);
 
 // ---- fused sweep arguments (passed by value / by pointer to the sweep kernels) ----------
 constexpr int kMaxIso = 48;

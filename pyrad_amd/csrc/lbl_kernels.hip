@@ -175,14 +175,16 @@ __device__ __forceinline__ double rcp_newton(double x) {           // x finite, 
     r = fma(fma(-x, r, 1.0), r, r);
     return fma(fma(-x, r, 1.0), r, r);
 }
+// (a NaN exponent must stay a NaN, as in np.exp(nan): fmin / fmax drop it, so it is put back explicitly - advisor, round 4)
 __device__ __forceinline__ double planck_budget(double n, double pa, double pbkT) {
     const double b = n * pbkT;
     const double e = exp_clamped(fmin(b, 700.0)) - 1.0;
     const double v = (pa * (n * n * n)) * rcp_newton(fmax(e, 1e-300));
-    return (b > 700.0 || !(e > 0.0)) ? ((b > 700.0) ? 0.0 : (pa * (n * n * n)) / e) : v;     // (n = 0: 0/0 like the reference)
+    const double r = (b > 700.0 || !(e > 0.0)) ? ((b > 700.0) ? 0.0 : (pa * (n * n * n)) / e) : v;     // (n = 0: 0/0 like the reference)
+    return b != b ? b : r;
 }
 __device__ __forceinline__ double exp_neg_budget(double x) {       // exp(-x), x >= 0 (optical depth)
-    return exp_clamped(fmax(-x, -800.0));
+    return x != x ? x : exp_clamped(fmax(-x, -800.0));
 }
 
 // ----------------------------------------------------------------------------------------
@@ -2398,7 +2400,7 @@ size_t sched_scratch_bytes(int total_tiles) {         // tile costs | items | pr
 
 void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, int total_tiles, int R, int spans_per_tile,
                            long long far_reach, double cost_near, double cost_edge, double cost_far, double cost_fixed,
-                           int n_cu, int32_t* tabs, void* scratch, int2* worklist, hipStream_t s) {
+                           int n_cu, int32_t* tabs, void* scratch, int2* worklist, hipStream_t s, int xcd_chunks) {
     if (total_spans <= 0 || total_tiles <= 0) return;
     const size_t n = (size_t)total_tiles;
     char* base = (char*)scratch;
@@ -2414,15 +2416,19 @@ void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, 
         return;
     }
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, tile_cost, total_tiles, prefix);
-    const int cap = 16384;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sched_order_xcd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  cap * (int)sizeof(unsigned long long));
-        attr_set = true;
+    // 128 KB of dynamic LDS for the per-XCD sort (gfx950 has 160 KB per CU).  The attribute belongs to the (kernel, device)
+    // pair and this runs once per new window, so it is simply set on every call, for the device the caller has made current
+    // (lbl_api.hip: hipSetDevice(ctx->device)) - a process-wide "already set" flag missed a second device and raced between
+    // host threads (advisor, round 4).  Where it is refused the sort takes 32 KB, which needs no attribute: parts that do
+    // not fit go through global scratch, slower, same result.
+    int cap = 16384;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sched_order_xcd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            cap * (int)sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = 4096;
     }
     hipLaunchKernelGGL(sched_order_xcd_kernel, dim3(8), dim3(1024), cap * sizeof(unsigned long long), s, prefix, tile_cost, items,
-                       total_tiles, 8 * 32, cap, g_keys, sched_key_stride(total_tiles), worklist);
+                       total_tiles, 8 * (xcd_chunks > 0 && xcd_chunks <= 64 ? xcd_chunks : 32), cap, g_keys, sched_key_stride(total_tiles), worklist);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -2647,6 +2653,7 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
                         const double b = pb_n[p] * A.term_pbkT[t];
                         const double e = exp_clamped(fmin(b, 700.0)) - 1.0;
                         B = (b > 700.0) ? 0.0 : (e > 0.0 ? pa_n[p] * rcp_newton(fmax(e, 1e-300)) : pa_n[p] / e);
+                        B = b != b ? b : B;
                     } else {
                         B = planck_at(pa_n[p], pb_n[p], A.term_T[t], A.term_rT[t]);
                     }

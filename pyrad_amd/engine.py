@@ -109,12 +109,35 @@ class Engine:
         master, first, count = hit
         key = id(master["nu"])
         entry = self._line_masters.get(key)
-        if entry is None or entry[1] is not master or entry[0].h is None:
-            entry = self._line_masters[key] = (self.ctx.lines(master), master)
-            if len(self._line_masters) > 64:                      # lists nobody windows any more
-                for k in [k for k, (dev, _) in self._line_masters.items() if k != key and dev.h is not None and not dev.has_views()]:
-                    self._line_masters.pop(k)[0].free()
+        if entry is None or entry[1]() is not master or entry[0].h is None:
+            import weakref
+            self._prune_masters(keep=key)
+            entry = self._line_masters[key] = (self.ctx.lines(master), weakref.ref(master))
         return entry[0].view(first, count)
+
+    MASTER_POOL_BYTES = 8 << 30      # resident line lists nobody windows any more are dropped beyond this (56 B per line)
+
+    def _prune_masters(self, keep=None):
+        """Free resident copies that nothing needs any more: lists whose host master is gone (a data source rebuilt it:
+        PyradDataDir makes a new list whenever it parses a segment it had not seen) as soon as no view of them is left,
+        and, oldest first, idle lists beyond MASTER_POOL_BYTES.  The host masters are held weakly: the pool never keeps
+        a dropped source's arrays alive."""
+        idle = [k for k, (dev, ref) in self._line_masters.items()
+                if k != keep and (dev.h is None or not dev.has_views())]
+        for k in idle:
+            dev, ref = self._line_masters[k]
+            if dev.h is None or ref() is None:
+                self._line_masters.pop(k)
+                if dev.h is not None:
+                    dev.free()
+        total = sum(dev.n * 56 for dev, _ in self._line_masters.values() if dev.h is not None)
+        for k in idle:                                            # (dict order = insertion order: oldest first)
+            if total <= self.MASTER_POOL_BYTES:
+                break
+            if k in self._line_masters:
+                dev, _ = self._line_masters.pop(k)
+                total -= dev.n * 56
+                dev.free()
 
     def close(self):
         self._line_masters = {}
@@ -216,15 +239,18 @@ class StepGraph:
         self.g = owner.ctx.capture(lambda: owner.enqueue(**self.kwargs))
 
     def launch(self):
-        try:
-            self.g.launch()
-        except nat.LblError as e:
-            if e.code != -6:
-                raise
+        if self.g is not None:
+            try:
+                self.g.launch()
+                return
+            except nat.LblError as e:
+                if e.code != -6:
+                    raise
             self.g.free()
-            self.owner.enqueue(**self.kwargs)      # this step, kernel by kernel
-            self.g = self.owner.ctx.capture(lambda: self.owner.enqueue(**self.kwargs))
-            self.recaptures += 1
+            self.g = None                          # (a failed recapture below leaves a consistent object: the next launch retries)
+        self.owner.enqueue(**self.kwargs)          # this step, kernel by kernel
+        self.g = self.owner.ctx.capture(lambda: self.owner.enqueue(**self.kwargs))
+        self.recaptures += 1
 
     def free(self):
         if self.g is not None:

@@ -353,6 +353,38 @@ def test_destroying_a_chained_predecessor_unlinks_it():
         a.close(); b.close()
 
 
+def test_sweeps_propagate_nan_in_both_arithmetics(ctx):
+    """advisor, round 4: a NaN absorption coefficient (bad line data) must give a NaN transmittance and radiance, as
+    np.exp(nan) does - the default arithmetic clamps its exponents with fmin / fmax, which drop a NaN - and a layer at the
+    point n = 0 follows the reference's 0/0.  Both arithmetics of the sweeps, the column step and the fold."""
+    n = 4096
+    xs = np.full(n, 1e-22)
+    bad = np.array([7, 100, 4095])
+    xs[bad] = np.nan
+    b = ctx.buffer(n).upload(xs)
+    k, t, I, out = (ctx.buffer(n).fill(0.0) for _ in range(4))
+    for ieee in (1, 0):
+        ctx.set_option("sweep_ieee_divisions", ieee)
+        try:
+            ctx.layer_sweep_dev([b], [0], [4e-4], 1013.25, 296, 10.0, 0.0, 800.0, n, surface_T=288.0, abs_coef=k, trans=t, I_out=I)
+            kk, tt, II = k.download(n), t.download(n), I.download(n)
+            good = np.ones(n, bool); good[bad] = False
+            assert np.all(np.isnan(kk[bad])) and np.all(np.isnan(tt[bad])) and np.all(np.isnan(II[bad])), ieee
+            assert np.all(np.isfinite(kk[good])) and np.all(np.isfinite(tt[good])) and np.all(np.isfinite(II[good][1:])), ieee
+            assert np.isnan(II[0])                      # nu = 0: B = 0 / (exp(0) - 1) = 0/0 in the reference too (pl:38-44)
+            ctx.column_step_dev([dict(xsec=[b], iso_mol=[0], conc=[4e-4], P=1013.25, T=296, depth=10.0, abs_coef=None, trans=None)],
+                                0.0, 800.0, n, out, surface_T=288.0)
+            oo = out.download(n)
+            assert np.all(np.isnan(oo[bad])) and np.all(np.isfinite(oo[good][1:])), ieee
+        finally:
+            ctx.set_option("sweep_ieee_divisions", 0)
+    ctx.column_fold_dev([k], [296], [10.0], 0.0, 800.0, n, out, surface_T=288.0, trans=[t])
+    oo, tt = out.download(n), t.download(n)
+    assert np.all(np.isnan(oo[bad])) and np.all(np.isnan(tt[bad])) and np.all(np.isfinite(oo[good][1:]))
+    for x in (b, k, t, I, out):
+        x.free()
+
+
 def test_production_library_has_no_ablation_option(ctx):
     from pyrad_amd import _native as nat
     with pytest.raises(nat.LblError) as e:
