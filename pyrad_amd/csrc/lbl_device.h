@@ -129,6 +129,8 @@ struct PrepJob {
     double weight;
 };
 
+static_assert(sizeof(PrepJob) % 8 == 0, "line_prep_merged_kernel copies PrepJob blocks to LDS in 8-byte words");
+
 // K1 in merged order: one per accumulate job of several line lists
 struct MergedPrep {
     const int32_t* src;        // merged position -> (list within the job << 26) | line within the list

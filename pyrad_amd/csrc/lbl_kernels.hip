@@ -31,6 +31,12 @@
 //        column) run xsec_accumulate_skew_kernel, in which every LANE walks the lines that reach its
 //        own points (lbl_set_option "accum_skew")
 //
+// Round 5: an accumulate job may hold ALL line lists of a layer (merged layer job: lbl_layer_merged_step_dev,
+// lbl_layers_merged_accumulate_dev).  K1 (line_prep_merged_kernel) then writes the lists' records into one array in
+// centre-index order with every amplitude times its molecule's conc P / 1E4 / k / T over a power of two, and the same K2
+// kernels accumulate the layer's absorption coefficient sum_m f_m sum_iso xs_iso (pyradClasses.py:707-712, 581-583, 566-571)
+// directly - the "shared wavenumber-grid absorption-coefficient array" - with the sweep in the output stage (output_point).
+//
 // K2 is fp64-VALU bound, not HBM bound: its compulsory traffic is 56 B per line and 8 B per grid
 // point against 5 fp64 instructions per directly evaluated (line, grid point) pair.
 #include "lbl_device.h"

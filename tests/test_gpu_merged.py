@@ -77,6 +77,12 @@ def test_merged_step_equals_per_list_step(ctx, name):
     assert all(np.array_equal(again[k_][sl], got[k_][sl]) for k_ in got)
     if shard is not None:      # nothing outside the shard is touched (abs_coef was poisoned before the merged step)
         assert np.all(np.isnan(got["abs_coef"][:L.first])) and np.all(np.isnan(got["abs_coef"][L.first + L.count:L.n]))
+    # the regime counters (cls:368-370, 406) of a merged batch are still per line list
+    if shard is None:
+        merged_counts = ctx.last_regime_counts(len(L.jobs))
+        L.enqueue_xsec()
+        assert np.array_equal(ctx.last_regime_counts(len(L.jobs)), merged_counts)
+        assert merged_counts.sum() == L.n_lines
     # only the absorption coefficient asked for: the kernel's plain store gives the same bits
     only_k = ctx.buffer(L.padded_n).fill(float("nan"))
     ctx.layer_merged_step_dev([j[0] for j in L.jobs], [j[1] for j in L.jobs], L.grid_native, L.iso_mol, L.conc, L.depth,
