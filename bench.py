@@ -585,8 +585,8 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="accumulate launch + separate sweep launch (A/B)")
     ap.add_argument("--step", default="auto", choices=["auto", "merged", "per-list"],
                     help="auto (default): merged, except for a cell of several line lists whose per-list accumulate launch is at most "
-                         "one round of workgroups (a shard of 8 of the 100-2500 cm^-1 cell: measured 0.057 per-list against 0.060 ms "
-                         "merged - the merged job's 4,688 waves are just more than the chip holds at once). "
+                         "about two rounds of workgroups (a shard of 8 of the 100-2500 cm^-1 cell: measured 0.057 per-list against 0.059 ms "
+                         "merged - the merged job's 4,688 waves are just more than the chip holds at once; a shard of 4: 0.094-0.096 / 0.097). "
                          "merged: ONE accumulate job per layer over its merged, factor-weighted line lists, the layer's "
                          "absorption coefficient accumulated directly with the sweep in the kernel's output stage "
                          "(lbl_layer_merged_step_dev / lbl_layers_merged_accumulate_dev + lbl_column_fold_dev); per-list: one job and "
@@ -724,7 +724,11 @@ def main():
     # setup also builds the host-side schedule of every resident set (dispatch order + per-span line
     # ranges, cached by the library per line lists and grid): one priming pass each, outside the
     # timed region whatever --warmup is
-    merged = (args.step == "merged" or (args.step == "auto" and not (small_cell and n_lists > len(layer_cfgs)))) \
+    # (auto: per-list for a cell of several line lists whose per-list accumulate launch is at most about two rounds of workgroups:
+    #  measured on shards of the 100-2500 cm^-1 cell, per-list / merged: of 8 0.0575 / 0.0589 ms, of 4 0.0943-0.0961 / 0.0970-0.0975,
+    #  of 2 0.1658-0.1680 / 0.1559-0.1577, the whole cell 0.306 / 0.260)
+    few_rounds = float(g0["n_work"]) * n_lists / shard_world <= 2.1 * 4.0 * 256 * 1024
+    merged = (args.step == "merged" or (args.step == "auto" and not (few_rounds and n_lists > len(layer_cfgs)))) \
         and not args.unfused and args.variant in (None, 3, 5)
     step_kwargs = (dict(layer_arrays=bool(args.column_layer_arrays), merged=merged) if args.workload == "C5"
                    else dict(surface_T=288.0, fused=not args.unfused, merged=merged))
@@ -1116,8 +1120,8 @@ def main():
                                 "reference's lazy getters do (cls:32-88); the per-list step is the per_list_leg"
                                 if merged else
                                 "per-list: one accumulate job and one cross-section array per line list, then the sweep over them" +
-                                ("" if args.step != "auto" else " (--step auto: this cell's per-list accumulate launch is at most one round of "
-                                 "workgroups, where the merged job measured slower; the merged step is the merged_leg)")),
+                                ("" if args.step != "auto" else " (--step auto: this cell's per-list accumulate launch is at most about two rounds of "
+                                 "workgroups, where the merged job measured no faster; the merged step is the merged_leg)")),
                        "accuracy": args.accuracy, "gathered": args.gather, "device": info["name"], "preconditioning_s": args.precondition_seconds,
                        "shard_bounds": (None if layer.plan is None else [list(b) for b in layer.plan.bounds]),
                        "shards": shard_choice,

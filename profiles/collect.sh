@@ -40,5 +40,5 @@ open(sys.argv[2], "a").write(json.dumps(rec) + "\n")
 PY
 # everything to commit, where gpurun brings it back from
 mkdir -p $OUT/final
-cp $R/profiles/${TAG}_${WL}_* $R/profiles/pmc_traffic.json $OUT/final/
+cp $R/profiles/${TAG}_${WL}_* $R/profiles/pmc_traffic.json $R/profiles/${TAG}_boxes.jsonl $OUT/final/
 cat $R/profiles/${TAG}_${WL}_kernel_stats.csv

@@ -213,3 +213,76 @@ def test_a_captured_step_goes_stale_when_an_option_changes(ctx):
         assert np.array_equal(L.results()["abs_coef"], exact)
         g.free()
     L.free()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_merged_random_cells(ctx, seed):
+    """Seeded random cells through the merged step against the per-list step AND the oracle: windows from a single point
+    to several thousand (every kernel route: small-span direct, skewed walk with 1 / 2 / 4 waves per span, far-field with
+    the edge walk or the edge series at 12 / 15 / 20 terms), one to five molecules, dense and sparse lists, duplicate
+    wavenumbers across lists, a list without lines, dynamic resolution (regrid) and both accuracy modes."""
+    from oracle import pyrad_oracle as orc
+    from conftest import point_tolerance, rel_err_points
+    from pyrad_amd import engine
+    from pyrad_amd.model import concentration_from_kwargs
+    rng = np.random.default_rng(9000 + seed)
+    base = float(rng.choice([0.01, 0.001]))
+    P = float(rng.choice([1013.25, 1013.25, 600.0, 250.0, 90.0, 20.0, 3.0, 0.15]))
+    if seed % 6 == 5:
+        P = float(rng.choice([3000.0, 10132.5]))           # coarse work grid with dynamic resolution -> regrid
+    dynamic = bool(seed % 6 == 5)
+    T = int(rng.integers(180, 340))
+    n_pts = int(rng.choice([3000, 20000, 60000, 400000])) if base == 0.001 else int(rng.choice([1500, 10000, 40000]))
+    rmin = float(rng.integers(5, 2000))
+    rmax = rmin + n_pts * base
+    n_mol = int(rng.integers(1, 6))
+    species = ["co2", "h2o", "ch4", "o3", "co2_636"][:n_mol]
+    dens = float(rng.choice([0.02, 0.06, 0.2]))             # lines per grid point and list
+    mols_cfg = []
+    first = None
+    for i, sp_name in enumerate(species):
+        n_lines = max(int(n_pts * dens), 3) if not (i == 2 and seed % 4 == 0) else 0
+        dfc = 5.0 * P / 1013.25
+        lines = synthetic.make_lines(100 * seed + i, max(n_lines, 1), max(rmin - dfc - 1, 0.01), rmax + dfc + 1)
+        if n_lines == 0:
+            lines = {k: v[:0] for k, v in lines.items()}
+        elif first is not None and seed % 3 == 0:           # ties across lists: the same wavenumbers as the first list's first half
+            k = min(len(first["nu"]) // 2, len(lines["nu"]))
+            lines["nu"] = np.sort(np.concatenate([first["nu"][:k], lines["nu"][k:]]))
+        if first is None:
+            first = lines
+        conc = [dict(ppm=400), {"%": 1.0}, dict(ppb=1800), dict(ppm=3.0), dict(ppm=4.0)][i]
+        mols_cfg.append(dict(species=sp_name, conc=conc, lines=lines))
+    cfg = dict(depth=float(rng.uniform(1, 1e4)), T=T, P=P, range_min=rmin, range_max=rmax, base_resolution=base,
+               dynamic_resolution=dynamic, molecules=mols_cfg)
+    mols = mols_of(cfg)
+    L = engine.ResidentLayer(ctx, cfg["depth"], T, P, rmin, rmax, mols, base, dynamic)
+    g = L.g
+    budget = seed % 5 == 4
+    ctx.set_option("accuracy", 1 if budget else 0)
+    try:
+        L.enqueue(surface_T=288.0)
+        ref = L.results()
+        for b in (L.abs_coef, L.trans, L.I_out):
+            b.fill(float("nan"))
+        L.enqueue(surface_T=288.0, merged=True)
+        got = L.results()
+    finally:
+        ctx.set_option("accuracy", 0)
+    assert np.all(np.isfinite(got["abs_coef"]))
+    tol_pair = 2e-13 if not budget else 2e-9                # (budget: the two paths cut different lines' series at 1e-9)
+    assert rel_err(got["abs_coef"], ref["abs_coef"]) <= tol_pair, (seed, P, base, g["W"], n_mol)
+    # the oracle on what it finishes in a second
+    if sum(len(m["lines"]["nu"]) for m in mols_cfg) * max(2 * g["W"], 1) <= 4e8:
+        k_ref = np.zeros(g["n_base"])
+        for m, mc in zip(mols, mols_cfg):
+            iso = m["isotopologues"][0]
+            sel = orc.select_window(iso["lines"], g["eff_min"], g["eff_max"])
+            xs, _ = orc.create_cross_section(sel, T, P, m["conc"], iso["molmass"], iso["q_T"], iso["q296"],
+                                             orc.layer_grid(P, rmin, rmax, base, dynamic))
+            k_ref = k_ref + orc.abs_coef(np.zeros(g["n_base"]) + xs, m["conc"], P, T)
+        xa = orc.x_axis(rmin, rmax, base)
+        tol = point_tolerance(xa, T, g["dfc"], rtol_base=(1e-9 if budget else 2e-12))
+        e = rel_err_points(got["abs_coef"], k_ref)
+        assert np.all(e <= tol), (seed, float(e.max()), P, base, g["W"], n_mol)
+    L.free()
