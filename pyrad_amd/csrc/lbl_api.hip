@@ -1140,7 +1140,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         }
         if (job_lines[j] > 2000000000ull) return fail(ctx, LBL_ERR_BAD_ARG, "job %d: too many lines for int32 indexing", j);
         if (l1(j) - l0(j) > 1) {                 // merged-order map: list within the job in 6 bits, line within the list in 26
-            if (l1(j) - l0(j) > 64) return fail(ctx, LBL_ERR_BAD_ARG, "job %d: at most 64 line lists per merged job", j);
+            if (l1(j) - l0(j) > kMaxIso) return fail(ctx, LBL_ERR_BAD_ARG, "job %d: at most %d line lists per merged job", j, kMaxIso);
             for (int l = l0(j); l < l1(j); ++l)
                 if (lines[l]->n >= (1LL << 26)) return fail(ctx, LBL_ERR_BAD_ARG, "line list %d: at most 2^26 - 1 lines per list of a merged job", l);
         }

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void line_prep_merged_kernel(const PrepJob* __
     if ((int)blockIdx.x >= M.blocks) return;
     // the job's per-list constants and field pointers, staged in LDS: every lane picks its own list's block (neighbouring
     // merged positions belong to different lists), which as global loads were ~25 divergent fetches per line
-    __shared__ PrepJob s_lists[64];
+    __shared__ PrepJob s_lists[kMaxIso];            // (a merged job holds at most kMaxIso lists: enqueue_accumulate)
     {
         const unsigned long long* src = reinterpret_cast<const unsigned long long*>(lists + M.first_list);
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(s_lists);
@@ -2329,6 +2329,100 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return ab < cd ? ab : cd;
 }
 
+template <int CTRL>
+__device__ __forceinline__ unsigned int dpp_min_u32(unsigned int v) {
+    const unsigned int o = (unsigned int)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, CTRL, 0xf, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
+    v = dpp_min_u32<0xB1>(v);
+    v = dpp_min_u32<0x4E>(v);
+    v = dpp_min_u32<0x141>(v);
+    v = dpp_min_u32<0x140>(v);
+    const unsigned int a = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned int)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned int c = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned int ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
+// The packing loop of sched_order_pack_kernel, one wave: item k (longest first) to the least loaded bin with a free
+// slot, lowest bin number on a tie.  Lane l owns bins l, 64 + l, ...; the two versions assign identically.
+__device__ __forceinline__ void pack_bins_u64(const unsigned long long* s_keys, short* s_bin, short* s_tier, short* s_size,
+                                              int N, int n_cu, int slots) {
+    const int lane = threadIdx.x;
+    unsigned long long load[8];
+    int cnt[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) { load[b] = 0ull; cnt[b] = 0; }
+    for (int k = 0; k < N; ++k) {
+        const unsigned int cost = 0xFFFFFFFFu - (unsigned int)(s_keys[k] >> 32);
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int bin = b * 64 + lane;
+            const unsigned long long cand = (bin < n_cu && cnt[b] < slots) ? ((load[b] << 10) | (unsigned long long)bin) : ~0ull;
+            best = cand < best ? cand : best;
+        }
+        best = wave_min_u64(best);
+        const int bin = (int)(best & 1023ull);
+        if ((bin & 63) == lane) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (b == (bin >> 6)) { s_tier[k] = (short)cnt[b]; load[b] += cost; cnt[b] += 1; }
+            s_bin[k] = (short)bin;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) if (b * 64 + lane < n_cu) s_size[b * 64 + lane] = (short)cnt[b];
+}
+// 32-bit keys (load << 12 | bin << 3 | items in the bin; all ones once the bin is full or absent): the wave minimum is
+// then a scalar that names the bin, its lane, its tier and its load at once, so the winner's new key is scalar
+// arithmetic and one select per register, and the (bin, tier) of item k0 + j is kept by lane j -
+// no LDS and no divergent branch inside the loop.  While every load is zero, item k goes to bin k: the first n_cu
+// items (of non-zero cost) are placed without the loop.
+template <int NB>
+__device__ __forceinline__ void pack_bins_u32(const unsigned long long* s_keys, short* s_bin, short* s_tier, short* s_size,
+                                              int N, int n_cu, int slots) {
+    const int lane = threadIdx.x;
+    auto cost_of = [&](int k) { return k < N ? 0xFFFFFFFFu - (unsigned int)(s_keys[k] >> 32) : 0u; };
+    const int first = N < n_cu ? N : n_cu;
+    const bool seeded = cost_of(first - 1) > 0u;       // sorted longest-first: then all of the first tier are non-zero
+    unsigned int key[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int bin = b * 64 + lane;
+        key[b] = bin < n_cu ? (unsigned int)(bin << 3) : 0xFFFFFFFFu;
+        if (seeded && bin < first) {
+            key[b] = slots > 1 ? ((cost_of(bin) << 12) | (unsigned int)(bin << 3) | 1u) : 0xFFFFFFFFu;
+            s_bin[bin] = (short)bin;
+            s_tier[bin] = 0;
+        }
+    }
+    for (int k0 = seeded ? first : 0; k0 < N; k0 += 64) {
+        const int my_cost = (int)cost_of(k0 + lane);   // the costs of 64 items, one per lane
+        const int n = N - k0 < 64 ? N - k0 : 64;
+        int placed = 0;                                // lane j: (bin << 3 | tier) of item k0 + j
+        for (int j = 0; j < n; ++j) {
+            const unsigned int cost = (unsigned int)__builtin_amdgcn_readlane(my_cost, j);
+            unsigned int best = key[0];
+#pragma unroll
+            for (int b = 1; b < NB; ++b) best = key[b] < best ? key[b] : best;
+            best = wave_min_u32(best);                                 // uniform
+            const int bin = (int)((best >> 3) & 511u), tier = (int)(best & 7u);
+            const unsigned int next = tier + 1 < slots ? best + (cost << 12) + 1u : 0xFFFFFFFFu;
+            const bool mine = (bin & 63) == lane;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) key[b] = (mine && (bin >> 6) == b) ? next : key[b];
+            placed = lane == j ? (int)(best & 4095u) : placed;
+        }
+        if (lane < n) { s_bin[k0 + lane] = (short)(placed >> 3); s_tier[k0 + lane] = (short)(placed & 7); }
+    }
+    // a bin's item count: what its key says, or `slots` once it is full
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (b * 64 + lane < n_cu) s_size[b * 64 + lane] = (short)(key[b] == 0xFFFFFFFFu ? slots : (int)(key[b] & 7u));
+}
+
 // Launches of one round (every workgroup resident from the first cycle, nothing dispatched dynamically: the kernel
 // lasts as long as the busiest CU): items sorted longest-first, each to the least loaded of the n_cu bins that still
 // has a free slot, emitted bin-interleaved so that the dispatcher's round robin over the CUs rebuilds the bins.
@@ -2343,33 +2437,14 @@ __global__ __launch_bounds__(256) void sched_order_pack_kernel(const unsigned in
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_keys[i] = i < N ? sched_key(tile_cost[i], i) : ~0ull;
     bitonic_sort_lds(s_keys, 1024);
     const int slots = (N + n_cu - 1) / n_cu;           // <= 4 (N <= 4 n_cu)
+    // A bin's load stays below slots * (largest cost): when that fits 20 bits the packing loop runs on 32-bit keys,
+    // ~40 instructions per item instead of ~160 (64-bit compares and selects, LDS stores under a divergent branch).
+    const unsigned int max_cost = 0xFFFFFFFFu - (unsigned int)(s_keys[0] >> 32);
+    const bool narrow = N > 0 && slots <= 7 && (unsigned long long)max_cost * (unsigned int)slots < (1ull << 20);
     if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        unsigned long long load[8];
-        int cnt[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) { load[b] = 0ull; cnt[b] = 0; }
-        for (int k = 0; k < N; ++k) {
-            const unsigned int cost = 0xFFFFFFFFu - (unsigned int)(s_keys[k] >> 32);
-            // this lane's best bin: least load among its bins with a free slot, lowest bin number on a tie
-            unsigned long long best = ~0ull;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int bin = b * 64 + lane;
-                const unsigned long long cand = (bin < n_cu && cnt[b] < slots) ? ((load[b] << 10) | (unsigned long long)bin) : ~0ull;
-                best = cand < best ? cand : best;
-            }
-            best = wave_min_u64(best);
-            const int bin = (int)(best & 1023ull);
-            if ((bin & 63) == lane) {
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (b == (bin >> 6)) { s_tier[k] = (short)cnt[b]; load[b] += cost; cnt[b] += 1; }
-                s_bin[k] = (short)bin;
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < 8; ++b) if (b * 64 + lane < n_cu) s_size[b * 64 + lane] = (short)cnt[b];
+        if (narrow && n_cu <= 256) pack_bins_u32<4>(s_keys, s_bin, s_tier, s_size, N, n_cu, slots);
+        else if (narrow) pack_bins_u32<8>(s_keys, s_bin, s_tier, s_size, N, n_cu, slots);
+        else pack_bins_u64(s_keys, s_bin, s_tier, s_size, N, n_cu, slots);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
