@@ -136,6 +136,16 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "accum_skew_points_per_lane"  1 | 2 | 4 | 8 (default)
  *   "accum_xcd_chunks"       XCD-partitioned order ("accum_longest_first" 4): contiguous chunks of the tile sequence per
  *                            XCD, 0 (default: about 29 workgroups per chunk, 10..32 chunks) .. 64
+ *   "accum_xcd_pack"         launches of one round (at most 4 workgroups per CU; device-built schedules): every XCD packs its own
+ *                            tiles into its own CUs.  1 (default): where every wave owns a span (no line split) an XCD's tiles
+ *                            are a contiguous run of the sequence worth an eighth of the cost (its L2 then holds that run's
+ *                            records only), else every 8th tile of the longest-first order (waves that share spans AND are
+ *                            neighbours in the spectrum queue for the same L2 lines: +9..17 % measured) | 2 always the run |
+ *                            3 always the mix | 0 one packing over all CUs by one wave (round 4).  The dispatch list has idle
+ *                            positions (workgroups that exit at once)
+ *   "accum_xcd_tolerance"    a contiguous run is kept as long as the busiest CU of no XCD carries more than this many percent
+ *                            (default 3; -1: any) above the mean of the eight by the cost model: an XCD whose run holds the
+ *                            spectrum's expensive tiles cannot hand any to another XCD's CUs; the mix takes over
  *   "accum_skew_line_split"  0 (default: by the lines per grid point) | 1 | 2 | 4 waves of a workgroup share one span of the
  *                            skewed-range kernel and deal its records (dense, merged line lists: a chunk of records
  *                            then covers the span again)

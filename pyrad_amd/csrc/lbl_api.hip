@@ -74,6 +74,10 @@ struct lbl_ctx {
     // schedule cache: (job, tile) lists sorted longest first, per launch group
     struct Schedule {
         std::vector<uint64_t> key; int2* d_list; int total; int32_t* d_tabs; std::vector<size_t> tab_off;
+        int xcd_tol = 3;
+        int sr_chunks = 1;                    // single-round launches packed per XCD: contiguous runs of tiles per XCD
+        int launch_total = 0;                 // entries of d_list = workgroups of the launch (>= total: see sched_launch_items)
+        int xcd_pack = 1;
         void* d_block = nullptr;              // the one allocation d_list and d_tabs live in
         // device build (launch_schedule_build): enqueued by the first batch that uses the schedule, right after its
         // line prep; until then d_list / d_tabs are uninitialised
@@ -120,6 +124,10 @@ struct lbl_ctx {
     int skew = 1;            // line lists whose window has no far line (narrower than 5 half-spans of 128 points): 1 (default) the
                              // skewed-range kernel when they fill the chip; 0 the all-direct span kernel; 2 EVERY job through the
                              // skewed-range kernel whatever its window and the grid size (parity tests)
+    int xcd_tol = 3;         // ... as long as no XCD's busiest CU carries more than this many percent above the mean of the eight (-1: always)
+    int xcd_pack = 1;        // single-round launches: every XCD packs its own tiles into its own CUs - 1 (default) a contiguous run of the
+                             // sequence where every wave owns a span, else every 8th tile of the longest-first order; 2 / 3 always the
+                             // run / always the mix; 0 one packing over all CUs by one wave (round 4)
     int xcd_chunks = 0;      // XCD-partitioned worklist: contiguous chunks of the tile sequence per XCD (0: by the workgroup count, 10..32)
     int skew_LS = 0;         // waves sharing a span in the skewed-range kernel: 0 (auto: by the lines per point), 1, 2, 4
     int skew_R = 8;          // points per lane of the skewed-range kernel (8: 118 VGPRs, 4 waves per SIMD; measured 7 % faster than 4 on the column)
@@ -477,7 +485,7 @@ void comm_prof_end(lbl_ctx* ctx, void* start) { prof_end(ctx, PROF_GATHER, (hipE
 // before (lbl_capture_end) would go on replaying the old ones.  A change of any option therefore bumps the context's epoch:
 // lbl_graph_launch reports the graph stale (LBL_ERR_STATE) and the caller captures again (engine.StepGraph does by itself).
 static uint64_t option_state(const lbl_ctx* c) {
-    const long long v[] = {c->accum_variant, c->accum_R, c->accum_LS, c->lpt, c->tile_order, c->skew, c->skew_R, c->skew_LS, c->xcd_chunks, c->far_min_H,
+    const long long v[] = {c->accum_variant, c->accum_R, c->accum_LS, c->lpt, c->tile_order, c->skew, c->skew_R, c->skew_LS, c->xcd_chunks, c->xcd_pack, c->xcd_tol, c->far_min_H,
                            c->ablate, c->accuracy, c->sweep_ieee, c->sched_build, c->no_fuse ? 1 : 0,
                            c->bal_workers[1], c->bal_workers[2], c->bal_workers[4], c->bal_workers[8]};
     uint64_t h = 1469598103934665603ull;
@@ -530,6 +538,12 @@ static int set_option_value(lbl_ctx* ctx, const char* key, int value) {
     } else if (!strcmp(key, "accum_xcd_chunks")) {
         if (value < 0 || value > 64) return fail(ctx, LBL_ERR_BAD_ARG, "accum_xcd_chunks must be 0 (auto: 10..32 by the workgroup count) .. 64");
         ctx->xcd_chunks = value;
+    } else if (!strcmp(key, "accum_xcd_tolerance")) {
+        if (value < -1 || value > 15) return fail(ctx, LBL_ERR_BAD_ARG, "accum_xcd_tolerance must be -1 (off) .. 15 percent");
+        ctx->xcd_tol = value;
+    } else if (!strcmp(key, "accum_xcd_pack")) {
+        if (value < 0 || value > 3) return fail(ctx, LBL_ERR_BAD_ARG, "accum_xcd_pack must be 0..3");
+        ctx->xcd_pack = value;
     } else if (!strcmp(key, "accum_skew_line_split")) {
         if (!(value == 0 || value == 1 || value == 2 || value == 4))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_skew_line_split must be 0 (auto), 1, 2 or 4");
@@ -871,7 +885,9 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
     long long n_wg = 0;
     for (int j : jobs_in_group) { long long sf, sc; shard_range(grid[j], &sf, &sc); n_wg += (sc + tile_pts - 1) / tile_pts; }
     const int xcd_chunks = ctx->xcd_chunks > 0 ? ctx->xcd_chunks : (int)std::min<long long>(32, std::max<long long>(10, (n_wg + 116) / 232));
-    key.push_back((uint64_t)xcd_chunks << 40 | (uint64_t)R << 32 | (uint64_t)far_half_spans << 16 | (uint64_t)LS << 8 | (uint64_t)build_bits << 4 | (uint64_t)lpt_bits << 1 | (uint64_t)far_field);
+    // (a launch of one round: 1..16 runs per XCD, default 1 - see launch_schedule_build)
+    const int sr_chunks = ctx->xcd_chunks > 0 ? std::min(ctx->xcd_chunks, 16) : 1;
+    key.push_back((uint64_t)(ctx->xcd_tol + 1) << 59 | (uint64_t)sr_chunks << 52 | (uint64_t)ctx->xcd_pack << 48 | (uint64_t)xcd_chunks << 40 | (uint64_t)R << 32 | (uint64_t)far_half_spans << 16 | (uint64_t)LS << 8 | (uint64_t)build_bits << 4 | (uint64_t)lpt_bits << 1 | (uint64_t)far_field);
     for (int j : jobs_in_group) {
         long long sf, sc;
         shard_range(grid[j], &sf, &sc);
@@ -939,6 +955,8 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
                 tile_run += (int32_t)((sc + tile_pts - 1) / tile_pts);
             }
             S->total_spans = span_run; S->total = tile_run;
+            S->xcd_pack = ctx->xcd_pack; S->sr_chunks = sr_chunks; S->xcd_tol = ctx->xcd_tol;
+            S->launch_total = sched_launch_items(tile_run, n_cu_i, S->xcd_pack != 0);
             size_t n_src = 0;
             for (int j : jobs_in_group) {
                 size_t n = 0;
@@ -946,7 +964,7 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
                 S->src_off.push_back(l1(j) - l0(j) > 1 ? n_src : SIZE_MAX);
                 if (l1(j) - l0(j) > 1) n_src += n;
             }
-            S->d_block = one_block((size_t)tile_run, (size_t)span_run * 8, &S->d_list, &S->d_tabs, n_src, &S->d_src);
+            S->d_block = one_block((size_t)S->launch_total, (size_t)span_run * 8, &S->d_list, &S->d_tabs, n_src, &S->d_src);
             if (!S->d_block) return nullptr;
             S->pending = true;
             S->merge_pending = n_src > 0;
@@ -1094,7 +1112,7 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
     }
     evict_oldest();
     std::unique_ptr<lbl_ctx::Schedule> S(new lbl_ctx::Schedule());
-    S->key = key; S->d_list = d_list; S->total = (int)host.size(); S->d_tabs = d_tabs; S->tab_off = tab_off; S->d_block = blk;
+    S->key = key; S->d_list = d_list; S->total = (int)host.size(); S->launch_total = S->total; S->d_tabs = d_tabs; S->tab_off = tab_off; S->d_block = blk;
     S->total_spans = -(int)(tabs.size() / 8);          // (negative: built on the host; lbl_schedule_export)
     ctx->schedules.push_back(std::move(S));
     return ctx->schedules.back().get();
@@ -1243,7 +1261,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
                 return fail(ctx, LBL_ERR_BAD_ARG, "merged layer jobs need the device schedule build, which does not cover a launch of this size: use the per-line-list step");
             if (!sc) return ctx->capturing ? LBL_ERR_STATE : fail(ctx, LBL_ERR_OOM, "schedule allocation failed");
             if ((sc->pending || sc->merge_pending) && ctx->capturing) return capture_refuses(ctx, "building a dispatch schedule");
-            g.worklist = sc->d_list; g.total_tiles = sc->total; g.tabs = sc->d_tabs; g.tab_off = sc->tab_off; g.sched = sc;
+            g.worklist = sc->d_list; g.total_tiles = sc->launch_total; g.tabs = sc->d_tabs; g.tab_off = sc->tab_off; g.sched = sc;
         }
         groups.push_back(g);
         k = e;
@@ -1449,7 +1467,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         launch_schedule_build((const SchedJob*)ctx->sched.ptr, g.count, sc->total_spans, sc->total, sc->R, sc->spans_per_tile,
                               sc->far_reach, sc->cost_near, sc->cost_edge, sc->cost_far, sc->cost_fixed,
                               ctx->n_cu > 0 ? ctx->n_cu : 256, sc->d_tabs, (char*)ctx->sched.ptr + jobs_bytes, sc->d_list, ctx->stream,
-                              sc->xcd_chunks);
+                              sc->xcd_chunks, sc->xcd_pack != 0, sc->sr_chunks, sc->xcd_tol, sc->xcd_pack == 2 ? 1 : sc->xcd_pack == 3 ? 0 : -1);
         HIP_TRY(ctx, hipGetLastError());
         sc->pending = false;
     }
@@ -1499,12 +1517,12 @@ extern "C" int lbl_schedule_export(lbl_ctx* ctx, int k, int32_t* list, int64_t l
     if (S.pending) return fail(ctx, LBL_ERR_STATE, "the schedule has not been built yet (no accumulate batch has used it)");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t n_tabs = (int64_t)std::abs(S.total_spans) * 8;
-    *n_items = S.total;
+    *n_items = S.launch_total;
     *n_tab_ints = n_tabs;
     if (built_on_device) *built_on_device = S.total_spans > 0 ? 1 : 0;
     if (list) {
-        if (list_cap < 2 * (int64_t)S.total) return fail(ctx, LBL_ERR_BAD_ARG, "list too short");
-        if (S.total > 0) HIP_TRY(ctx, hipMemcpy(list, S.d_list, (size_t)S.total * sizeof(int2), hipMemcpyDeviceToHost));
+        if (list_cap < 2 * (int64_t)S.launch_total) return fail(ctx, LBL_ERR_BAD_ARG, "list too short");
+        if (S.launch_total > 0) HIP_TRY(ctx, hipMemcpy(list, S.d_list, (size_t)S.launch_total * sizeof(int2), hipMemcpyDeviceToHost));
     }
     if (tabs && n_tabs > 0) {
         if (tabs_cap < n_tabs) return fail(ctx, LBL_ERR_BAD_ARG, "tabs too short");

@@ -167,7 +167,10 @@ bool sched_device_supported(int total_tiles, int n_cu);
 size_t sched_scratch_bytes(int total_tiles);
 void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, int total_tiles, int R, int spans_per_tile,
                            long long far_reach, double cost_near, double cost_edge, double cost_far, double cost_fixed,
-                           int n_cu, int32_t* tabs, void* scratch, int2* worklist, hipStream_t s, int xcd_chunks = 32);
+                           int n_cu, int32_t* tabs, void* scratch, int2* worklist, hipStream_t s, int xcd_chunks = 32, bool xcd_pack = true,
+                           int single_round_chunks = 1, int xcd_tol = 3, int xcd_local = -1);
+// entries of the dispatch list of a launch (a single-round launch packed per XCD has more positions than tiles: the rest exit at once)
+int sched_launch_items(int total_tiles, int n_cu, bool xcd_pack);
 
 // ---- fused sweep arguments (passed by value / by pointer to the sweep kernels) ----------
 constexpr int kMaxIso = 48;

@@ -1543,7 +1543,7 @@ __device__ __forceinline__ void edge_rounds_masked(const HotRec* hot, const Cold
 }
 
 template <int R, int LS, int NT = 0>                                                     // NT: far-field series terms (0: every pair direct)
-__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), ((R >= 4 && LS <= 4) ? 4 : 1))     // HIP: min waves per SIMD
+__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), (R >= 4 ? 4 : 1))                // HIP: min waves per SIMD
 void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* __restrict__ worklist) {
     constexpr bool FF = NT > 0;
     constexpr int NW = LS > 4 ? LS : 4;              // wavefronts per workgroup (LS = 8: 512 threads)
@@ -2463,6 +2463,184 @@ __global__ __launch_bounds__(256) void sched_order_pack_kernel(const unsigned in
     }
 }
 
+// Single-round launches, packed per XCD (round 5).  Workgroup p of a launch runs on XCD p % 8: XCD x packs ITS tiles
+// longest-first into its own n_cu / 8 CUs (one wave per XCD, one bin per lane: the loop of pack_bins_u32) and emits them
+// at the positions k 8 + x; eight waves in parallel, ~35 us where the one-wave packing of 879 items over all CUs took
+// 0.14 ms (0.43 before its 32-bit keys, 0.60 in round 4).  Which tiles are an XCD's:
+//   local 1: a CONTIGUOUS run of the tile sequence worth an eighth of the cost (midpoint rule on the cost prefix; `chunks`
+//     / 8 runs per XCD): its L2 then holds its own records only - 5.3 MB fetched per launch instead of 14.8 on a
+//     per-list shard of 8 (879 workgroups), 5.5 instead of 21 on a one-list 500-900 cm^-1 cell (782).  But every wave of a
+//     single round starts at the same time and walks its records in step with its neighbours, and with neighbours that
+//     are neighbours in the SPECTRUM all CUs of an XCD ask for the same lines of the same L2 channels at once.  Measured
+//     against the mixed order, same box: launches whose waves each own a span (4 spans per workgroup) 391 workgroups
+//     +-0, 588 +-0, 879 -1 %; launches whose spans are shared by 2 or 4 waves (which read the same records again) 782
+//     workgroups +10 %, 586 (merged shard of 16) +17 %, a per-list shard of 16 +9 % (the order inside the XCD - tiers
+//     closed up, one position per CU and tier, bins by fill - changed nothing; 2, 4 or 8 runs per XCD neither).  So: the
+//     launches with unsplit spans (the caller's rule; "accum_xcd_pack" 2 / 3 force either).
+//   local 0: every 8th tile of the longest-first order - each XCD a like sample of the whole spectrum, which is what
+//     the one packing over all CUs (sched_order_pack_kernel) gave it.
+// A local launch falls back to the mixed order inside this kernel when a run does not fit the `m_cap` positions the
+// host reserved per XCD (costs piled up in a few tiles) or when the busiest CU of some XCD carries more than `tol`
+// percent above the mean of the eight by the cost model (an XCD whose run holds the spectrum's expensive tiles cannot
+// hand any to another XCD's CUs).  Positions without a tile hold (0, -1): workgroups that exit at once.
+__global__ __launch_bounds__(512) void sched_order_pack_xcd_kernel(const unsigned int* __restrict__ tile_cost,
+                                                                   const int2* __restrict__ items, int N, int n_cu, int m_cap,
+                                                                   int local, int chunks, int tol, int2* __restrict__ worklist) {
+    __shared__ unsigned long long s_keys[1024];
+    __shared__ unsigned long long s_pref[1024];          // inclusive prefix of the costs, in tile order
+    __shared__ unsigned long long s_scan[8];
+    __shared__ int s_end[9], s_cnt[8], s_retry;
+    __shared__ unsigned int s_make[8];
+    __shared__ short s_xcd[1024];
+    __shared__ short s_place[1024];                      // k-th item of XCD x (slot x * 128 + k ... see at()) -> bin << 3 | tier
+    __shared__ short s_inv[8][7 * 64];                   // position of the XCD -> its k-th item, -1 idle
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = wave, B = n_cu >> 3;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool mixed = local == 0 || attempt == 1;
+        if (!mixed) {
+            // cost prefix: two items per thread, a wave scan, the eight wave totals
+            const unsigned int c0 = 2 * tid < N ? tile_cost[2 * tid] : 0u, c1 = 2 * tid + 1 < N ? tile_cost[2 * tid + 1] : 0u;
+            unsigned long long run = (unsigned long long)c0 + c1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned long long o = __shfl_up(run, d);
+                if (lane >= d) run += o;
+            }
+            if (lane == 63) s_scan[wave] = run;
+            if (tid < 8) s_cnt[tid] = 0;
+            __syncthreads();
+            unsigned long long base = 0ull, total = 0ull;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { base += w < wave ? s_scan[w] : 0ull; total += s_scan[w]; }
+            s_pref[2 * tid + 1] = base + run;
+            s_pref[2 * tid] = base + run - c1;
+            __syncthreads();
+            // XCD of item i: the midpoint of its cost falls into one of `chunks` equal shares of the total; share c is XCD c % 8's
+            for (int i = tid; i < N; i += blockDim.x) {
+                const unsigned long long cost = (unsigned long long)tile_cost[i];
+                const unsigned long long mid = 2ull * (s_pref[i] - cost) + cost;        // 2 x midpoint
+                unsigned long long c = total ? mid * (unsigned long long)chunks / (2ull * total) : 0ull;
+                c = c >= (unsigned long long)chunks ? (unsigned long long)chunks - 1ull : c;
+                s_xcd[i] = (short)(c & 7ull);
+                atomicAdd(&s_cnt[(int)(c & 7ull)], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int run_n = 0, worst = 0;
+                for (int y = 0; y < 8; ++y) { s_end[y] = run_n; run_n += s_cnt[y]; worst = max(worst, s_cnt[y]); }
+                s_end[8] = run_n;
+                s_retry = worst > m_cap ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_retry) continue;                       // (uniform: every thread reads the same flag)
+        }
+        // one sort: (by XCD,) longest first, ties by position
+        __syncthreads();
+        for (int i = tid; i < 1024; i += blockDim.x) {
+            unsigned long long key = ~0ull;
+            if (i < N)
+                key = ((unsigned long long)(mixed ? 0 : s_xcd[i]) << 42) | ((unsigned long long)(0xFFFFFFFFu - tile_cost[i]) << 10) | (unsigned long long)i;
+            s_keys[i] = key;
+        }
+        bitonic_sort_lds(s_keys, 1024);
+        // wave x packs its items - the sorted positions [s_end[x], s_end[x + 1]), or x, x + 8, ... - into its bins = lanes 0 .. B - 1
+        const int first = mixed ? x : s_end[x], stride = mixed ? 8 : 1;
+        const int n_x = mixed ? (N - x + 7) / 8 : s_end[x + 1] - s_end[x];
+        auto at = [&](int k) { return first + k * stride; };
+        const int slots = (n_x + B - 1) / B;             // <= 7 (sched_xcd_positions)
+        auto cost_at = [&](int k) { return k < n_x ? 0xFFFFFFFFu - (unsigned int)((s_keys[at(k)] >> 10) & 0xFFFFFFFFull) : 0u; };
+        // loads as 23-bit numbers: costs scaled down where slots x (largest cost) needs more (the order of nearly equal
+        // loads is all that changes)
+        int shift = 0;
+        while (n_x > 0 && (((unsigned long long)cost_at(0) * (unsigned int)(slots > 0 ? slots : 1)) >> shift) >= (1ull << 23)) ++shift;
+        const int seed_n = n_x < B ? n_x : B;
+        const bool seeded = n_x > 0 && (cost_at(seed_n - 1) >> shift) > 0u;     // while every load is zero, item k goes to bin k
+        unsigned int key = lane < B ? (unsigned int)(lane << 3) : 0xFFFFFFFFu;  // load << 9 | bin << 3 | items in the bin
+        if (seeded && lane < seed_n) {
+            key = slots > 1 ? (((cost_at(lane) >> shift) << 9) | (unsigned int)(lane << 3) | 1u) : 0xFFFFFFFFu;
+            s_place[at(lane)] = (short)(lane << 3);
+        }
+        int full_cnt = (seeded && lane < seed_n && slots == 1) ? 1 : 0;         // what an all-ones key no longer says
+        unsigned int my_load = (seeded && lane < seed_n) ? cost_at(lane) : 0u;  // the bin's load, unscaled
+        for (int k0 = seeded ? seed_n : 0; k0 < n_x; k0 += 64) {
+            const int my_raw = (int)cost_at(k0 + lane);
+            const int my_cost = (int)((unsigned int)my_raw >> shift);
+            const int n = n_x - k0 < 64 ? n_x - k0 : 64;
+            int placed = 0;
+            for (int j = 0; j < n; ++j) {
+                const unsigned int cost = (unsigned int)__builtin_amdgcn_readlane(my_cost, j);
+                const unsigned int raw = (unsigned int)__builtin_amdgcn_readlane(my_raw, j);
+                const unsigned int best = wave_min_u32(key);
+                const int bin = (int)((best >> 3) & 63u), tier = (int)(best & 7u);
+                const bool last = tier + 1 >= slots;
+                const unsigned int next = last ? 0xFFFFFFFFu : best + (cost << 9) + 1u;
+                if (lane == bin) { key = next; full_cnt = last ? tier + 1 : 0; my_load += raw; }
+                placed = lane == j ? (int)(best & 511u) : placed;
+            }
+            if (lane < n) s_place[at(k0 + lane)] = (short)placed;
+        }
+        if (!mixed) {
+            unsigned int mk = my_load;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) mk = max(mk, (unsigned int)__shfl_xor((int)mk, d));
+            if (lane == 0) s_make[x] = mk;
+            __syncthreads();
+            unsigned long long sum = 0ull;
+            unsigned int worst = 0u;
+#pragma unroll
+            for (int y = 0; y < 8; ++y) { sum += s_make[y]; worst = max(worst, s_make[y]); }
+            if (tol >= 0 && (unsigned long long)worst * 800ull > sum * (unsigned long long)(100 + tol)) continue;   // (uniform)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int my_size = lane < B ? (key == 0xFFFFFFFFu ? full_cnt : (int)(key & 7u)) : 0;
+        // tier by tier, closed up, the bins in bin order
+        for (int k = lane; k < m_cap; k += 64) s_inv[x][k] = (short)-1;
+        unsigned long long tier_mask[8];
+        int tier_off[8];
+        int off = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            tier_mask[t] = __ballot(my_size > t);
+            tier_off[t] = off;
+            off += __popcll(tier_mask[t]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < n_x; k += 64) {
+            const int pl = s_place[at(k)], bin = pl >> 3, t = pl & 7;
+            unsigned long long m = 0ull;
+            int o = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { m = u == t ? tier_mask[u] : m; o = u == t ? tier_off[u] : o; }
+            s_inv[x][o + __popcll(m & ((1ull << bin) - 1ull))] = (short)k;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < m_cap; k += 64) {
+            const int src = s_inv[x][k];
+            worklist[(size_t)k * 8 + x] = src >= 0 ? items[(int)(s_keys[at(src)] & 1023ull)] : make_int2(0, -1);
+        }
+        return;
+    }
+}
+
+// Entries of a launch's dispatch list: the tiles, or - single round on a chip of 8 XCDs - eight runs of `m_cap` positions
+int sched_xcd_positions(int total_tiles, int n_cu) {
+    if (total_tiles <= 0 || total_tiles > 4 * n_cu || total_tiles > 1024 || n_cu % 8 != 0 || n_cu < 64 || n_cu > 512) return 0;
+    const int b = n_cu / 8;                                      // bins per XCD; up to twice an eighth of the tiles per XCD (a
+    int m = 2 * ((total_tiles + 7) / 8);                         // sparse spectral region is many cheap tiles), in whole tiers
+    m = (m + b - 1) / b * b;                                     // of b positions, at most 7
+    if (m > 7 * b) m = 7 * b;
+    if (8 * m < total_tiles) return 0;
+    return m;
+}
+int sched_launch_items(int total_tiles, int n_cu, bool xcd_pack) {
+    const int m = xcd_pack ? sched_xcd_positions(total_tiles, n_cu) : 0;
+    return m > 0 ? 8 * m : total_tiles;
+}
+
 // What the device build covers (else the caller builds the schedule on the host), and the scratch it needs.
 bool sched_device_supported(int total_tiles, int n_cu) {
     if (total_tiles <= 4 * n_cu) return total_tiles <= 1024 && n_cu <= 512;
@@ -2481,7 +2659,8 @@ size_t sched_scratch_bytes(int total_tiles) {         // tile costs | items | pr
 
 void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, int total_tiles, int R, int spans_per_tile,
                            long long far_reach, double cost_near, double cost_edge, double cost_far, double cost_fixed,
-                           int n_cu, int32_t* tabs, void* scratch, int2* worklist, hipStream_t s, int xcd_chunks) {
+                           int n_cu, int32_t* tabs, void* scratch, int2* worklist, hipStream_t s, int xcd_chunks, bool xcd_pack,
+                           int single_round_chunks, int xcd_tol, int xcd_local) {
     if (total_spans <= 0 || total_tiles <= 0) return;
     const size_t n = (size_t)total_tiles;
     char* base = (char*)scratch;
@@ -2493,7 +2672,17 @@ void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, 
     hipLaunchKernelGGL(sched_spans_kernel, dim3((total_spans + 255) / 256), dim3(256), 0, s, d_jobs, n_jobs, total_spans, R,
                        spans_per_tile, far_reach, cost_near, cost_edge, cost_far, cost_fixed, tabs, tile_cost, items);
     if (total_tiles <= 4 * n_cu) {
-        hipLaunchKernelGGL(sched_order_pack_kernel, dim3(1), dim3(256), 0, s, tile_cost, items, total_tiles, n_cu, worklist);
+        const int m_cap = xcd_pack ? sched_xcd_positions(total_tiles, n_cu) : 0;
+        if (m_cap > 0) {
+            // (runs per XCD: 1 by default.  A tile's records reach ~20 tiles to either side, so only runs much longer than that
+            // keep an L2 to its own records: one run of ~50-110 tiles fetched 5.3-5.5 MB where 2 / 4 / 8 runs fetched 6.0 / 7.1 /
+            // 9.2 and the packing over all CUs 14.8-21; the step times of 1, 2, 4 and 8 runs did not differ on the shards.)
+            const int local = xcd_local == 1 || (xcd_local < 0 && spans_per_tile >= 4) ? 1 : 0;         // (auto: unsplit spans only)
+            hipLaunchKernelGGL(sched_order_pack_xcd_kernel, dim3(1), dim3(512), 0, s, tile_cost, items, total_tiles, n_cu, m_cap,
+                               local, 8 * single_round_chunks, xcd_tol, worklist);
+        } else {
+            hipLaunchKernelGGL(sched_order_pack_kernel, dim3(1), dim3(256), 0, s, tile_cost, items, total_tiles, n_cu, worklist);
+        }
         return;
     }
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, tile_cost, total_tiles, prefix);

@@ -41,6 +41,8 @@ def compare(dev, host, n_jobs_expected=None):
     (out_d, (list_d, tabs_d, on_dev)), (out_h, (list_h, tabs_h, on_dev_h)) = dev, host
     assert on_dev and not on_dev_h
     assert tabs_d.shape == tabs_h.shape and np.array_equal(tabs_d, tabs_h)
+    # (a single-round launch packed per XCD has idle positions: (0, -1), workgroups that exit at once)
+    list_d = list_d[list_d[:, 1] >= 0]
     assert list_d.shape == list_h.shape
     key = lambda a: np.sort(a[:, 0].astype(np.int64) * (1 << 32) + a[:, 1].astype(np.int64))
     assert np.array_equal(key(list_d), key(list_h))                      # the same workgroups, each exactly once
@@ -59,7 +61,37 @@ def test_single_round_cell_bin_packed(ctx):
     dev = run_layer(ctx, L, 1)
     host = run_layer(ctx, L, 0)
     compare(dev, host)
-    assert len(dev[1][0]) <= 1024
+    assert len(dev[1][0]) <= 2048
+    # the order of a single-round launch: workgroup p runs on XCD p % 8 and every XCD packs its own tiles into its own CUs.
+    # Below 3 workgroups per CU (this cell) an XCD's tiles are every 8th of the longest-first order; forced local
+    # (`accum_xcd_pack` 2) they are contiguous runs of the sequence, 1 per XCD or `accum_xcd_chunks`.  Idle positions: (0, -1).
+    def runs_per_xcd(lst):
+        assert len(lst) % 8 == 0
+        worst = 0
+        for x in range(8):
+            mine = lst[x::8]
+            tiles = np.sort(mine[mine[:, 1] >= 0][:, 1])
+            worst = max(worst, 1 + int(np.count_nonzero(np.diff(tiles) != 1)) if len(tiles) else 0)
+        return worst
+    assert runs_per_xcd(dev[1][0]) > 8
+    ctx.set_option("accum_xcd_pack", 2)
+    ctx.set_option("accum_xcd_tolerance", -1)
+    one = run_layer(ctx, L, 1)
+    assert runs_per_xcd(one[1][0]) == 1
+    compare(one, host)
+    ctx.set_option("accum_xcd_chunks", 4)
+    four = run_layer(ctx, L, 1)
+    ctx.set_option("accum_xcd_chunks", 0)
+    assert 1 < runs_per_xcd(four[1][0]) <= 4
+    compare(four, host)
+    ctx.set_option("accum_xcd_tolerance", 0)           # (whichever order the tolerance leaves this cell: a permutation again)
+    compare(run_layer(ctx, L, 1), host)
+    ctx.set_option("accum_xcd_tolerance", 3)
+    ctx.set_option("accum_xcd_pack", 0)                # round 4's order: one packing over all CUs, no idle positions
+    old = run_layer(ctx, L, 1)
+    ctx.set_option("accum_xcd_pack", 1)
+    assert np.all(old[1][0][:, 1] >= 0)
+    compare(old, host)
     L.free()
 
 
