@@ -197,6 +197,13 @@ int lbl_buffer_size(const lbl_buffer* buf, int64_t* n);
 int lbl_buffer_upload(lbl_buffer* buf, const double* host, int64_t n, int64_t dst_offset);
 int lbl_buffer_download(lbl_buffer* buf, double* host, int64_t n, int64_t src_offset);
 int lbl_buffer_fill(lbl_buffer* buf, double value);                    /* async */
+/* Download that does not wait: ordered behind everything enqueued on the context stream so far, carried out on the
+ * context's copy stream beside the kernels enqueued after it (pyrad_amd.model sends a column's outgoing spectrum -
+ * Atmosphere.transmission, pyradClasses.py:784-787 over all layers - home in pieces while the next piece is folded).
+ * `host` should be page-locked (lbl_host_alloc); the range must not be rewritten, nor `host` read, before
+ * lbl_download_wait (lbl_sync waits for these copies too).  Not capturable. */
+int lbl_buffer_download_async(lbl_buffer* buf, double* host, int64_t n, int64_t src_offset);
+int lbl_download_wait(lbl_ctx* ctx);
 /* Page-locked host memory for the arrays a caller keeps handing to upload / download: the copy then
  * runs at the link's DMA rate instead of through the runtime's staging of pageable memory (3-5x
  * faster for a spectrum of a few MB).  Plain memory otherwise; free it with lbl_host_free (ctx may be

@@ -71,6 +71,8 @@ SIGNATURES = {
     "lbl_buffer_upload": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "lbl_buffer_download": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "lbl_buffer_fill": (C.c_int, [_P, C.c_double]),
+    "lbl_buffer_download_async": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    "lbl_download_wait": (C.c_int, [_P]),
     "lbl_buffer_devptr": (C.c_int, [_P, C.POINTER(_P)]),
     "lbl_host_alloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "lbl_host_free": (C.c_int, [_P, _P]),
@@ -220,6 +222,9 @@ class Context:
 
     def sync(self):
         self.check(self.lib.lbl_sync(self.h))
+
+    def download_wait(self):
+        self.check(self.lib.lbl_download_wait(self.h))
 
     def stream(self) -> int:
         s = _P()
@@ -543,6 +548,15 @@ class Buffer:
         n = self.n - offset if n is None else int(n)
         out = self.ctx.host_array(n) if pinned else np.empty(n, dtype=np.float64)
         self.ctx.check(self.ctx.lib.lbl_buffer_download(self.h, _ptr(out), n, int(offset)))
+        return out
+
+    def download_async(self, out: np.ndarray, n: int, offset: int = 0, out_offset: int = 0):
+        """out[out_offset : out_offset + n] = self[offset : offset + n] without waiting (lbl_buffer_download_async: behind
+        the work enqueued so far, beside what is enqueued next); ``out`` from Context.host_array; Context.download_wait()
+        before reading it."""
+        if not (out.dtype == np.float64 and out.flags["C_CONTIGUOUS"] and 0 <= out_offset and out_offset + int(n) <= out.size):
+            raise ValueError("download_async needs a contiguous float64 array that holds the range")
+        self.ctx.check(self.ctx.lib.lbl_buffer_download_async(self.h, _ptr(out[out_offset:]), int(n), int(offset)))
         return out
 
     def fill(self, value: float):

@@ -38,6 +38,8 @@ struct DeviceArena {      // grow-only device scratch
 struct lbl_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;       // lbl_buffer_download_async: device-to-host copies beside later kernels
+    hipEvent_t copy_ev = nullptr;
     std::string err;
     int n_cu = 0;
     // scratch
@@ -390,6 +392,8 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) try {
     DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->bal, &ctx->red, &ctx->zeros, &ctx->sched, &ctx->merge_tmp, &ctx->ktmp};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return LBL_OK;
@@ -400,6 +404,7 @@ extern "C" const char* lbl_last_error(const lbl_ctx* ctx) { return ctx ? ctx->er
 extern "C" int lbl_sync(lbl_ctx* ctx) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->copy_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
     return LBL_OK;
 } LBL_GUARD_END(ctx)
 
@@ -635,6 +640,32 @@ extern "C" int lbl_buffer_download(lbl_buffer* buf, double* host, int64_t n, int
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return LBL_OK;
 } LBL_GUARD_END(buf ? buf->ctx : nullptr)
+
+// Download that does not wait: the copy is ordered behind everything enqueued on the context stream so far and runs on
+// the context's copy stream, beside the kernels enqueued after it (a column's outgoing spectrum leaves in pieces while the
+// fold of the next piece runs).  `host` should be page-locked (lbl_host_alloc) - pageable memory makes the runtime stage
+// the copy and the call blocks.  The range must not be rewritten, nor `host` read, before lbl_download_wait.
+extern "C" int lbl_buffer_download_async(lbl_buffer* buf, double* host, int64_t n, int64_t src_offset) try {
+    if (!buf) return fail(nullptr, LBL_ERR_BAD_ARG, "buf is NULL");
+    lbl_ctx* ctx = buf->ctx;
+    if (n < 0 || src_offset < 0 || n > buf->n - src_offset) return fail(ctx, LBL_ERR_BAD_ARG, "download range out of bounds");
+    if (n == 0) return LBL_OK;
+    if (!host) return fail(ctx, LBL_ERR_BAD_ARG, "host is NULL");
+    if (ctx->capturing) return capture_refuses(ctx, "an asynchronous download");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->copy_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->copy_ev, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->copy_ev, 0));
+    HIP_TRY(ctx, hipMemcpyAsync(host, buf->d + src_offset, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
+    return LBL_OK;
+} LBL_GUARD_END(buf ? buf->ctx : nullptr)
+
+extern "C" int lbl_download_wait(lbl_ctx* ctx) try {
+    if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
+    if (ctx->copy_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    return LBL_OK;
+} LBL_GUARD_END(ctx)
 
 extern "C" int lbl_buffer_fill(lbl_buffer* buf, double value) try {
     if (!buf) return fail(nullptr, LBL_ERR_BAD_ARG, "buf is NULL");

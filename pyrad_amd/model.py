@@ -1266,35 +1266,43 @@ class Atmosphere(list):
                 st = L.__dict__["_sweep_state"] = _SweepState(L)
             st.reserve(ctx, n)
             plan.append((L, st, g, members, flat, conc, L._merged_key(flat, conc, L, g)))
-        todo = [p for p in plan if p[1].key != p[6]]
+        # (a layer's absorption coefficient stands as long as everything but the depth is what it was computed from)
+        todo = [p for p in plan if not (isinstance(p[1].key, tuple) and p[1].key[:-1] == p[6][:-1])]
         ctx.layers_merged_accumulate_dev(
             [dict(lines=[i._device_lines(ctx) for i in flat], iso=[_iso_params(i) for i in flat],
                   grid=_engine.native_grid(g), iso_mol=[m for m, isos in enumerate(members) for _ in isos], conc=conc,
                   abs_coef=st.buf(ctx, "abs_coef")) for (L, st, g, members, flat, conc, key) in todo])
-        tmp = []
-        try:
-            # (the outgoing spectrum's buffer stays with the atmosphere: a hipMalloc + hipFree pair per call is 0.2 ms of a 5 ms call)
-            ast = self.__dict__.get("_toa_state")
-            if ast is None:
-                ast = self.__dict__["_toa_state"] = _SweepState(self)
-            out = ast.reserve(ctx, n).buf(ctx, "toa")
-            I_in = None
-            if surfaceSpectrum is not None:
-                I_in = ast.buf(ctx, "I_in").upload(np.ascontiguousarray(surfaceSpectrum, dtype=np.float64))
-            stale = {id(p[0]) for p in todo}
-            first = layers[0]
+        # (the outgoing spectrum's buffer stays with the atmosphere: a hipMalloc + hipFree pair per call is 0.2 ms of a 5 ms call)
+        ast = self.__dict__.get("_toa_state")
+        if ast is None:
+            ast = self.__dict__["_toa_state"] = _SweepState(self)
+        out = ast.reserve(ctx, n).buf(ctx, "toa")
+        I_in = None
+        if surfaceSpectrum is not None:
+            I_in = ast.buf(ctx, "I_in").upload(np.ascontiguousarray(surfaceSpectrum, dtype=np.float64))
+        first = layers[0]
+        # The fold in four pieces of the grid, each piece's part of the outgoing spectrum on its way to the host while the
+        # next piece is folded (19 MB at the link's rate are 0.4 ms of a 5 ms call).  No layer's transmittance is written
+        # (30 x 19 MB for arrays nobody has asked for): a layer's own getter makes it from the resident absorption
+        # coefficient, as after changeDepth (_ensure_swept: key equal up to its last entry).
+        host = ctx.host_array(n)
+        pieces = 4 if n >= (1 << 16) else 1
+        step = max(((n + pieces - 1) // pieces + 1) & ~1, 2)
+        for lo in range(0, n, step):
+            cnt = min(step, n - lo)
             ctx.column_fold_dev([p[1].bufs["abs_coef"] for p in plan], [p[0].T for p in plan], [p[0].depth for p in plan],
                                 first.rangeMin, first.rangeMax, n, out, I_in=I_in, surface_T=float(surfaceTemperature or 0.0),
-                                trans=[p[1].buf(ctx, "trans") if id(p[0]) in stale else None for p in plan])
-            for (L, st, g, members, flat, conc, key) in todo:
-                st.key = key
-                for iso in flat:
-                    iso._defer_cross_section()
-                L._members_ready()
-            return out.download(n, pinned=True)
-        finally:
-            for b in tmp:
-                b.free()
+                                first=lo, count=cnt)
+            out.download_async(host, cnt, lo, lo)
+        for (L, st, g, members, flat, conc, key) in plan:
+            if st.key != key:
+                st.key = key[:-1] + ("absorption coefficient only",)
+        for (L, st, g, members, flat, conc, key) in todo:
+            for iso in flat:
+                iso._defer_cross_section()
+            L._members_ready()
+        ctx.download_wait()
+        return host
 
 
 # ----------------------------------------------------------------------------------------

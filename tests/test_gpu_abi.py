@@ -406,3 +406,31 @@ def test_line_view_bounds_cannot_overflow(ctx):
     assert ctx.lib.lbl_lines_view(L.h, 50, 2**63 - 1, nat.C.byref(h)) == -1
     assert ctx.lib.lbl_lines_view(L.h, 2**62, 2**62, nat.C.byref(h)) == -1
     L.free()
+
+
+def test_asynchronous_download_lands_behind_the_work_before_it(ctx):
+    """lbl_buffer_download_async / lbl_download_wait: pieces of a buffer leave for page-locked memory behind the kernels
+    enqueued before each call and beside those enqueued after it; lbl_sync waits for them too; bad ranges are refused."""
+    from pyrad_amd import _native as nat
+    n = 300001
+    rng = np.random.default_rng(11)
+    a = rng.random(n)
+    buf = ctx.buffer(n).upload(a)
+    total = ctx.buffer(n)
+    host = ctx.host_array(n)
+    host[:] = -1.0
+    for lo, cnt in ((0, 100000), (100000, 100000), (200000, 100001)):
+        ctx.sum_dev([buf, buf], n, total)                      # (a kernel on the context stream before every piece)
+        total.download_async(host, cnt, lo, lo)
+        buf.fill(0.0) if lo == 200000 else None                # later work on ANOTHER buffer does not disturb the copies
+    ctx.download_wait()
+    assert np.array_equal(host, a + a)
+    host[:] = -1.0
+    total.download_async(host, n)
+    ctx.sync()                                                 # (lbl_sync covers the copy stream)
+    assert np.array_equal(host, a + a)
+    with pytest.raises(nat.LblError):
+        total.download_async(host, n, 1)                       # range past the end of the buffer
+    with pytest.raises(ValueError):
+        total.download_async(host[:10], 11)
+    total.free(); buf.free()
