@@ -243,7 +243,7 @@ def api_path(cfg, reps=5):
         engine.shutdown()
 
 
-def api_path_column(cfg, reps=3):
+def api_path_column(cfg, reps=5):
     """The drop-in route for the column: pyrad_amd.model's Atmosphere -> addLayer -> addMolecule ->
     Atmosphere.transmission(surfaceTemperature) on the bench column, host array out.  ms_per_call = one
     transmission after every layer's changeTemperature has invalidated its cross sections: all layers' line
@@ -289,7 +289,8 @@ def api_path_column(cfg, reps=3):
             t0 = time.perf_counter()
             spec = atm.transmission(surfaceTemperature=cfg["surface_T"])
             t_get.append(time.perf_counter() - t0)
-        return {"ms_per_call": ms_call, "evals_per_s": evals / (ms_call * 1e-3), "ms_build_atmosphere": 1e3 * t_build,
+        return {"ms_per_call": ms_call, "ms_calls": [round(1e3 * t, 4) for t in t_call],
+                "evals_per_s": evals / (ms_call * 1e-3), "ms_build_atmosphere": 1e3 * t_build,
                 "ms_engine_create": 1e3 * t_engine,
                 "ms_change_pressure": 1e3 * float(np.median(t_get)), "ms_change_pressure_mutator": 1e3 * float(np.median(t_mut)),
                 "rewindow_what": "Atmosphere.transmission AFTER changePressure on every layer (new windows: new line selections, "
@@ -297,8 +298,10 @@ def api_path_column(cfg, reps=3):
                                  "changePressure calls themselves" % len(cfg["layers"]),
                 "ms_first_call": 1e3 * t_first, "bytes_downloaded_per_call": 8 * int(spec.size),
                 "what": "model.Atmosphere.transmission(surfaceTemperature) after changeTemperature on all %d layers "
-                        "(recompute on resident line lists, column step, download of the outgoing spectrum); median of %d; "
-                        "checks: %d points, finite %s" % (len(cfg["layers"]), reps, spec.size, bool(np.isfinite(spec).all()))}
+                        "(recompute on resident line lists, one accumulate job per layer, the fold in four pieces with the outgoing "
+                        "spectrum downloaded beside the next piece); median of %d consecutive calls, all of them in ms_calls (the "
+                        "first calls after the idle set-up run at lower clocks: the timed loop above preconditions for that, this "
+                        "leg does not); checks: %d points, finite %s" % (len(cfg["layers"]), reps, spec.size, bool(np.isfinite(spec).all()))}
     finally:
         settings.set_resolution_multiplier(keep[0])
         data.set_source(keep[1])

@@ -49,5 +49,9 @@ col.free()
 pr = cProfile.Profile()
 for L in atm: L.changeTemperature(L.T)
 pr.enable(); atm.transmission(surfaceTemperature=288); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(12); print(s.getvalue())
+st = pstats.Stats(pr)
+rows = sorted(((v[2], v[3], v[0], "%s:%d %s" % (os.path.basename(k[0]), k[1], k[2])) for k, v in st.stats.items()), reverse=True)
+print("own us | cumulative us | calls | function")
+for own, cum, calls, name in rows[:22]:
+    print("%8.0f %8.0f %6d  %s" % (1e6 * own, 1e6 * cum, calls, name))
 engine.shutdown()
