@@ -135,7 +135,8 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *                            (all-direct instantiation) | 2 EVERY job through the skewed-range kernel (parity tests)
  *   "accum_skew_points_per_lane"  1 | 2 | 4 | 8 (default)
  *   "accum_xcd_chunks"       XCD-partitioned order ("accum_longest_first" 4): contiguous chunks of the tile sequence per
- *                            XCD, 0 (default: about 29 workgroups per chunk, 10..32 chunks) .. 64
+ *                            XCD, 0 (default: about 29 workgroups per chunk, 10..32 chunks) .. 64; for a launch of one
+ *                            round: the contiguous runs per XCD of "accum_xcd_pack" (default 1, at most 16)
  *   "accum_xcd_pack"         launches of one round (at most 4 workgroups per CU; device-built schedules): every XCD packs its own
  *                            tiles into its own CUs.  1 (default): where every wave owns a span (no line split) an XCD's tiles
  *                            are a contiguous run of the sequence worth an eighth of the cost (its L2 then holds that run's

@@ -126,6 +126,35 @@ def test_lopsided_costs_take_the_global_sort(ctx):
     L.free()
 
 
+def test_single_round_runs_that_do_not_fit_fall_back_to_the_mix(ctx):
+    """one round of workgroups whose cost sits in a few tiles (all lines within half a wavenumber of a 100 cm^-1 grid): a
+    contiguous run worth an eighth of the cost would hold half of the tiles - more than the positions reserved per XCD - so
+    the packing kernel falls back to the longest-first mix by itself; forced either way the result is the host's"""
+    from pyrad_amd import engine
+    base = synthetic.make_lines(78, 4000, 650.0, 650.5)
+    mol = dict(conc=4e-4, isotopologues=[dict(lines=base, molmass=synthetic.SPECIES["co2"]["molmass"],
+                                              q_T=synthetic.q_value("co2", 296), q296=synthetic.SPECIES["co2"]["q296"])])
+    L = engine.ResidentLayer(ctx, 10.0, 296, 1013.25, 600.0, 700.0, [mol], .001, False)
+    ctx.set_option("accum_line_split", 1)
+    host = run_layer(ctx, L, 0)
+    for pack, tol in ((2, -1), (2, 3), (3, 3), (1, 3), (0, 3)):
+        ctx.set_option("accum_xcd_pack", pack)
+        ctx.set_option("accum_xcd_tolerance", tol)
+        dev = run_layer(ctx, L, 1)
+        compare(dev, host)
+        lst = dev[1][0]
+        real = lst[lst[:, 1] >= 0]
+        assert len(real) == len(host[1][0])
+        if pack == 2:
+            # fell back: no XCD holds a contiguous run of the sequence
+            mine = np.sort(lst[0::8][lst[0::8][:, 1] >= 0][:, 1])
+            assert len(mine) > 2 and np.count_nonzero(np.diff(mine) != 1) > 0
+    ctx.set_option("accum_xcd_pack", 1)
+    ctx.set_option("accum_xcd_tolerance", 3)
+    ctx.set_option("accum_line_split", 0)
+    L.free()
+
+
 def test_column_groups(ctx):
     """a 6-layer column, 1013 -> 20 mbar: the wide layers' group (far-field kernel) and the narrow layers' group
     (skewed-range kernel) get a device-built schedule each; every layer's arrays and the outgoing spectrum agree"""
