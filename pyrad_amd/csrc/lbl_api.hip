@@ -156,7 +156,8 @@ struct lbl_lines {
     lbl_ctx* ctx;
     double* d;        // 7 arrays of `stride` doubles: nu, sw, elower, gamma_air, gamma_self, n_air, delta_air (a view: offset into its root's)
     int64_t n;
-    std::vector<double> host_nu;   // for scheduling only: longest-first tile order (never used for results)
+    std::vector<double> host_nu_own;   // for scheduling only: longest-first tile order (never used for results)
+    const double* host_nu = nullptr;   // ... the owning list's copy; a view points into its root's (which outlives it: `views`)
     uint64_t serial;               // identity for the schedule cache
     int64_t stride = 0;            // distance between the field arrays: the OWNING list's line count
     lbl_lines* root = nullptr;     // a view (lbl_lines_view): the list that owns the device arrays
@@ -725,9 +726,10 @@ extern "C" int lbl_lines_create(lbl_ctx* ctx, const double* nu, const double* sw
     TraceScope tr("lines_create", (long long)n_lines);
     // host-side allocations first: if they throw, nothing on the device has to be released
     std::vector<double> host_nu(nu, nu + n_lines);
-    lbl_lines* L = new (std::nothrow) lbl_lines{ctx, nullptr, n_lines, {}, 0};
+    lbl_lines* L = new (std::nothrow) lbl_lines{ctx, nullptr, n_lines, {}, nullptr, 0};
     if (!L) return fail(ctx, LBL_ERR_OOM, "host allocation failed");
-    L->host_nu.swap(host_nu);
+    L->host_nu_own.swap(host_nu);
+    L->host_nu = L->host_nu_own.data();
     L->stride = n_lines;
     double* d = nullptr;
     {
@@ -754,10 +756,9 @@ extern "C" int lbl_lines_view(lbl_lines* parent, int64_t first, int64_t count, l
     *out = nullptr;
     if (first < 0 || count < 0 || first > parent->n || count > parent->n - first) return fail(ctx, LBL_ERR_BAD_ARG, "view outside the line list");
     lbl_lines* root = parent->root ? parent->root : parent;
-    std::vector<double> host_nu(parent->host_nu.begin() + first, parent->host_nu.begin() + first + count);
-    lbl_lines* V = new (std::nothrow) lbl_lines{ctx, parent->d + first, count, {}, 0};
+    lbl_lines* V = new (std::nothrow) lbl_lines{ctx, parent->d + first, count, {}, nullptr, 0};
     if (!V) return fail(ctx, LBL_ERR_OOM, "host allocation failed");
-    V->host_nu.swap(host_nu);
+    V->host_nu = parent->host_nu ? parent->host_nu + first : nullptr;        // (no copy: 1 MB and 0.1 ms per view of 131,072 lines, 90 views per re-windowed column)
     V->stride = root->stride;
     V->root = root;
     V->serial = ++ctx->lines_serial;
