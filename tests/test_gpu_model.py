@@ -502,3 +502,43 @@ def test_atmosphere_transmission_merged_equals_per_list(pyrad):
     finally:
         settings.set_layer_step("merged")
     assert rel_err(atm.transmission(surfaceTemperature=288), ref2) <= 1e-12
+
+
+def test_atmosphere_transmission_in_pieces_equals_one_pass(pyrad):
+    """a column wide enough (100,001 points) for Atmosphere.transmission to fold it in four pieces, each piece's part of
+    the outgoing spectrum downloaded beside the next piece (lbl_buffer_download_async): the same spectrum as the per-list
+    route's one pass, with a surface temperature and with a surface spectrum; a second call reuses the resident buffers"""
+    from pyrad_amd import settings
+    lines = dict(co2=synthetic.make_lines(61, 3000, 590, 710), h2o=synthetic.make_lines(62, 2000, 590, 710))
+    source(**lines)
+    keep = settings.RES_MULTIPLIER
+    settings.set_resolution_multiplier(0.1)               # base resolution 0.001 cm^-1
+
+    def build():
+        pyrad.Layer.hasAtmosphere = False
+        atm = pyrad.Atmosphere("col")
+        for depth, T, P in ((1e4, 288, 1013.25), (3e4, 260, 500.0), (8e4, 230, 120.0)):
+            L = atm.addLayer(depth, T, P, 600, 700)
+            L.addMolecule('co2', ppm=400)
+            L.addMolecule('h2o', percentage=0.4)
+        return atm
+
+    try:
+        settings.set_layer_step("per-list")
+        try:
+            ref_atm = build()
+            ref = np.array(ref_atm.transmission(surfaceTemperature=288))
+            surf = np.array(ref_atm[0].planck(300))
+            ref_s = np.array(ref_atm.transmission(surfaceSpectrum=surf))
+        finally:
+            settings.set_layer_step("merged")
+        atm = build()
+        got = np.array(atm.transmission(surfaceTemperature=288))
+        assert got.size >= (1 << 16) and got.size == ref.size
+        assert np.all(np.isfinite(got)) and rel_err(got, ref) <= 1e-12
+        assert rel_err(atm.transmission(surfaceSpectrum=surf), ref_s) <= 1e-12
+        assert np.array_equal(atm.transmission(surfaceTemperature=288), got)
+        k = np.array(pyrad.getAbsCoef(atm[1]))
+        assert rel_err(pyrad.getTransmittance(atm[1]), np.exp(-k * atm[1].depth), floor=1e-300) <= 1e-9
+    finally:
+        settings.set_resolution_multiplier(keep)
