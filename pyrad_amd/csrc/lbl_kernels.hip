@@ -803,13 +803,21 @@ template <bool MASKED>
 __device__ __forceinline__ void gauss_runs16(const double* __restrict__ lh, const double* __restrict__ lc,
                                              unsigned long long m, double xrun, double Hf, int lane, double (&G)[16]) {
     const int q = lane >> 4;
-    while (m) {
-        const int j0 = __builtin_ctzll(m); m &= m - 1;
-        const int j1 = m ? __builtin_ctzll(m) : -1; m &= m - (m ? 1ull : 0ull);
-        const int j2 = m ? __builtin_ctzll(m) : -1; m &= m - (m ? 1ull : 0ull);
-        const int j3 = m ? __builtin_ctzll(m) : -1; m &= m - (m ? 1ull : 0ull);
-        const int j = q == 0 ? j0 : q == 1 ? j1 : q == 2 ? j2 : j3;
-        const int jj = j < 0 ? j0 : j;
+    // The records of the mask as a list of bytes in the wave's LDS (behind the staged records), built once: every pass then
+    // reads its four record numbers (one ds_read_u8 per lane) instead of scanning the mask with ~32 scalar instructions -
+    // which are not free: each takes an issue slot of its wave (round 5: merged C3 K2 243.5 -> 238.7 us, bit-identical).
+    unsigned char* list = reinterpret_cast<unsigned char*>(const_cast<double*>(lh) + 512);
+    const int cnt = __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if ((m >> lane) & 1ull)
+        list[__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u))] = (unsigned char)lane;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int j_first = __builtin_ctzll(m);
+    for (int p = 0; p < cnt; p += 4) {
+        const int slot = p + q;
+        const int j = slot < cnt ? (int)list[slot] : -1;
+        const int jj = j < 0 ? j_first : j;
         const double cf = lh[jj * 4];
         const double* c = lc + jj * 4;
         const double KG = j < 0 ? 0.0 : c[0], b = c[1], q2 = c[2];
@@ -1550,7 +1558,7 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
     constexpr int PG = NW / LS;                      // point groups (64*R points each) per workgroup
     // per wave: hot records [0,256), cold records [256,512); after the line loop the same words
     // hold the wave's 64*R sums in point order (+ padding) for the coalesced store
-    constexpr int STAGE_MIN = FF ? 576 : 512;        // FF: 8 x 72 doubles for wave_sum_rows
+    constexpr int STAGE_MIN = FF ? 576 : 520;        // FF: 8 x 72 doubles for wave_sum_rows; else 512 + the 64-byte record list of gauss_runs16
     constexpr int STAGE = (68 * R > STAGE_MIN) ? 68 * R : STAGE_MIN;
     __shared__ double s_stage[NW][STAGE];
     // edge lines through the skewed walk (skew_edges): the production shape only (unsplit spans of 256 points)
