@@ -750,7 +750,8 @@ __device__ __forceinline__ HotVals lds_hot(const double* __restrict__ lh, int j)
 // Lorentz terms of records j0..j1-1 of the chunk parked in this wave's LDS, as a branch-free
 // running-fraction loop: per point  d = d0+k, den = d*d+a2, t = K*D, N = N*den+t, D = D*den.
 // The NEXT record's broadcast read is issued before the current record's arithmetic, so the LDS
-// latency hides under the 5*R fp64 instructions (slot 63 is re-read harmlessly at the chunk end).
+// latency hides under the 5*R fp64 instructions (at the chunk end that read lands in the cold records behind slot 63 - at most
+// `step` slots further, inside the wave's staging area - and is dropped: no clamp, the address just counts up).
 // The flush test sits outside the inner loop (blocks of at most `every` lines), and Gaussian /
 // plain-divide lines are handled after the chunk from bit masks, so the hot loop has no branch.
 template <int R, bool MASKED>
@@ -765,7 +766,7 @@ __device__ __forceinline__ void rf_segment(const double* __restrict__ lh, int j0
 #pragma unroll 2
         for (int t = 0; t < nb; ++t) {
             const HotVals cur = nxt;
-            nxt = lds_hot(lh, min(j + (t + 1) * step, 63));
+            nxt = lds_hot(lh, j + (t + 1) * step);      // (past the chunk's last record: words of the cold records, read and never used)
             const double d0 = x0 - cur.cf;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
@@ -1167,18 +1168,21 @@ __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec
         double qb = al * qa;
         C[1] += qb;
         // the chunk's nearest line (centres are sorted and a call stays on one side of the span: the first or the last
-        // valid lane) decides how many terms the whole chunk takes; wave-uniform branch
+        // valid lane) decides how many terms the whole chunk takes; wave-uniform branches.  In integers (a centre is an
+        // integer, xc = wlo + 32 R - 1/2): dmin2 = 2 |c - xc| from two v_readlane and scalar arithmetic instead of four
+        // v_readlane and six fp64 vector instructions; the class limits are d half-spans = 32 R d points.
         const int nv = min(64, m1 - c0);
-        const double dmin = fmin(fabs(readlane_f64(w0.x, 0) - xc), fabs(readlane_f64(w0.x, nv - 1) - xc));
+        const int ca = __builtin_amdgcn_readlane(ci, 0), cb = __builtin_amdgcn_readlane(ci, nv - 1);
+        const int dmin2 = min(abs(2 * (ca - wlo) - (64 * R - 1)), abs(2 * (cb - wlo) - (64 * R - 1)));
         typedef FarTerms<NT> FT;
         series_terms<2, FT::t32, NT>(al, bp, qa, qb, C);
-        if (dmin < 32.0 * hh) {
+        if (dmin2 < 2 * 32 * 32 * R) {
             series_terms<FT::t32, FT::t16, NT>(al, bp, qa, qb, C);
-            if (dmin < 16.0 * hh) {
+            if (dmin2 < 2 * 16 * 32 * R) {
                 series_terms<FT::t16, FT::t8, NT>(al, bp, qa, qb, C);
-                if (dmin < 8.0 * hh) {
+                if (dmin2 < 2 * 8 * 32 * R) {
                     series_terms<FT::t8, FT::t4, NT>(al, bp, qa, qb, C);
-                    if (FT::t4 < NT && dmin < 4.0 * hh) series_terms<FT::t4, NT, NT>(al, bp, qa, qb, C);
+                    if (FT::t4 < NT && dmin2 < 2 * 4 * 32 * R) series_terms<FT::t4, NT, NT>(al, bp, qa, qb, C);
                 }
             }
         }
