@@ -1035,8 +1035,10 @@ template <int NT> struct FarThreshold { static constexpr int value = NT == FF_NT
 template <int CTRL>
 __device__ __forceinline__ double dpp_move_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    // (bound_ctrl with full row and bank masks: a lane without a source reads 0 and the compiler needs no preset of the
+    // destination - with bound_ctrl off every 64-bit move cost two extra v_mov_b32 0; round 6)
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -1374,36 +1376,40 @@ __device__ __forceinline__ void skew_edges(const HotRec* hot, const ColdRec* col
 // the far lines' series phase, so that its NTE coefficients and that phase's NT are never live together.
 // NTE terms: by the distance of the job's nearest edge line, H - 32 R points (FarTerms classes: 20 / 15 / 12 from 8 / 16 / 32
 // half-spans on, exact to half an ulp); nearer than 8 half-spans 30 terms would cost what the walk costs: the walk stays.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_move_rows_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-// inclusive prefix sum over the 64 lanes (lanes without a source add 0); fixed summation tree
-__device__ __forceinline__ double wave_prefix_sum_f64(double v) {
-    v += dpp_move_rows_f64<0x111, 0xf>(v);      // row_shr:1
-    v += dpp_move_rows_f64<0x112, 0xf>(v);      // row_shr:2
-    v += dpp_move_rows_f64<0x114, 0xf>(v);      // row_shr:4
-    v += dpp_move_rows_f64<0x118, 0xf>(v);      // row_shr:8
-    v += dpp_move_rows_f64<0x142, 0xa>(v);      // row_bcast:15 -> rows 1, 3
-    v += dpp_move_rows_f64<0x143, 0xc>(v);      // row_bcast:31 -> rows 2, 3
+// inclusive prefix sum over the 64 lanes (lanes without a source add 0); fixed summation tree.  The two steps across rows
+// fetch with full masks and are switched on per row by a factor (m15: 1.0 in rows 1 and 3, m31: 1.0 in rows 2 and 3, else
+// 0.0; x * 1.0 is exact and the values are finite, so the sums are those of masked moves) - a DPP move under a partial row
+// mask needs its destination preset, two more instructions per step.
+__device__ __forceinline__ double wave_prefix_sum_f64(double v, double m15, double m31) {
+    v += dpp_move_f64<0x111>(v);                // row_shr:1
+    v += dpp_move_f64<0x112>(v);                // row_shr:2
+    v += dpp_move_f64<0x114>(v);                // row_shr:4
+    v += dpp_move_f64<0x118>(v);                // row_shr:8
+    v = fma(dpp_move_f64<0x142>(v), m15, v);    // row_bcast:15 -> rows 1, 3
+    v = fma(dpp_move_f64<0x143>(v), m31, v);    // row_bcast:31 -> rows 2, 3
     return v;
 }
 
-template <int R, int NTE>
+template <int R>
 __device__ __forceinline__ void series_edges(const HotRec* hot, const ColdRec* cold, int iA, int iB, int iC, int iD, int wlo,
-                                             int whi, int H, double x0, double Hf, double xc, double* lh, double* lc,
+                                             int whi, int H, double x0, double Hf, double xc, int nte, double* lh, double* lc,
                                              unsigned int* cntL, unsigned int* cntR, int lane, WaveAcc<R>& S, unsigned long long& odd) {
-    double C[NTE];                                       // this lane's coefficients of the edge lines' polynomial
+    // Round 6: no coefficient array.  The polynomial of the edge lines is summed in ASCENDING powers as the terms come -
+    // v_k += p_n tau_k^n with a running power per point - so a lane keeps 3 R doubles (tau, tau^n, v) instead of NTE
+    // coefficients, both sides share one pass, and the term loop is a real loop with a run-time count (one body instead of
+    // three unrolled instantiations).  |tau| < 1 and the p_n fall by at least 8x per term (edge lines are >= 8 half-spans
+    // away), so the ascending sum is as accurate as Horner's.  With the coefficient array the kernel needed 162 VGPRs,
+    // spilled 35 at its 128 and wrote the wave's sums to scratch in every round (round-5 verdict: 625 MB of stores on
+    // the column where 250 MB are compulsory).
+    double tau[R], v[R];
 #pragma unroll
-    for (int n = 0; n < NTE; ++n) C[n] = 0.0;
+    for (int k = 0; k < R; ++k) { tau[k] = ((x0 + (double)k) - xc) * (1.0 / (32.0 * R)); v[k] = 0.0; }
     typedef double v2f64 __attribute__((ext_vector_type(2)));
     typedef const v2f64 __attribute__((address_space(1)))* GlobalF64x2;
     const GlobalF64x2 gh = (GlobalF64x2)(unsigned long long)hot;
     constexpr int SENT = 128;                             // records 0..63: left-edge, 64..127: right-edge, 128: the sentinel
     constexpr double hh = 32.0 * R;
+    const double m15 = (lane & 16) ? 1.0 : 0.0, m31 = (lane & 32) ? 1.0 : 0.0;
     auto slot = [&](int c, int base) { const int i = c - base + 1; return i < 0 ? 0 : (i > 64 * R + 1 ? 64 * R + 1 : i); };
     int round = 0;
     for (int cL = iA, cR = iC; (cL < iB || cR < iD) && round < 64; cL += 64, cR += 64, ++round) {
@@ -1440,46 +1446,56 @@ __device__ __forceinline__ void series_edges(const HotRec* hot, const ColdRec* c
         skew_counts<R>(cntL, lane, a_part, a_full);
         skew_counts<R>(cntR, lane, b_full, b_part);
         // lines covering all of the lane's points: left-edge [a_full, nL) = the lanes 0 .. nL-1-a_full of the reversed
-        // order, right-edge [0, b_full) = the lanes 0 .. b_full-1.  One side after the other (registers).
-        auto side = [&](double cf, double a2, double K, int g) {
-            const bool has = g >= 0;
-            const int src = has ? g : 0;
+        // order, right-edge [0, b_full) = the lanes 0 .. b_full-1
+        const int gL = nL - 1 - a_full, gR = b_full - 1;
+        const double hasL = gL >= 0 ? 1.0 : 0.0, hasR = gR >= 0 ? 1.0 : 0.0;
+        const int srcL = max(gL, 0), srcR = max(gR, 0);
+        double alL, bpL, qaL, qbL, alR, bpR, qaR, qbR;
+        auto start = [&](double cf, double a2, double K, double& al, double& bp, double& qa, double& qb) {
             const double dl = cf - xc, sq = fma(dl, dl, a2);
             double be = __builtin_amdgcn_rcp(sq);
             be = fma(fma(-sq, be, 1.0), be, be);
             be = fma(fma(-sq, be, 1.0), be, be);
-            const double al = (dl * (2.0 * hh)) * be, bp = (hh * hh) * be;
-            double qa = K * be, qb = al * qa;
-            auto deposit = [&](double q, double& Cn) {
-                const double p = __shfl(wave_prefix_sum_f64(q), src, 64);
-                Cn += has ? p : 0.0;
-                // (the scheduler may not run the whole chain of q_n ahead of the scans: NTE more live values, spilled)
-                asm volatile("" : "+v"(Cn));
-            };
-            deposit(qa, C[0]);
-            deposit(qb, C[1]);
-#pragma unroll
-            for (int n = 2; n < NTE; ++n) {
-                const double qn = fma(al, qb, -(bp * qa));
-                deposit(qn, C[n]);
-                qa = qb; qb = qn;
-            }
+            al = (dl * (2.0 * hh)) * be; bp = (hh * hh) * be;
+            qa = K * be; qb = al * qa;
         };
-        side(l0.x, l0.y, vL ? l1.x : 0.0, nL - 1 - a_full);
-        side(r0.x, r0.y, vR ? r1.x : 0.0, b_full - 1);
+        start(l0.x, l0.y, vL ? l1.x : 0.0, alL, bpL, qaL, qbL);
+        start(r0.x, r0.y, vR ? r1.x : 0.0, alR, bpR, qaR, qbR);
+        // sum over the lines that cover this lane's points, of term n of their series: the prefix sums of both sides,
+        // each lane picking its own (left first, then right: fixed order)
+        auto pick = [&](double qL, double qR) {
+            const double pL = __shfl(wave_prefix_sum_f64(qL, m15, m31), srcL, 64);
+            const double pR = __shfl(wave_prefix_sum_f64(qR, m15, m31), srcR, 64);
+            return fma(pR, hasR, pL * hasL);
+        };
+        double pw[R];
+        {
+            const double p0 = pick(qaL, qaR), p1 = pick(qbL, qbR);
+#pragma unroll
+            for (int k = 0; k < R; ++k) { v[k] += p0; pw[k] = tau[k]; v[k] = fma(p1, pw[k], v[k]); }
+        }
+        // q_n = al q_(n-1) - bp q_(n-2) written over q_(n-2): two terms per trip, so that the pair (q_(n-2), q_(n-1)) never moves
+        auto term = [&](double& oldL, double newestL, double& oldR, double newestR) {
+            oldL = fma(alL, newestL, -(bpL * oldL));
+            oldR = fma(alR, newestR, -(bpR * oldR));
+            const double p = pick(oldL, oldR);
+#pragma unroll
+            for (int k = 0; k < R; ++k) { pw[k] *= tau[k]; v[k] = fma(p, pw[k], v[k]); }
+        };
+        int n = 2;
+#pragma clang loop unroll(disable)
+        for (; n + 1 < nte; n += 2) {
+            term(qaL, qbL, qaR, qbR);
+            term(qbL, qaL, qbR, qaR);
+        }
+        if (n < nte) term(qaL, qbL, qaR, qbR);
         // the 0-2 lines per lane that cover only some of its points: the masked walk, folded in at once
         int it = 0;
         skew_lorentz<R, true, true>(lh, SENT, a_part, a_full - a_part, 64 + b_full, b_part - b_full, x0, Hf, S, it);
         S.flush();
     }
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const double tau = ((x0 + (double)k) - xc) * (1.0 / (32.0 * R));
-        double v = C[NTE - 1];
-#pragma unroll
-        for (int n = NTE - 2; n >= 0; --n) v = fma(v, tau, C[n]);
-        S.acc[k] += v;
-    }
+    for (int k = 0; k < R; ++k) S.acc[k] += v[k];
 }
 
 // Fused sweep of a layer with ONE line list (lbl_layer_step_dev): the arithmetic and operation order of
@@ -1554,8 +1570,11 @@ __device__ __forceinline__ void edge_rounds_masked(const HotRec* hot, const Cold
     }
 }
 
+#ifndef LBL_FF_WPS
+#define LBL_FF_WPS 4      // waves per SIMD the production shape of the far-field kernel is built for (A/B builds: 3 = 168 VGPRs)
+#endif
 template <int R, int LS, int NT = 0>                                                     // NT: far-field series terms (0: every pair direct)
-__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), (R >= 4 ? 4 : 1))                // HIP: min waves per SIMD
+__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), (R >= 4 ? (NT > 0 && R == 4 && LS == 1 ? LBL_FF_WPS : 4) : 1))   // HIP: min waves per SIMD
 void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* __restrict__ worklist) {
     constexpr bool FF = NT > 0;
     constexpr int NW = LS > 4 ? LS : 4;              // wavefronts per workgroup (LS = 8: 512 threads)
@@ -1647,12 +1666,9 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
             // series from 42 / 49 / 62 edge lines per span on (a merged 100-2500 cm^-1 span has 84, one of its line lists 28:
             // measured on the per-list step, series for everything: K2 +4.5 %)
             const int n_edge = (iB - iA) + (iD - iC);
-            if (EDGE_SERIES && dmin >= 32 * 32 * R && n_edge * 21 >= 52 * FT::t32 + 250)
-                series_edges<R, FT::t32>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, xc, lh, lc, eL, eR, lane, S, odd);
-            else if (EDGE_SERIES && dmin >= 16 * 32 * R && dmin < 32 * 32 * R && n_edge * 21 >= 52 * FT::t16 + 250)
-                series_edges<R, FT::t16>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, xc, lh, lc, eL, eR, lane, S, odd);
-            else if (EDGE_SERIES && dmin >= 8 * 32 * R && dmin < 16 * 32 * R && n_edge * 21 >= 52 * FT::t8 + 250)
-                series_edges<R, FT::t8>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, xc, lh, lc, eL, eR, lane, S, odd);
+            const int nte = dmin >= 32 * 32 * R ? FT::t32 : dmin >= 16 * 32 * R ? FT::t16 : FT::t8;
+            if (EDGE_SERIES && dmin >= 8 * 32 * R && n_edge * 21 >= 52 * nte + 250)
+                series_edges<R>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, xc, nte, lh, lc, eL, eR, lane, S, odd);
             else
                 skew_edges<R>(J.hot, J.cold, iA, iB, iC, iD, wlo, whi, H, x0, Hf, lh, lc, eL, eR, lane, S, odd);
             if (odd || iB - iA > 64 * 64 || iD - iC > 64 * 64)
