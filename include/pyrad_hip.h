@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LBL_ABI_VERSION 4
+#define LBL_ABI_VERSION 5
 
 typedef enum lbl_status {
     LBL_OK = 0,
@@ -85,6 +85,14 @@ typedef struct lbl_grid {
 
 /* ---- library / context ------------------------------------------------------------- */
 int lbl_abi_version(void);
+/* Fixed sizes of the library (ABI 5), so that a host can choose a route instead of running into LBL_ERR_BAD_ARG:
+ *   "merged_lists_per_job"  line lists one merged layer job takes (lbl_layer_merged_step_dev, lbl_layers_merged_accumulate_dev): 64
+ *   "arrays_per_layer"      cross-section arrays of lbl_layer_sweep_dev / line lists of lbl_layer_step_dev: 511 (the reference
+ *                           sums however many isotopologues a layer holds, pyradClasses.py:566-571, 707-712; HITRAN has ~160)
+ *   "arrays_per_sum"        inputs of lbl_sum_dev: 64 (a longer sum is chained: the partial sum first)
+ *   "arrays_per_column"     terms of lbl_column_step_dev: 511      "layers_per_column": 128      "jobs_per_batch": LBL_MAX_JOBS
+ * Unknown name: LBL_ERR_BAD_ARG. */
+int lbl_limit(const char* name, int64_t* value);
 int lbl_device_count(int* count);
 int lbl_ctx_create(int device, lbl_ctx** out);
 int lbl_ctx_destroy(lbl_ctx* ctx);
@@ -150,6 +158,10 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *   "accum_skew_line_split"  0 (default: by the lines per grid point) | 1 | 2 | 4 waves of a workgroup share one span of the
  *                            skewed-range kernel and deal its records (dense, merged line lists: a chunk of records
  *                            then covers the span again)
+ *   "accum_gauss_run"        far-field kernel, production shape (4 points per lane, unsplit spans): points a lane walks per Gaussian
+ *                            run.  16: two exp per 16 points, 128 VGPRs, four waves per SIMD | 32: two exp per 32 points, 164
+ *                            VGPRs, three waves per SIMD (the 100-2500 cm^-1 cell: -4 %; a launch that fits one round of the
+ *                            chip's wave slots: +4 %) | 0 (default): 32 for launches of more than 16 waves per CU, else 16
  *   "accum_far_min_window"   windows below this many points take the skewed-range kernel even where the far-field
  *                            kernel could run them (0, the default: its own limit, 640; measured flat up to 1000)
  *   "debug_ablate"           ONLY in diagnostic builds of the library (make EXTRA=-DLBL_DIAG): timing experiments,

@@ -51,6 +51,7 @@ _D = C.POINTER(C.c_double)
 # name -> (restype, argtypes): every symbol include/pyrad_hip.h declares
 SIGNATURES = {
     "lbl_abi_version": (C.c_int, []),
+    "lbl_limit": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "lbl_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "lbl_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "lbl_ctx_destroy": (C.c_int, [_P]),
@@ -163,6 +164,21 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+_limits = {}
+
+
+def limit(name: str) -> int:
+    """A fixed size of the library (lbl_limit): "merged_lists_per_job", "arrays_per_layer", "arrays_per_sum",
+    "arrays_per_column", "layers_per_column", "jobs_per_batch"."""
+    if name not in _limits:
+        v = C.c_int64()
+        rc = load().lbl_limit(name.encode(), C.byref(v))
+        if rc != LBL_OK:
+            raise LblError(rc, "unknown limit %r" % name)
+        _limits[name] = int(v.value)
+    return _limits[name]
 
 
 def _as_f64(a):
@@ -501,9 +517,17 @@ class Context:
                                                  I_in.h if I_in is not None else None, float(surface_T), I_out.h))
 
     def sum_dev(self, bufs, n, out):
-        k = len(bufs)
-        B = (_P * max(k, 1))(*[b.h for b in bufs])
-        self.check(self.lib.lbl_sum_dev(self.h, k, B, int(n), out.h))
+        """out = zeros + bufs[0] + bufs[1] + ... in list order (pyradClasses.py:566-571, 684-689).  A list longer than the
+        library takes at once is chained with the partial sum first: 0 + partial is exact, the order of additions the same."""
+        cap = limit("arrays_per_sum")
+        bufs = list(bufs)
+        first = True
+        while first or bufs:
+            take = bufs[:cap] if first else [out] + bufs[:cap - 1]
+            bufs = bufs[cap:] if first else bufs[cap - 1:]
+            B = (_P * max(len(take), 1))(*[b.h for b in take])
+            self.check(self.lib.lbl_sum_dev(self.h, len(take), B, int(n), out.h))
+            first = False
 
     def optical_dev(self, trans, n, kind, out):
         self.check(self.lib.lbl_optical_dev(self.h, trans.h, int(n), int(kind), out.h))

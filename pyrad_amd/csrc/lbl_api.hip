@@ -72,6 +72,7 @@ struct lbl_ctx {
                              // Lorentz lines more than 4 half-spans from a span
     int accum_R = 0;         // points per lane, 0 = choose per launch
     int accum_LS = 0;        // waves sharing one span of points (line split), 0 = choose per launch
+    int gauss_run = 0;       // points per lane of a Gaussian run in the far-field kernel's production shape: 0 = by the launch's wave count, 16, 32
     int bal_workers[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // resident wavefronts of the balanced kernel per R (cached)
     // schedule cache: (job, tile) lists sorted longest first, per launch group
     struct Schedule {
@@ -343,6 +344,19 @@ static bool needs_regrid(const lbl_grid& g) {
 // ----------------------------------------------------------------------------------------
 extern "C" int lbl_abi_version(void) { return LBL_ABI_VERSION; }
 
+// The library's fixed sizes, for hosts that pick a route by them (pyrad_amd.model: merged layer step or per-line-list step)
+extern "C" int lbl_limit(const char* name, int64_t* value) {
+    if (!name || !value) return LBL_ERR_BAD_ARG;
+    if (!strcmp(name, "merged_lists_per_job")) *value = kMaxIso;               // line lists of one merged layer job
+    else if (!strcmp(name, "arrays_per_layer")) *value = kMaxColumnIso - 1;    // cross-section arrays lbl_layer_sweep_dev / lbl_layer_step_dev take
+    else if (!strcmp(name, "arrays_per_sum")) *value = kMaxIso;                // inputs of lbl_sum_dev
+    else if (!strcmp(name, "arrays_per_column")) *value = kMaxColumnIso - 1;   // terms of lbl_column_step_dev
+    else if (!strcmp(name, "layers_per_column")) *value = kMaxLayers;
+    else if (!strcmp(name, "jobs_per_batch")) *value = LBL_MAX_JOBS;
+    else return LBL_ERR_BAD_ARG;
+    return LBL_OK;
+}
+
 extern "C" int lbl_device_count(int* count) try {
     if (!count) return fail(nullptr, LBL_ERR_BAD_ARG, "count is NULL");
     int n = 0;
@@ -491,7 +505,7 @@ void comm_prof_end(lbl_ctx* ctx, void* start) { prof_end(ctx, PROF_GATHER, (hipE
 // before (lbl_capture_end) would go on replaying the old ones.  A change of any option therefore bumps the context's epoch:
 // lbl_graph_launch reports the graph stale (LBL_ERR_STATE) and the caller captures again (engine.StepGraph does by itself).
 static uint64_t option_state(const lbl_ctx* c) {
-    const long long v[] = {c->accum_variant, c->accum_R, c->accum_LS, c->lpt, c->tile_order, c->skew, c->skew_R, c->skew_LS, c->xcd_chunks, c->xcd_pack, c->xcd_tol, c->far_min_H,
+    const long long v[] = {c->accum_variant, c->accum_R, c->accum_LS, c->gauss_run, c->lpt, c->tile_order, c->skew, c->skew_R, c->skew_LS, c->xcd_chunks, c->xcd_pack, c->xcd_tol, c->far_min_H,
                            c->ablate, c->accuracy, c->sweep_ieee, c->sched_build, c->no_fuse ? 1 : 0,
                            c->bal_workers[1], c->bal_workers[2], c->bal_workers[4], c->bal_workers[8]};
     uint64_t h = 1469598103934665603ull;
@@ -554,6 +568,9 @@ static int set_option_value(lbl_ctx* ctx, const char* key, int value) {
         if (!(value == 0 || value == 1 || value == 2 || value == 4))
             return fail(ctx, LBL_ERR_BAD_ARG, "accum_skew_line_split must be 0 (auto), 1, 2 or 4");
         ctx->skew_LS = value;
+    } else if (!strcmp(key, "accum_gauss_run")) {
+        if (value != 0 && value != 16 && value != 32) return fail(ctx, LBL_ERR_BAD_ARG, "accum_gauss_run must be 0 (auto), 16 or 32");
+        ctx->gauss_run = value;
     } else if (!strcmp(key, "accum_far_min_window")) {
         if (value < 0) return fail(ctx, LBL_ERR_BAD_ARG, "accum_far_min_window must be >= 0");
         ctx->far_min_H = value;
@@ -1258,7 +1275,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
     std::vector<int> order(n_jobs);
     for (int j = 0; j < n_jobs; ++j) order[j] = j;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return group_key(a) > group_key(b); });
-    struct Group { int first, count, R, LS, max_tiles, variant; const int2* worklist; int total_tiles; const int32_t* tabs; std::vector<size_t> tab_off; lbl_ctx::Schedule* sched; };
+    struct Group { int first, count, R, LS, max_tiles, variant; int grun; const int2* worklist; int total_tiles; const int32_t* tabs; std::vector<size_t> tab_off; lbl_ctx::Schedule* sched; };
     std::vector<Group> groups;
     for (int k = 0; k < n_jobs;) {
         int e = k;
@@ -1271,7 +1288,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             mh = std::min(mh, H); mxh = std::max(mxh, H);
             ++e;
         }
-        Group g{k, e - k, 0, 0, 0, ctx->accum_variant, nullptr, 0, nullptr, {}, nullptr};
+        Group g{k, e - k, 0, 0, 0, ctx->accum_variant, 16, nullptr, 0, nullptr, {}, nullptr};
         if (is_skew(order[k])) {
             g.R = ctx->skew_R; g.LS = 1; g.variant = 6;
             // dense (merged) line lists: a chunk of 80 records must cover about the span's 64 R points, else only part of
@@ -1282,6 +1299,12 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             choose_shape(ctx, g.variant, pts, lns, mh, &g.R, &g.LS);
             // with the R actually chosen (a small grid may have shrunk it): does any job of the group have far lines?
             if (ctx->accum_variant == 5 && mxh < 32LL * g.R * (far_half_spans + 1)) g.variant = 3;
+            // Gaussian runs of 32 points (the far-field kernel's three-waves-per-SIMD build, lbl_kernels.hip) for launches of
+            // more than one round of the chip's wave slots at four per SIMD; a launch that fits one round keeps the 16-point build
+            if (g.variant == 5 && g.R == 4 && g.LS == 1) {
+                const long long waves = (pts + 255) / 256, slots = 16LL * (ctx->n_cu > 0 ? ctx->n_cu : 256);
+                g.grun = ctx->gauss_run ? ctx->gauss_run : (waves > slots ? 32 : 16);
+            }
         }
         if ((g.variant == 3 || g.variant == 5 || g.variant == 6) && (ctx->lpt || merge)) {
             // cached schedule of this group: dispatch order + the line ranges of every span (+ merged positions)
@@ -1522,7 +1545,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             launch_accumulate_skew(da + g.first, g.count, g.max_tiles, g.R, g.worklist, g.total_tiles, ctx->stream, g.LS);
         } else {
             launch_accumulate(da + g.first, g.count, g.max_tiles, g.R, g.LS, g.variant, g.worklist, g.total_tiles,
-                              ctx->stream, ctx->accuracy);
+                              ctx->stream, ctx->accuracy, g.grun);
         }
         prof_end(ctx, PROF_ACCUM, ev);
         HIP_TRY(ctx, hipGetLastError());
@@ -1698,18 +1721,87 @@ static int check_buf(lbl_ctx* ctx, const lbl_buffer* b, int64_t n, const char* w
     return LBL_OK;
 }
 
+// smallest / largest Planck-exponent factor 100 h c / k / T of a column's terms (ColumnStepArgs.pbkT_min / _max)
+static void column_pbkT_range(ColumnStepArgs* a) {
+    a->pbkT_min = a->pbkT_max = a->n_terms > 0 ? a->term_pbkT[0] : 0.0;
+    for (int t = 1; t < a->n_terms; ++t) {
+        a->pbkT_min = std::min(a->pbkT_min, a->term_pbkT[t]);
+        a->pbkT_max = std::max(a->pbkT_max, a->term_pbkT[t]);
+    }
+}
+
+// A layer with more cross-section arrays than SweepArgs holds (kMaxIso): the same sums, in the same order, by the column-step
+// kernel on a column of one layer (its term list lives in device memory: up to kMaxColumnIso - 1 arrays).  The reference sums
+// however many molecules and isotopologues a layer holds (pyradClasses.py:566-571, 707-712).
+static int layer_sweep_as_column(lbl_ctx* ctx, int n_iso, lbl_buffer* const* xsec, const int32_t* iso_mol, int n_mol,
+                                 const double* conc, double P, double T, double depth, double range_min, double range_max,
+                                 int64_t n, int64_t first, int64_t count, lbl_buffer* I_in, double surface_T,
+                                 lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out) {
+    int rc;
+    if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
+    if ((rc = check_buf(ctx, abs_coef, n, "abs_coef", false))) return rc;
+    if ((rc = check_buf(ctx, trans, n, "trans", false))) return rc;
+    if ((rc = check_buf(ctx, I_out, n, "I_out", false))) return rc;
+    if (I_out && !I_in && !(surface_T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "I_out needs I_in or surface_T > 0");
+    std::vector<char> blk(sizeof(ColumnStepArgs), 0);
+    ColumnStepArgs* a = (ColumnStepArgs*)blk.data();
+    for (int i = 0; i < n_iso; ++i) {
+        if ((rc = check_buf(ctx, xsec[i], n, "xsec", true))) return rc;
+        if (iso_mol[i] < 0 || iso_mol[i] >= n_mol || (i > 0 && iso_mol[i] < iso_mol[i - 1]))
+            return fail(ctx, LBL_ERR_BAD_ARG, "iso_mol must be non-decreasing and < n_mol");
+        a->xsec[i] = xsec[i]->d;
+        a->term_conc[i] = conc[iso_mol[i]];
+        a->term_factor[i] = budget_factor(conc[iso_mol[i]], P, T);
+        a->term_flags[i] = (i == n_iso - 1 || iso_mol[i + 1] != iso_mol[i]) ? TERM_LAST_MOL : 0;
+        a->term_P[i] = P; a->term_T[i] = T; a->term_depth[i] = depth;
+        a->term_rT[i] = uniform_rcp(T);
+        a->term_pbkT[i] = budget_pbkT(T);
+    }
+    a->term_flags[n_iso - 1] |= TERM_LAST_LAYER;
+    a->n_terms = n_iso; a->n_layers = 1;
+    column_pbkT_range(a);
+    a->ablate = ctx->ablate;
+    if (abs_coef) { a->abs_coef[0] = abs_coef->d; a->layer_arrays = 1; }
+    if (trans) { a->trans[0] = trans->d; a->layer_arrays = 1; }
+    a->start = range_min; a->stop = range_max; a->step = axis_step(range_min, range_max, n);
+    planck_constants(&a->pa, &a->pb);
+    const double ts = (I_in || surface_T > 0) ? surface_T : T;       // (no radiance wanted: any positive temperature will do)
+    a->surface_T = ts;
+    a->r_surface_T = uniform_rcp(ts);
+    a->pbk_surface = budget_pbkT(ts);
+    a->I_in = I_in ? I_in->d : nullptr;
+    if (I_out) {
+        a->I_out = I_out->d;
+    } else {                                                          // the kernel always writes the radiance: into scratch
+        if ((rc = arena_reserve(ctx, ctx->ktmp, (size_t)std::max<int64_t>(n, 1) * sizeof(double)))) return rc;
+        a->I_out = (double*)ctx->ktmp.ptr;
+    }
+    a->n = n; a->first = first; a->count = count;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void* d_args = nullptr;
+    if ((rc = device_args(ctx, a, sizeof(ColumnStepArgs), &d_args))) return rc;
+    hipEvent_t ev = prof_begin(ctx, PROF_SWEEP);
+    launch_column_step((const ColumnStepArgs*)d_args, first, count, ctx->stream, !ctx->sweep_ieee);
+    prof_end(ctx, PROF_SWEEP, ev);
+    HIP_TRY(ctx, hipGetLastError());
+    return LBL_OK;
+}
+
 extern "C" int lbl_layer_sweep_dev(lbl_ctx* ctx, int n_iso, lbl_buffer* const* xsec, const int32_t* iso_mol, int n_mol,
                                    const double* conc, double P, double T, double depth, double range_min,
                                    double range_max, int64_t n, int64_t first, int64_t count, lbl_buffer* I_in,
                                    double surface_T, lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
-    if (n_iso < 0 || n_iso > kMaxIso || n_mol < 0 || n_mol > kMaxIso) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d isotopologues per sweep", kMaxIso);
+    if (n_iso < 0 || n_iso >= kMaxColumnIso || n_mol < 0 || n_mol >= kMaxColumnIso) return fail(ctx, LBL_ERR_BAD_ARG, "at most %d isotopologues per sweep", kMaxColumnIso - 1);
     if (n < 0) return fail(ctx, LBL_ERR_BAD_ARG, "negative n");
     if (first < 0 || count < 0 || count > n - first) return fail(ctx, LBL_ERR_BAD_ARG, "swept range outside [0, n)");
     if (count == 0) { first = 0; count = n; }
     if (n_iso > 0 && (!xsec || !iso_mol)) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     if (n_mol > 0 && !conc) return fail(ctx, LBL_ERR_BAD_ARG, "conc is NULL");
     if (!(T > 0)) return fail(ctx, LBL_ERR_BAD_ARG, "T must be > 0");
+    if (n_iso > kMaxIso)       // more arrays than a sweep's argument block holds: the column-step kernel on a column of this one layer
+        return layer_sweep_as_column(ctx, n_iso, xsec, iso_mol, n_mol, conc, P, T, depth, range_min, range_max, n, first, count,
+                                     I_in, surface_T, abs_coef, trans, I_out);
     SweepArgs a;
     memset(&a, 0, sizeof a);
     int rc;
@@ -1752,7 +1844,7 @@ extern "C" int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lin
                                   const double* conc, double depth, lbl_buffer* I_in, double surface_T,
                                   lbl_buffer* abs_coef, lbl_buffer* trans, lbl_buffer* I_out) try {
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
-    if (n_iso < 1 || n_iso > kMaxIso || n_mol < 1 || n_mol > kMaxIso) return fail(ctx, LBL_ERR_BAD_ARG, "1..%d line lists and molecules per layer step", kMaxIso);
+    if (n_iso < 1 || n_iso >= kMaxColumnIso || n_mol < 1 || n_mol >= kMaxColumnIso) return fail(ctx, LBL_ERR_BAD_ARG, "1..%d line lists and molecules per layer step", kMaxColumnIso - 1);
     if (!lines || !iso || !grid || !xsec || !iso_mol || !conc) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
     int rc;
     if ((rc = check_grid(ctx, grid))) return rc;
@@ -1846,6 +1938,7 @@ extern "C" int lbl_layer_merged_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* con
     if (!ctx) return fail(nullptr, LBL_ERR_BAD_ARG, "ctx is NULL");
     if (n_iso < 1 || n_iso > kMaxIso || n_mol < 1 || n_mol > kMaxIso) return fail(ctx, LBL_ERR_BAD_ARG, "1..%d line lists and molecules per layer step", kMaxIso);
     if (!lines || !iso || !grid || !iso_mol || !conc) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    if (ctx->sweep_ieee) return fail(ctx, LBL_ERR_BAD_ARG, "merged layer jobs exist in the sweeps' default arithmetic only: with \"sweep_ieee_divisions\" 1 use the per-line-list step");
     int rc;
     if ((rc = check_grid(ctx, grid))) return rc;
     if ((rc = check_layer_lists(ctx, n_iso, iso, iso_mol, n_mol, 0))) return rc;
@@ -1954,6 +2047,7 @@ extern "C" int lbl_column_fold_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const
     if (first < 0 || count < 0 || count > n - first) return fail(ctx, LBL_ERR_BAD_ARG, "swept range outside [0, n)");
     if (count == 0) { first = 0; count = n; }
     if (n_layers > 0 && (!abs_coef || !T || !depth)) return fail(ctx, LBL_ERR_BAD_ARG, "NULL argument");
+    if (ctx->sweep_ieee) return fail(ctx, LBL_ERR_BAD_ARG, "the fold over absorption coefficients exists in the sweeps' default arithmetic only: with \"sweep_ieee_divisions\" 1 use lbl_column_step_dev on the cross sections");
     int rc;
     if ((rc = check_buf(ctx, I_out, n, "I_out", true))) return rc;
     if ((rc = check_buf(ctx, I_in, n, "I_in", false))) return rc;
@@ -1973,6 +2067,7 @@ extern "C" int lbl_column_fold_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const
         if (trans && trans[l]) { if ((rc = check_buf(ctx, trans[l], n, "trans", true))) return rc; a->trans[l] = trans[l]->d; a->layer_arrays = 1; }
     }
     a->n_terms = n_layers;
+    column_pbkT_range(a);
     a->ablate = ctx->ablate;
     a->n_layers = n_layers;
     a->start = range_min; a->stop = range_max; a->step = axis_step(range_min, range_max, n);
@@ -2091,6 +2186,7 @@ extern "C" int lbl_column_step_dev(lbl_ctx* ctx, int n_layers, const int32_t* n_
         iso0 += n_iso[l]; mol0 += n_mol[l];
     }
     a->n_terms = nt;
+    column_pbkT_range(a);
     a->ablate = ctx->ablate;
     a->n_layers = n_layers;
     a->start = range_min; a->stop = range_max; a->step = axis_step(range_min, range_max, n);

@@ -43,8 +43,9 @@ static_assert(sizeof(HotRec) == 32 && sizeof(ColdRec) == 32, "record halves must
 enum : int32_t {
     REC_DIRECT_DIV = 1,   // Lorentz denominator outside the running-fraction range: plain divide
     REC_NO_RECUR = 2,     // Gaussian too narrow for the two-exp recurrence (b > 4): one exp per point
-    REC_LONG_RUN = 4      // Gaussian wide enough (b <= 1) for the 16-point runs of the transposed pass: a run that
+    REC_LONG_RUN = 4,     // Gaussian wide enough (b <= 1) for the 16-point runs of the transposed pass: a run that
                           // starts from an underflowed seed cannot reach a point where the term still matters
+    REC_LONG_RUN32 = 8    // ... and for its 32-point runs (b <= 0.3)
 };
 
 // One accumulate job = one isotopologue of one layer (Isotope.createCrossSection).
@@ -173,7 +174,10 @@ void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, 
 int sched_launch_items(int total_tiles, int n_cu, bool xcd_pack);
 
 // ---- fused sweep arguments (passed by value / by pointer to the sweep kernels) ----------
-constexpr int kMaxIso = 48;
+// line lists of one MERGED accumulate job (6 bits of the merged-order map, PrepJob blocks in K1's LDS) and arrays a layer
+// sweep takes as a kernel argument; a layer with more arrays is swept by the column-step kernel, whose term list lives in
+// device memory (kMaxColumnIso), so a layer holds up to kMaxColumnIso - 1 line lists (HITRAN knows ~160 isotopologues)
+constexpr int kMaxIso = 64;
 // A sweep walks a flat list of terms, one per cross-section array, molecule after molecule (and, in a column,
 // layer after layer from the bottom): the flags say where a molecule's isotopologue sum is complete
 // (pyradClasses.py:566-571 -> 583) and where a layer's molecules are (pyradClasses.py:707-716).
@@ -208,6 +212,7 @@ struct ColumnStepArgs {
     double term_P[kMaxColumnIso], term_T[kMaxColumnIso], term_rT[kMaxColumnIso], term_depth[kMaxColumnIso];   // rT = RN(1/T) (0: plain divide)
     double term_factor[kMaxColumnIso], term_pbkT[kMaxColumnIso];     // default arithmetic (see SweepArgs)
     double pbk_surface;
+    double pbkT_min, pbkT_max;          // smallest / largest term_pbkT of the column (the kernel's test for its one-exp-per-thread Planck path)
     int32_t term_flags[kMaxColumnIso];
     int32_t n_terms, n_layers;
     int32_t ablate;                     // LBL_DIAG builds only (lbl_set_option debug_ablate, scripts/ablate.sh): timing-only variants; else 0 and never read
@@ -238,7 +243,7 @@ void launch_line_prep(const PrepJob* d_jobs, int n_jobs, int max_lines, hipStrea
 void launch_line_quantities(const PrepJob* d_job, int n_lines, long long* index, double* lhw, double* ghw, double* intensity,
                             int32_t* regime, hipStream_t s);
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
-                       const int2* worklist, int total_tiles, hipStream_t s, int budget = 0);
+                       const int2* worklist, int total_tiles, hipStream_t s, int budget = 0, int gauss_run = 16);
 // narrow windows: every lane walks the lines that reach its own R points (skewed ranges); tiles of 256 R points
 void launch_accumulate_skew(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, const int2* worklist, int total_tiles,
                             hipStream_t s, int LS = 1);      // LS 2 | 4: R = 8 only (waves of a workgroup share a span and deal its records)

@@ -41,6 +41,7 @@
 // point against 5 fp64 instructions per directly evaluated (line, grid point) pair.
 #include "lbl_device.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace lbl {
 
@@ -190,7 +191,9 @@ __device__ __forceinline__ double planck_budget(double n, double pa, double pbkT
     return b != b ? b : r;
 }
 __device__ __forceinline__ double exp_neg_budget(double x) {       // exp(-x), x >= 0 (optical depth)
-    return x != x ? x : exp_clamped(fmax(-x, -800.0));
+    // (the clamp as a select, not as fmax, which would drop a NaN: a NaN argument then runs through exp_clamped as a NaN -
+    // rint, fma, ldexp all pass it on - and needs no test of its own; x = +inf gives 0 like the reference's exp(-inf))
+    return exp_clamped(x > 800.0 ? -800.0 : -x);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -311,7 +314,7 @@ __device__ __forceinline__ void prep_one_line(const PrepJob& J, int i, HotRec& r
     // narrower profiles take one exp per point
     rc.q2 = (rc.b <= 4.0) ? exp(-2.0 * rc.b) : -1.0;
     if (!(rc.b <= 4.0)) r.flags |= REC_NO_RECUR;
-    // 16-point runs (gauss_runs16): a lane walks 15 steps from its first point, possibly TOWARDS the centre.
+    // 16-point runs (gauss_runs): a lane walks 15 steps from its first point, possibly TOWARDS the centre.
     // If its seed KG exp(-b d0^2) has underflowed (b d0^2 > T, T = 745 - ln(1/KG) >= ~600 for any KG down
     // to 1e-60) the run's values stay 0; that is harmless as long as no point of the run can matter: the
     // nearest one has b d^2 > b (sqrt(T/b) - 15)^2, which exceeds the 45 beyond which the term is below
@@ -320,6 +323,9 @@ __device__ __forceinline__ void prep_one_line(const PrepJob& J, int i, HotRec& r
     // recurrence exact; a clamped r only lowers a value that is negligible anyway.)  Pure-Gaussian lines
     // (no Lorentz part to be negligible against: their term counts until it underflows) keep the 4-point pass.
     if (rc.b <= 1.0 && KL != 0.0) r.flags |= REC_LONG_RUN;
+    // 32-point runs (round 6, the three-waves-per-SIMD build of the far-field kernel): 31 steps towards the centre need
+    // sqrt(b) < (sqrt(600) - sqrt(45)) / 31 = 0.57; b <= 0.3 keeps the same margin
+    if (rc.b <= 0.3 && KL != 0.0) r.flags |= REC_LONG_RUN32;
     rc.KLd = r.KL;
 }
 
@@ -797,13 +803,18 @@ __device__ __forceinline__ int span_slot(int o) { return o + (o >> 4); }
 // lane%16 of the group walks the 16 consecutive points 16t .. 16t+15 of the span with the recurrence
 // g(d+1) = g(d) r(d), r(d+1) = r(d) q2: two exp per 16 points instead of per 4 (25 instead of 51 wave
 // instructions per record).  Sums go to G[16] per lane (point 16t+k of the span, partial over this
-// group's records); gauss_runs16_fold adds the four groups' partial sums to the owners of the points
+// group's records); gauss_runs_fold adds the four groups' partial sums to the owners of the points
 // in a fixed order.  Lines flagged REC_LONG_RUN by K1 come here; MASKED for those whose support ends
 // inside the span.
-template <bool MASKED>
-__device__ __forceinline__ void gauss_runs16(const double* __restrict__ lh, const double* __restrict__ lc,
-                                             unsigned long long m, double xrun, double Hf, int lane, double (&G)[16]) {
-    const int q = lane >> 4;
+// RUN = 16 points per lane: 16 lanes per record, four records per pass (the description above).  RUN = 32 (round 6, the
+// three-waves-per-SIMD build of the far-field kernel: -DLBL_FF_WPS=3 -DLBL_GAUSS_RUN=32): 8 lanes per record, eight records
+// per pass, two exp per 32 points - 142 instead of 92 wave-instructions per pass for twice the records - and 64 instead of
+// 32 registers of sums.
+template <int RUN, bool MASKED>
+__device__ __forceinline__ void gauss_runs(const double* __restrict__ lh, const double* __restrict__ lc,
+                                           unsigned long long m, double xrun, double Hf, int lane, double (&G)[RUN]) {
+    constexpr int LPR = 256 / RUN, NREC = 64 / LPR;       // lanes per record, records per pass
+    const int q = lane / LPR;
     // The records of the mask as a list of bytes in the wave's LDS (behind the staged records), built once: every pass then
     // reads its four record numbers (one ds_read_u8 per lane) instead of scanning the mask with ~32 scalar instructions -
     // which are not free: each takes an issue slot of its wave (round 5: merged C3 K2 243.5 -> 238.7 us, bit-identical).
@@ -815,7 +826,7 @@ __device__ __forceinline__ void gauss_runs16(const double* __restrict__ lh, cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int j_first = __builtin_ctzll(m);
-    for (int p = 0; p < cnt; p += 4) {
+    for (int p = 0; p < cnt; p += NREC) {
         const int slot = p + q;
         const int j = slot < cnt ? (int)list[slot] : -1;
         const int jj = j < 0 ? j_first : j;
@@ -826,7 +837,7 @@ __device__ __forceinline__ void gauss_runs16(const double* __restrict__ lh, cons
         double g = KG * exp_clamped(-b * (d0 * d0));
         double rr = exp_clamped(fmin(-b * (2.0 * d0 + 1.0), 700.0));
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < RUN; ++k) {
             if (MASKED) G[k] += (fabs(d0 + (double)k) <= Hf) ? g : 0.0;      // support ends inside the span (cls:394)
             else G[k] += g;
             g *= rr;
@@ -835,32 +846,53 @@ __device__ __forceinline__ void gauss_runs16(const double* __restrict__ lh, cons
     }
 }
 
-// G (lane (q, t): points 16t..16t+15, partial sums of group q) -> acc (lane l: points R l .. R l + R-1), through
-// 2 KB of the wave's LDS scratch, one group per round, groups added in the order 0..3
-template <int R>
-__device__ __forceinline__ void gauss_runs16_fold(const double (&G)[16], double* scratch, int lane, double (&acc)[R]) {
-    const int q = lane >> 4, t = lane & 15;
+// G (lane (q, t): points RUN t .. RUN t + RUN-1, partial sums of group q) -> acc (lane l: points R l .. R l + R-1), through
+// the wave's LDS scratch.  RUN = 16: 2 KB, one group per round, groups added in the order 0..3.  RUN = 32: four regions of
+// 272 doubles, four groups per round (group q in region q % 4), two rounds; groups added in the order 0..7.
+template <int R, int RUN>
+__device__ __forceinline__ void gauss_runs_fold(const double (&G)[RUN], double* scratch, int lane, double (&acc)[R]) {
+    constexpr int LPR = 256 / RUN, NREC = 64 / LPR, NREG = RUN / 8, REGION = 272;      // regions in use at once: 2 (RUN 16: one suffices, kept at 1 below) / 4
+    const int q = lane / LPR, t = lane % LPR;
+    if (RUN == 16) {
 #pragma unroll
-    for (int round = 0; round < 4; ++round) {
-        __builtin_amdgcn_wave_barrier();
-        if (q == round) {
+        for (int round = 0; round < 4; ++round) {
+            __builtin_amdgcn_wave_barrier();
+            if (q == round) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) scratch[span_slot(16 * t + k)] = G[k];
+                for (int k = 0; k < RUN; ++k) scratch[span_slot(16 * t + k)] = G[k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < R; ++k) acc[k] += scratch[span_slot(lane * R + k)];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    } else {
 #pragma unroll
-        for (int k = 0; k < R; ++k) acc[k] += scratch[span_slot(lane * R + k)];
+        for (int round = 0; round < NREC / NREG; ++round) {
+            __builtin_amdgcn_wave_barrier();
+            if (q / NREG == round) {
+                double* reg = scratch + (q % NREG) * REGION;
+#pragma unroll
+                for (int k = 0; k < RUN; ++k) reg[span_slot(RUN * t + k)] = G[k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int g = 0; g < NREG; ++g) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) acc[k] += scratch[g * REGION + span_slot(lane * R + k)];
+            }
+        }
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int R, int LONGG = 0>
+template <int R, int LONGG = 0, int RUN = 16>
 __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, const double* __restrict__ lc,
                                              unsigned long long gmask, unsigned long long emask,
                                              unsigned long long dmask, unsigned long long imask, double x0, double Hf,
                                              WaveAcc<R>& S, unsigned long long lmask, double xrun, int lane,
-                                             double (&G16)[16]) {
+                                             double (&G16)[RUN]) {
     // emask bit j: record j must use one exp per point (profile too narrow for the recurrence)
     // imask bit j: record j is an interior line (every point of the wave inside its support): no masking
     // lmask bit j: record j may take the transposed 16-point runs (LONGG kernels, R = 4)
@@ -869,8 +901,8 @@ __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, cons
         // masked instantiation costs it 1 % in registers and code); 2: masked ones too (all-direct kernel,
         // i.e. the narrow-window layers of a column, where most records end inside the span)
         const unsigned long long ml = gmask & ~emask & lmask & (LONGG >= 2 ? ~0ull : imask);
-        if (ml & imask) gauss_runs16<false>(lh, lc, ml & imask, xrun, Hf, lane, G16);
-        if (LONGG >= 2 && (ml & ~imask)) gauss_runs16<true>(lh, lc, ml & ~imask, xrun, Hf, lane, G16);
+        if (ml & imask) gauss_runs<RUN, false>(lh, lc, ml & imask, xrun, Hf, lane, G16);
+        if (LONGG >= 2 && (ml & ~imask)) gauss_runs<RUN, true>(lh, lc, ml & ~imask, xrun, Hf, lane, G16);
         gmask &= ~ml;
     }
     unsigned long long m = gmask & ~emask & imask;
@@ -920,10 +952,10 @@ __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, cons
 // Lines below iB or from iC on end inside the wave's span and are masked per point.
 // The wave streams the records in chunks of 64 through its own LDS (lh: hot halves, lc: cold
 // halves), with the next chunk's loads in flight while the current one is consumed.
-template <int R, int LONGG = 0>
+template <int R, int LONGG = 0, int RUN = 16>
 __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRec* cold, int mA, int mD, int iB, int iC,
                                                  int wlo, int whi, double x0, double Hf, double* lh, double* lc, int lane,
-                                                 WaveAcc<R>& S, double (&G16)[16], int stride = 64, int step = 1, int phase = 0) {
+                                                 WaveAcc<R>& S, double (&G16)[RUN], int stride = 64, int step = 1, int phase = 0) {
     // step > 1 (with stride = 64): every wave of the span walks ALL chunks but takes only the records
     // j % step == phase of each, so the split is exact to a line.  Dealing whole chunks left one wave
     // of a two-way split with 128 of a span's ~210 near lines and the other with 82.
@@ -954,7 +986,7 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
         const unsigned long long gmask = __ballot(gauss);
         const unsigned long long dmask = __ballot(direct) & stripe;
         const unsigned long long emask = __ballot((fl & REC_NO_RECUR) != 0);
-        const unsigned long long lmask = LONGG ? __ballot((fl & REC_LONG_RUN) != 0) : 0ull;
+        const unsigned long long lmask = LONGG ? __ballot((fl & (RUN == 32 ? REC_LONG_RUN32 : REC_LONG_RUN)) != 0) : 0ull;
         v2f64 w0 = h0, w1 = h1;
         if (direct) { w0.y = 1.0; w1.x = 0.0; }          // a2 = 1, KL = 0 in the hot loop's copy
         reinterpret_cast<v2f64*>(lh)[lane * 2] = w0;
@@ -988,8 +1020,8 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
             __builtin_amdgcn_wave_barrier();
             // records a1..b1-1 of the chunk are interior lines
             const unsigned long long imask = (b1 > a1) ? ((b1 - a1 >= 64 ? ~0ull : ((1ull << (b1 - a1)) - 1ull)) << a1) : 0ull;
-            chunk_extras<R, LONGG>(lh, lc, gmask, emask, dmask, imask, x0, Hf, S, lmask,
-                                   (double)(wlo + 16 * (lane & 15)), lane, G16);
+            chunk_extras<R, LONGG, RUN>(lh, lc, gmask, emask, dmask, imask, x0, Hf, S, lmask,
+                                        (double)(wlo + RUN * (lane % (256 / RUN))), lane, G16);
         }
     }
 }
@@ -1570,18 +1602,22 @@ __device__ __forceinline__ void edge_rounds_masked(const HotRec* hot, const Cold
     }
 }
 
-#ifndef LBL_FF_WPS
-#define LBL_FF_WPS 4      // waves per SIMD the production shape of the far-field kernel is built for (A/B builds: 3 = 168 VGPRs)
-#endif
-template <int R, int LS, int NT = 0>                                                     // NT: far-field series terms (0: every pair direct)
-__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), (R >= 4 ? (NT > 0 && R == 4 && LS == 1 ? LBL_FF_WPS : 4) : 1))   // HIP: min waves per SIMD
+// GRUN: points per lane of a Gaussian run (gauss_runs).  16: 128 VGPRs, four waves per SIMD.  32 (round 6; the production
+// shape R = 4, LS = 1 with the series only): half the exp per point in the Gaussian parts for 32 more registers of sums -
+// 164 VGPRs, three waves per SIMD, 43 KB of LDS per workgroup.  Same box, merged 100-2500 cm^-1 cell: K2 242.9 -> 233.1 us
+// (-4 %), half of it (a shard of 2) -4 %, budget mode -3.5 %, the column's wide layers +-0; a launch that fits ONE round of
+// the chip's 4,096 wave slots loses (a per-list shard of 8, 3,516 waves: 44.6 -> 46.4 us - it needs a second round at three
+// waves per SIMD), so the host picks 32 for launches of more than 4,096 waves (lbl_set_option "accum_gauss_run").
+template <int R, int LS, int NT = 0, int GRUN = 16>                                      // NT: far-field series terms (0: every pair direct)
+__global__ __launch_bounds__((LS > 4 ? 64 * LS : 256), (R >= 4 ? (GRUN == 32 ? 3 : 4) : 1))   // HIP: min waves per SIMD
 void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* __restrict__ worklist) {
     constexpr bool FF = NT > 0;
     constexpr int NW = LS > 4 ? LS : 4;              // wavefronts per workgroup (LS = 8: 512 threads)
     constexpr int PG = NW / LS;                      // point groups (64*R points each) per workgroup
     // per wave: hot records [0,256), cold records [256,512); after the line loop the same words
     // hold the wave's 64*R sums in point order (+ padding) for the coalesced store
-    constexpr int STAGE_MIN = FF ? 576 : 520;        // FF: 8 x 72 doubles for wave_sum_rows; else 512 + the 64-byte record list of gauss_runs16
+    static_assert(GRUN == 16 || (GRUN == 32 && FF && R == 4 && LS == 1), "32-point Gaussian runs: production shape of the far-field kernel only");
+    constexpr int STAGE_MIN = GRUN == 32 ? 4 * 272 : FF ? 576 : 520;        // FF: 8 x 72 doubles for wave_sum_rows; else 512 + the 64-byte record list of gauss_runs; 32-point runs: four fold regions
     constexpr int STAGE = (68 * R > STAGE_MIN) ? 68 * R : STAGE_MIN;
     __shared__ double s_stage[NW][STAGE];
     // edge lines through the skewed walk (skew_edges): the production shape only (unsplit spans of 256 points)
@@ -1628,7 +1664,7 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
 #pragma unroll
         for (int k = 0; k < 16; ++k) G[k] = 0.0;
         accumulate_lines<R, 2>(J.hot, J.cold, iA + part * 64, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64 * LS);
-        if (R == 4) gauss_runs16_fold<R>(G, s_stage[wave], lane, S.acc);
+        if (R == 4) gauss_runs_fold<R, 16>(G, s_stage[wave], lane, S.acc);
         S.flush();
     }
     if (active && FF) {
@@ -1698,20 +1734,20 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         // they are one contiguous run and go through the first stream alone (one prologue, not three).
         // (the LS waves of a span interleave these classes line by line; series chunks are dealt whole)
         // (Gaussian parts of interior lines: 16-point runs into G, folded into the sums once per span)
-        double G[16];
+        double G[GRUN];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) G[k] = 0.0;
+        for (int k = 0; k < GRUN; ++k) G[k] = 0.0;
         if (LBL_ABLATE(J, 512)) {                                            // (512: near lines dropped)
         } else if (edges_done) {
-            accumulate_lines<R, 1>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+            accumulate_lines<R, 1, GRUN>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
         } else {
-            accumulate_lines<R, 1>(J.hot, J.cold, iA, any_far ? iB : iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+            accumulate_lines<R, 1, GRUN>(J.hot, J.cold, iA, any_far ? iB : iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
             if (any_far) {
-                accumulate_lines<R, 1>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
-                accumulate_lines<R, 1>(J.hot, J.cold, iC, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+                accumulate_lines<R, 1, GRUN>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+                accumulate_lines<R, 1, GRUN>(J.hot, J.cold, iC, iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
             }
         }
-        if (R == 4) gauss_runs16_fold<R>(G, s_stage[wave], lane, S.acc);
+        if (R == 4) gauss_runs_fold<R, GRUN>(G, s_stage[wave], lane, S.acc);
         S.flush();
     }
 
@@ -2894,11 +2930,20 @@ __global__ __launch_bounds__(256) void column_sweep_kernel(const ColumnArgs* __r
 // term of a molecule and of a layer).  NB terms are loaded at once, independent of one another; everything
 // that depends on the grid point only (2E8 h c^2 n^3 and 100 h c n / k of pyradPlanck.py:41-42) is computed
 // once per point, not once per layer.
+// exp(x) for 0 <= x <= 1e-3 (the Planck exponent's growth over the 1-3 grid steps between a thread's points): degree-4
+// Taylor polynomial, remainder x^5 / 120 <= 8.4e-18 relative
+__device__ __forceinline__ double expm1_tiny(double x) {
+    return x * fma(x, fma(x, fma(x, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
+}
+
 template <int NP, bool BUDGET = false>
-__global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* __restrict__ Ap, long long first, long long count) {
+__global__ __launch_bounds__(256, (NP == 4 ? 3 : 1)) void column_step_kernel(const ColumnStepArgs* __restrict__ Ap, long long first, long long count) {
 #pragma clang fp contract(off)
-    // NP grid points per thread (2: 16-byte loads; the host gives this instantiation an even first point and an even count)
-    constexpr int NB = 6;
+    // NP grid points per thread (2: 16-byte loads, 4: 32-byte; the host gives these instantiations a first point and a count
+    // that are multiples of NP)
+    // terms per batch of loads (two batches in flight).  Four points per thread: 2 - 144 VGPRs, three waves per SIMD, the fold of the
+    // 30-layer column 147-150 us; 3 needs 169 (two waves per SIMD: 172 us; capped at 168 it spills: 161 us)
+    constexpr int NB = NP == 4 ? 2 : 6;
     typedef double vec __attribute__((ext_vector_type(NP)));
     typedef const vec __attribute__((address_space(1)))* GlobalVec;
     const ColumnStepArgs& A = *Ap;
@@ -2927,8 +2972,19 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
             }
             kk[p] = 0.0; xs[p] = 0.0;
         }
+        // Round 6, default arithmetic with several points per thread: ONE exp per thread and layer for the Planck function.
+        // exp(nu_p c) = exp(nu_0 c) exp((nu_p - nu_0) c): the difference of two neighbouring grid wavenumbers is exact in
+        // fp64 and (nu_p - nu_0) c <= 1e-3 for every layer (checked here with the column's largest c = 100 h c / k / T_min),
+        // so the second factor is a degree-4 polynomial (7 instructions instead of the 17 of exp; 1-2 ulp).  Also only
+        // where no lane of the wave can meet a special case - exponent above 700, exp(b) - 1 not positive (nu = 0), NaN
+        // wavenumbers - which keep the general expression with its selects and its IEEE division (wave-uniform branch).
+        const double dnu_last = BUDGET ? pb_n[NP - 1] - pb_n[0] : 0.0;
+        const bool plain = BUDGET && NP > 1 && pb_n[0] * A.pbkT_min >= 1e-6 && pb_n[NP - 1] * A.pbkT_max <= 690.0
+                           && dnu_last * A.pbkT_max <= 1e-3 && dnu_last >= 0.0;
+        const bool fast = BUDGET && NP > 1 && __builtin_amdgcn_ballot_w64(!plain) == 0ull;
         int l = 0;
-        auto term = [&](int t, vec v) {
+        auto term = [&](auto fast_tag, int t, vec v) {
+            constexpr bool FAST = decltype(fast_tag)::value;
             const int f = A.term_flags[t];
 #pragma unroll
             for (int p = 0; p < NP; ++p) xs[p] += v[p];
@@ -2941,6 +2997,8 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
                 }
             }
             if (f & TERM_LAST_LAYER) {
+                double E0 = 0.0;
+                if (FAST) E0 = exp_clamped(pb_n[0] * A.term_pbkT[t]);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const double tr = BUDGET ? exp_neg_budget(kk[p] * A.term_depth[t]) : exp(-kk[p] * A.term_depth[t]);
@@ -2949,7 +3007,10 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
                         if (A.trans[l]) A.trans[l][j + p] = tr;
                     }
                     double B;
-                    if (BUDGET) {
+                    if (FAST) {
+                        const double E = p == 0 ? E0 : fma(E0, expm1_tiny((pb_n[p] - pb_n[0]) * A.term_pbkT[t]), E0);
+                        B = pa_n[p] * rcp_newton(E - 1.0);
+                    } else if (BUDGET) {
                         const double b = pb_n[p] * A.term_pbkT[t];
                         const double e = exp_clamped(fmin(b, 700.0)) - 1.0;
                         B = (b > 700.0) ? 0.0 : (e > 0.0 ? pa_n[p] * rcp_newton(fmax(e, 1e-300)) : pa_n[p] / e);
@@ -2973,17 +3034,21 @@ __global__ __launch_bounds__(256) void column_step_kernel(const ColumnStepArgs* 
 #pragma unroll
             for (int u = 0; u < NB; ++u) cur[u] = LBL_ABLATE(A, 32) ? (vec)(1e-22 * (double)(j & 7)) : load(A.xsec[u], j);
         }
-        for (int t0 = 0; t0 < n_full; t0 += NB) {
-            if (t0 + NB < n_full) {
+        auto walk = [&](auto fast_tag) {
+            for (int t0 = 0; t0 < n_full; t0 += NB) {
+                if (t0 + NB < n_full) {
 #pragma unroll
-                for (int u = 0; u < NB; ++u) nxt[u] = LBL_ABLATE(A, 32) ? (vec)(1e-22 * (double)(j & 7)) : load(A.xsec[t0 + NB + u], j);
+                    for (int u = 0; u < NB; ++u) nxt[u] = LBL_ABLATE(A, 32) ? (vec)(1e-22 * (double)(j & 7)) : load(A.xsec[t0 + NB + u], j);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) term(fast_tag, t0 + u, cur[u]);
+#pragma unroll
+                for (int u = 0; u < NB; ++u) cur[u] = nxt[u];
             }
-#pragma unroll
-            for (int u = 0; u < NB; ++u) term(t0 + u, cur[u]);
-#pragma unroll
-            for (int u = 0; u < NB; ++u) cur[u] = nxt[u];
-        }
-        for (int t = n_full; t < n_terms; ++t) term(t, load(A.xsec[t], j));
+            for (int t = n_full; t < n_terms; ++t) term(fast_tag, t, load(A.xsec[t], j));
+        };
+        if (BUDGET && NP > 1 && fast) walk(std::true_type{});
+        else walk(std::false_type{});
 #pragma unroll
         for (int p = 0; p < NP; ++p) A.I_out[j + p] = I[p];
     }
@@ -3089,7 +3154,7 @@ static void launch_accum_scalar(const AccumJob* d_jobs, int n_jobs, int max_tile
 
 template <int R, int NT>
 static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, int LS, const int2* worklist,
-                             int total_tiles, hipStream_t s) {
+                             int total_tiles, hipStream_t s, int gauss_run = 16) {
     dim3 grid(((max_tiles + 7) / 8) * 8, n_jobs);
     if (worklist) {
         if (total_tiles <= 0) return;
@@ -3104,7 +3169,14 @@ static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, 
         case 8: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 8, NT>), grid, dim3(512), pad, s, d_jobs, worklist); break;
         case 4: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 4, NT>), grid, dim3(256), pad, s, d_jobs, worklist); break;
         case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2, NT>), grid, dim3(256), pad, s, d_jobs, worklist); break;
-        default: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1, NT>), grid, dim3(256), pad, s, d_jobs, worklist); break;
+        default:
+            if constexpr (R == 4 && NT > 0) {
+                if (gauss_run == 32) {
+                    hipLaunchKernelGGL((xsec_accumulate_lds_kernel<4, 1, NT, 32>), grid, dim3(256), pad, s, d_jobs, worklist);
+                    break;
+                }
+            }
+            hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 1, NT>), grid, dim3(256), pad, s, d_jobs, worklist); break;
     }
 }
 
@@ -3139,13 +3211,13 @@ int accumulate_tile_points(int R, int LS, int variant) {
 }
 
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
-                       const int2* worklist, int total_tiles, hipStream_t s, int budget) {
+                       const int2* worklist, int total_tiles, hipStream_t s, int budget, int gauss_run) {
     if (n_jobs <= 0 || max_tiles <= 0) return;
     if (variant >= 5 && budget) {
         switch (R) {
             case 1: launch_accum_lds<1, FF_NT_BUDGET>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
             case 2: launch_accum_lds<2, FF_NT_BUDGET>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-            case 4: launch_accum_lds<4, FF_NT_BUDGET>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 4: launch_accum_lds<4, FF_NT_BUDGET>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s, gauss_run); break;
             default: launch_accum_lds<8, FF_NT_BUDGET>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
         }
         return;
@@ -3154,7 +3226,7 @@ void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R,
         switch (R) {
             case 1: launch_accum_lds<1, FF_NT>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
             case 2: launch_accum_lds<2, FF_NT>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
-            case 4: launch_accum_lds<4, FF_NT>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
+            case 4: launch_accum_lds<4, FF_NT>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s, gauss_run); break;
             default: launch_accum_lds<8, FF_NT>(d_jobs, n_jobs, max_tiles, LS, worklist, total_tiles, s); break;
         }
         return;
@@ -3239,7 +3311,16 @@ static void launch_column_step_b(const ColumnStepArgs* d_args, long long first, 
 #else
     constexpr bool pairs = true;
 #endif
-    // (four points per thread with 32-byte loads measured slower: 174 VGPRs, 0.486 vs 0.419 ms exact, 0.394 vs 0.377 budget)
+    // default arithmetic: four points per thread (32-byte loads, three terms per batch; one Planck exp per thread and layer);
+    // the reference's rounding chain: two (four measured slower there in round 3: 174 VGPRs with six terms per batch)
+    if constexpr (BUDGET) {
+        if (pairs && (first & 3) == 0 && count >= 4) {
+            const long long quad = count & ~3LL;
+            hipLaunchKernelGGL((column_step_kernel<4, true>), dim3(sweep_blocks(quad / 4)), dim3(256), 0, s, d_args, first, quad);
+            if (count & 3) hipLaunchKernelGGL((column_step_kernel<1, true>), dim3(1), dim3(64), 0, s, d_args, first + quad, count & 3);
+            return;
+        }
+    }
     if (pairs && (first & 1) == 0 && count >= 2) {     // two points per thread with 16-byte loads; an odd last point by itself
         const long long even = count & ~1LL;
         hipLaunchKernelGGL((column_step_kernel<2, BUDGET>), dim3(sweep_blocks(even / 2)), dim3(256), 0, s, d_args, first, even);

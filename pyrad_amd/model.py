@@ -99,6 +99,7 @@ def resetCrossSection(obj):
             type(obj).crossSection.defer(obj, lambda n=n: np.zeros(n))      # the zeros of cls:41, made when read
             if isinstance(obj, Isotope):
                 obj._host_array_assigned("_crossSection_host")
+                obj._xs_installed = False            # (the zeros above are the reference's reset, not somebody's array)
                 obj._inputs_version += 1             # (a merged layer step computed from this isotopologue is stale too)
             obj.progressCrossSection = False
     if isinstance(obj, Isotope):
@@ -370,6 +371,7 @@ def _mark_computed(ctx, isotopes, n):
         iso._xs_version += 1
         iso._dev_xsec_valid = True
         iso._xs_deferred = False
+        iso._xs_installed = False
         Isotope.crossSection.defer(iso, (lambda b=iso._dev_xsec, n=n: b.download(n, pinned=True)))
         iso._regime_counts = None
         iso.progressCrossSection = True
@@ -423,7 +425,7 @@ class _OpticalMixin:
         lbl = [i for i in flat if not i.exotic]
         dirty = [i for i in lbl if not i.progressCrossSection]
         fusable = (dirty and len(dirty) == len(flat) and g["resolution"] == g["base_resolution"]
-                   and g["n_work"] == n and len(flat) <= 48)
+                   and g["n_work"] == n and len(flat) <= nat.limit("arrays_per_layer"))
         if self._merged_step_applies(flat, lbl):
             # A LAYER whose line lists are due (any of them dirty): ONE accumulate job over the merged, factor-weighted
             # line lists - the absorption coefficient sum_m f_m sum_iso xs_iso (cls:707-712, 581-583, 566-571) accumulated
@@ -585,6 +587,8 @@ class Isotope(_OpticalMixin, list):
         self._dev_xsec_valid = False
         self._xs_version = 0
         self._xs_deferred = False        # marked computed by a merged layer step: the array itself is made when somebody reads it
+        self._xs_installed = False       # somebody assigned ``crossSection`` an array of their own (and nothing has recomputed it since):
+                                         # the layer's sums must use THAT array, as the reference's getters do (cls:32-35, 566-571)
         self._inputs_version = 0         # bumped by everything that marks the cross section dirty (resetCrossSection, new lines)
         self._regime_counts = (0, 0, 0)
         _copy_of_layer_cross_section(Isotope.crossSection, self, self.layer)
@@ -670,6 +674,7 @@ class Isotope(_OpticalMixin, list):
             self._dev_xsec_valid = False
             self._xs_deferred = False
             self._xs_version += 1
+            self._xs_installed = True
 
     def _defer_cross_section(self):
         """A merged layer step (one accumulate job over all the layer's line lists, settings.LAYER_STEP) has just produced
@@ -680,6 +685,7 @@ class Isotope(_OpticalMixin, list):
         if self.exotic or (self.progressCrossSection and not self._xs_deferred):
             return                                  # a computed, current array exists
         self._xs_deferred = True
+        self._xs_installed = False                  # (what stands now is computed from the lines)
         self._dev_xsec_valid = False
         self._xs_version += 1
         self._regime_counts = None
@@ -1070,7 +1076,9 @@ class Layer(_OpticalMixin, list):
         """settings.LAYER_STEP "merged" (default): the layer's property chain comes from one merged accumulate job when
         any of its line lists is due (all of them line-by-line: a measured cross-section table has no lines to merge).
         With every cross section current (somebody asked for each of them) the sweep kernel over those arrays is cheaper."""
-        return (settings.LAYER_STEP == "merged" and bool(lbl) and len(lbl) == len(flat) and len(flat) <= 48
+        return (settings.LAYER_STEP == "merged" and bool(lbl) and len(lbl) == len(flat)
+                and len(flat) <= nat.limit("merged_lists_per_job")      # (more line lists: the per-line-list step, up to "arrays_per_layer")
+                and not any(i._xs_installed and i.progressCrossSection for i in lbl)     # an installed array is not the lines' (advisor, round 5)
                 and any(not i.progressCrossSection or i._xs_deferred for i in lbl))
 
     def createCrossSection(self):
@@ -1249,17 +1257,24 @@ class Atmosphere(list):
         factor-weighted line lists, all of them in one launch sequence (lbl_layers_merged_accumulate_dev: the layers'
         absorption coefficients, cls:707-712), then one pass folds transmittance and emission bottom to top over those
         arrays (lbl_column_fold_dev, cls:714-716, 784-787) and leaves every layer's transmittance resident for its own
-        getters.  None when a layer cannot take that route (no line list, or a measured cross-section table among its
-        molecules): the caller then goes through the per-line-list cross sections."""
+        getters.  A layer that cannot be a merged job (no line list, a measured cross-section table among its molecules, more
+        line lists than a job takes, an installed cross section) brings its absorption coefficient by its own route
+        (_ensure_swept) and is folded with the others.  None only when settings.LAYER_STEP is not "merged": the caller then
+        goes through the per-line-list cross sections of the whole column (lbl_column_step_dev)."""
         if settings.LAYER_STEP != "merged":
             return None
         plan = []
         for L in layers:
             members, conc = L._sweep_members()
             flat = [iso for isos in members for iso in isos]
-            if not flat or any(i.exotic for i in flat) or len(flat) > 48:
-                return None
             g = L._grid()
+            if (not flat or any(i.exotic for i in flat) or len(flat) > nat.limit("merged_lists_per_job")
+                    or any(i._xs_installed and i.progressCrossSection for i in flat)):
+                # a layer that cannot be one merged job (no line list, a measured cross-section table, more line lists than a
+                # job takes, somebody's own array installed): its own route leaves the same resident absorption coefficient
+                st, _ = L._ensure_swept()
+                plan.append((L, st, g, members, flat, conc, None))
+                continue
             _check_window(g)
             st = L.__dict__.get("_sweep_state")
             if st is None:
@@ -1267,7 +1282,7 @@ class Atmosphere(list):
             st.reserve(ctx, n)
             plan.append((L, st, g, members, flat, conc, L._merged_key(flat, conc, L, g)))
         # (a layer's absorption coefficient stands as long as everything but the depth is what it was computed from)
-        todo = [p for p in plan if not (isinstance(p[1].key, tuple) and p[1].key[:-1] == p[6][:-1])]
+        todo = [p for p in plan if p[6] is not None and not (isinstance(p[1].key, tuple) and p[1].key[:-1] == p[6][:-1])]
         ctx.layers_merged_accumulate_dev(
             [dict(lines=[i._device_lines(ctx) for i in flat], iso=[_iso_params(i) for i in flat],
                   grid=_engine.native_grid(g), iso_mol=[m for m, isos in enumerate(members) for _ in isos], conc=conc,
@@ -1287,21 +1302,25 @@ class Atmosphere(list):
         # coefficient, as after changeDepth (_ensure_swept: key equal up to its last entry).
         host = ctx.host_array(n)
         pieces = 4 if n >= (1 << 16) else 1
-        step = max(((n + pieces - 1) // pieces + 1) & ~1, 2)
-        for lo in range(0, n, step):
-            cnt = min(step, n - lo)
-            ctx.column_fold_dev([p[1].bufs["abs_coef"] for p in plan], [p[0].T for p in plan], [p[0].depth for p in plan],
-                                first.rangeMin, first.rangeMax, n, out, I_in=I_in, surface_T=float(surfaceTemperature or 0.0),
-                                first=lo, count=cnt)
-            out.download_async(host, cnt, lo, lo)
-        for (L, st, g, members, flat, conc, key) in plan:
-            if st.key != key:
-                st.key = key[:-1] + ("absorption coefficient only",)
-        for (L, st, g, members, flat, conc, key) in todo:
-            for iso in flat:
-                iso._defer_cross_section()
-            L._members_ready()
-        ctx.download_wait()
+        step = max(((n + pieces - 1) // pieces + 3) & ~3, 4)
+        try:
+            for lo in range(0, n, step):
+                cnt = min(step, n - lo)
+                ctx.column_fold_dev([p[1].bufs["abs_coef"] for p in plan], [p[0].T for p in plan], [p[0].depth for p in plan],
+                                    first.rangeMin, first.rangeMax, n, out, I_in=I_in, surface_T=float(surfaceTemperature or 0.0),
+                                    first=lo, count=cnt)
+                out.download_async(host, cnt, lo, lo)
+            for (L, st, g, members, flat, conc, key) in plan:
+                if key is not None and st.key != key:
+                    st.key = key[:-1] + ("absorption coefficient only",)
+            for (L, st, g, members, flat, conc, key) in todo:
+                for iso in flat:
+                    iso._defer_cross_section()
+                L._members_ready()
+        finally:
+            # (also when a piece raised: copies into `host` may be in flight, and its page-locked block must not go back to
+            # the pool before they have landed - advisor, round 5)
+            ctx.download_wait()
         return host
 
 

@@ -874,9 +874,93 @@ def g11():
     save("G11_plots", **arrays)
 
 
+
+# ----------------------------------------------------------------------------
+# G12: HITRAN-shaped rows (round-5 verdict, item 3b): what real .pyr rows hand to createCrossSection beside the seeded
+# lists' gamma in [0.05, 0.12], n in [0.5, 0.8], delta <= 0 (ut:421-448 reads whatever the columns hold): gamma_self = 0,
+# gamma_air = 0 (both: lorentzHW = 0 -> hwRatio < 0.01 -> the Gaussian-only branch over the full 500-point window at 1013
+# mbar, cls:379-381), n_air < 0, delta_air > 0, E" = -1 (HITRAN's "unknown"), S = 0, wavenumbers on exact grid multiples and
+# on the window's ends, the same wavenumber in two isotopologues, very weak and very strong lines, a very wide line.
+# ----------------------------------------------------------------------------
+def g12():
+    rmin, rmax = 600, 700
+    rng = np.random.default_rng(1200)
+    special = [
+        #  nu         sw       elower  g_air   g_self  d_air    n_air
+        (612.340000, 3e-21,    500.0,  0.0,    0.0,    -0.002,  0.7),     # Gaussian-only, W = 500
+        (612.345678, 2e-21,    800.0,  0.0,    0.0,     0.0,    0.0),     # Gaussian-only, no shift, n = 0
+        (620.000000, 5e-22,   1200.0,  0.07,   0.0,    -0.003,  0.75),    # gamma_self = 0
+        (620.010000, 4e-21,    300.0,  0.0,    0.09,   -0.001,  0.6),     # gamma_air = 0: lorentzHW = q * gamma_self (tiny)
+        (630.500000, 1e-20,    900.0,  0.08,   0.1,    -0.004, -0.3),     # n_air < 0
+        (631.250000, 8e-21,   1500.0,  0.06,   0.08,    0.006,  0.65),    # delta_air > 0
+        (640.000000, 6e-21,     -1.0,  0.07,   0.09,   -0.002,  0.7),     # E" = -1
+        (641.000000, 0.0,      700.0,  0.07,   0.09,   -0.002,  0.7),     # S = 0
+        (650.000000, 2e-20,    100.0,  0.075,  0.095,  -0.001,  0.72),    # exact grid multiples
+        (650.010000, 1e-20,    150.0,  0.065,  0.085,   0.0,    0.68),
+        (650.020000, 3e-40,    150.0,  0.065,  0.085,  -0.002,  0.68),    # very weak
+        (655.123456, 7e-21,   2000.0,  0.09,   0.11,   -0.005,  0.55),    # the same wavenumber in the second isotopologue
+        (660.000000, 5e-16,     50.0,  0.05,   0.06,   -0.001,  0.5),     # very strong
+        (670.300000, 2e-21,    400.0,  0.5,    0.6,    -0.002,  0.7),     # very wide
+        (600.000000, 1e-20,    600.0,  0.07,   0.09,   -0.002,  0.7),     # on the window's lower end
+        (699.990000, 1e-20,    600.0,  0.07,   0.09,   -0.002,  0.7),     # last grid point
+        (700.000000, 1e-20,    600.0,  0.07,   0.09,   -0.002,  0.7),     # on the window's upper end (index N: outside)
+        (596.000000, 4e-21,    600.0,  0.0,    0.0,    -0.002,  0.7),     # Gaussian-only line 4 cm^-1 below the window
+    ]
+    sp = np.array(special)
+    n_fill = 60
+    lo, hi = synthetic.layer_window(1013.25, rmin, rmax)
+    fill = synthetic.make_lines(1201, n_fill, lo, hi)
+    lines = dict(nu=np.concatenate([sp[:, 0], fill["nu"]]), sw=np.concatenate([sp[:, 1], fill["sw"]]),
+                 a=np.ones(len(sp) + n_fill), elower=np.concatenate([sp[:, 2], fill["elower"]]),
+                 gamma_air=np.concatenate([sp[:, 3], fill["gamma_air"]]), gamma_self=np.concatenate([sp[:, 4], fill["gamma_self"]]),
+                 delta_air=np.concatenate([sp[:, 5], fill["delta_air"]]), n_air=np.concatenate([sp[:, 6], fill["n_air"]]))
+    order = np.argsort(lines["nu"], kind="stable")
+    lines = {k: v[order] for k, v in lines.items()}
+    # second isotopologue: shares 655.123456 and 650.000000 with the first list, has rows of its own kind
+    n2 = 40
+    l2 = synthetic.make_lines(1202, n2, lo, hi)
+    l2["nu"][5], l2["nu"][6] = 655.123456, 650.000000
+    l2["gamma_self"][7] = 0.0
+    l2["gamma_air"][8], l2["gamma_self"][8] = 0.0, 0.0
+    l2["elower"][9] = -1.0
+    l2["delta_air"][10] = 0.008
+    l2["n_air"][11] = -0.5
+    order = np.argsort(l2["nu"], kind="stable")
+    l2 = {k: v[order] for k, v in l2.items()}
+    arrays = {}
+    for T in (296, 250):
+        cfg = dict(depth=10.0, T=T, P=1013.25, range_min=rmin, range_max=rmax, base_resolution=.01,
+                   dynamic_resolution=True, surface_T=288,
+                   molecules=[dict(species="co2", conc=dict(ppm=400), lines=lines, lines2=l2, isotope_depth=2),
+                              dict(species="h2o", conc={"%": 1.0}, lines=fill)])
+        ref, layer = run_reference_layer(cfg)
+        t = "T%d." % T
+        arrays[t + "iso0.xsec"] = ref["iso_xsec"][0][0]
+        arrays[t + "iso1.xsec"] = ref["iso_xsec"][0][1]
+        arrays[t + "h2o.xsec"] = ref["xsec"][1]
+        arrays[t + "abs_coef"] = ref["abs_coef"]
+        if T == 296:                       # (the molecule's sum and the swept arrays once: the file stays below 1 MB)
+            arrays[t + "co2.xsec"] = ref["xsec"][0]
+            arrays[t + "transmittance"] = ref["transmittance"]
+            arrays[t + "transmission"] = ref["transmission"]
+        arrays[t + "line_lhw"] = ref["line_lhw"]; arrays[t + "line_ghw"] = ref["line_ghw"]
+        arrays[t + "line_broadened"] = ref["line_broadened"]; arrays[t + "line_index"] = ref["line_index"]
+        arrays[t + "line_nu"] = ref["line_nu"]
+        # which branch the reference's regime select takes per line of the first list (cls:378-387)
+        ratio = ref["line_lhw"] / ref["line_ghw"]
+        arrays[t + "regime"] = np.where(ratio < 0.01, 0, np.where(ratio > 100, 1, 2)).astype(np.int64)
+    arrays.update(cfg_scalars(cfg))
+    arrays.update(pack_lines("lines", lines)); arrays.update(pack_lines("lines2", l2)); arrays.update(pack_lines("h2o.lines", fill))
+    # the Gaussian-only line alone: its support is the full window (cls:379-381, 392-400)
+    one = {k: v[lines["nu"] == 612.34] for k, v in lines.items()}
+    r, _ = run_reference_layer(dict(cfg, T=296, molecules=[dict(species="co2", conc=dict(ppm=400), lines=one)]))
+    arrays["gauss_only.xsec"] = r["xsec"][0]
+    save("G12_hitran_shaped_rows", **arrays)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REFERENCE):
         sys.exit("needs /root/reference (build container only)")
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for name in which:
         globals()[name]()

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(lib, name), "libpyrad_hip.so does not export %s" % name
     # the ctypes binding declares a signature for each of them and nothing else
     assert sorted(_native.SIGNATURES) == names
-    assert lib.lbl_abi_version() == 4
+    assert lib.lbl_abi_version() == 5
 
 
 def test_struct_layouts_match_header():

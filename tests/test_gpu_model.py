@@ -542,3 +542,133 @@ def test_atmosphere_transmission_in_pieces_equals_one_pass(pyrad):
         assert rel_err(pyrad.getTransmittance(atm[1]), np.exp(-k * atm[1].depth), floor=1e-300) <= 1e-9
     finally:
         settings.set_resolution_multiplier(keep)
+
+
+def _many_isotopologue_source(molecule_ids, n_lines, lo, hi, seed=700):
+    """A MemorySource holding a small line list for EVERY isotopologue of the given HITRAN molecule numbers (global
+    isotopologue ids from the model's table, cls:951-1016), with a power-law partition sum and a molar mass per id."""
+    from pyrad_amd import data, model
+    src = data.MemorySource()
+    spec = {}
+    for m in molecule_ids:
+        for k, gid in model.HITRAN_GLOBAL_ISO[m].items():
+            lines = synthetic.make_lines(seed + gid, n_lines, lo, hi)
+            q296, beta, molmass = 150.0 + 7.0 * gid, 1.0 + 0.01 * (gid % 50), 16.0 + 0.37 * gid
+            t = np.arange(1, 1001, dtype=np.float64)
+            q = {int(a): float(b) for a, b in zip(t, q296 * (t / 296.0) ** beta)}
+            src.register(gid, lines, q, [gid, "M%d" % m, m, k, 1.0, q296, 1, molmass])
+            spec[gid] = dict(lines=lines, q=q, q296=q296, molmass=molmass)
+    data.set_source(src)
+    return spec
+
+
+@pytest.mark.parametrize("molecule_ids,n_lists", [((1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14), 57),
+                                                   ((1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19), 74)])
+def test_layer_of_any_size_against_the_oracle(pyrad, molecule_ids, n_lists):
+    """The reference sums however many molecules and isotopologues a layer holds (cls:566-571, 707-712; addMolecule with
+    isotopeDepth, cls:757-779, 446).  57 line lists: one merged accumulate job (the library takes 64 per job); 74: more
+    than a merged job or a sweep's argument block holds - the per-line-list step, swept by the column-step kernel on a
+    column of one layer.  Every point against the oracle's sum over 57 / 74 cross sections, through model.Layer; a column
+    containing such a layer through Atmosphere.transmission (round-5 verdict, item 3c)."""
+    from oracle import pyrad_oracle as orc
+    from pyrad_amd import _native as nat, settings
+    spec = _many_isotopologue_source(molecule_ids, 300, 590, 710)
+    assert nat.limit("merged_lists_per_job") == 64 and nat.limit("arrays_per_layer") == 511
+
+    def build(T, P, atmosphere=None):
+        if atmosphere is None:
+            pyrad.Layer.hasAtmosphere = False
+            layer = pyrad.Layer(1000.0, T, P, 600, 700)
+        else:
+            layer = atmosphere.addLayer(1000.0, T, P, 600, 700)
+        for j, m in enumerate(molecule_ids):
+            layer.addMolecule(m, isotopeDepth=len(pyrad.HITRAN_GLOBAL_ISO[m]), ppm=50.0 + 10.0 * j)
+        return layer
+
+    def oracle_k(layer):
+        g = orc.layer_grid(layer.P, 600, 700, 0.01, True)
+        k = np.zeros(g["n_base"])
+        for mol in layer:
+            xs_m = np.zeros(g["n_base"])
+            for iso in mol:
+                s = spec[iso.globalIsoNumber]
+                sel = orc.select_window(s["lines"], g["eff_min"], g["eff_max"])
+                xs = orc.create_cross_section(sel, layer.T, layer.P, mol.concentration, s["molmass"],
+                                              s["q"][int(layer.T)], s["q296"], g)[0]
+                xs_m = xs_m + xs
+            k = k + orc.abs_coef(xs_m, mol.concentration, layer.P, layer.T)
+        return k
+
+    layer = build(296, 1013.25)
+    assert sum(len(m) for m in layer) == n_lists
+    k_ref = oracle_k(layer)
+    k = np.array(pyrad.getAbsCoef(layer))
+    assert rel_err(k, k_ref) <= RTOL
+    merged = n_lists <= 64
+    assert all(iso._xs_deferred == merged for m in layer for iso in m)          # which route ran
+    assert rel_err(pyrad.getTransmittance(layer), np.exp(-k_ref * layer.depth), floor=1e-300) <= 1e-9
+    # the per-line-list route on the same layer (a sweep over 57 arrays fits its argument block; 74 go through the column-step kernel)
+    settings.set_layer_step("per-list")
+    try:
+        other = build(296, 1013.25)
+        assert rel_err(pyrad.getAbsCoef(other), k_ref) <= RTOL
+        xs_layer = np.array(pyrad.getCrossSection(other))                      # sum of 14 / 19 molecule sums of up to 12 arrays
+        assert xs_layer.shape == k_ref.shape and np.all(np.isfinite(xs_layer))
+    finally:
+        settings.set_layer_step("merged")
+    # a column with such a layer between two ordinary ones
+    pyrad.Layer.hasAtmosphere = False
+    atm = pyrad.Atmosphere("col")
+    small = []
+    for T, P in ((288, 1013.25), (250, 400.0)):
+        L = atm.addLayer(2000.0, T, P, 600, 700)
+        L.addMolecule(2, ppm=400)
+        small.append(L)
+    big = build(270, 700.0, atmosphere=atm)
+    order = [small[0], big, small[1]]
+    atm[:] = order
+    got = np.array(atm.transmission(surfaceTemperature=288))
+    xa = orc.x_axis(600, 700, 0.01)
+    I = orc.planckWavenumber(xa, 288)
+    for L in order:
+        tr = orc.transmittance(oracle_k(L), L.depth)
+        I = orc.transmission(tr, I, orc.planckWavenumber(xa, L.T))
+    assert rel_err(got, I) <= RTOL
+
+
+def test_an_installed_cross_section_is_what_the_layer_sums(pyrad):
+    """advisor, round 5: ``iso.crossSection = array`` with progressCrossSection left set is what the reference's getters use
+    (getCrossSection does not recompute, cls:32-35); when a SIBLING line list is due, the merged layer step (all lines of
+    the layer) would silently recompute the layer from the installed isotopologue's LINES.  A layer holding an installed
+    array takes the per-line-list route: merged setting and per-list setting agree, and both show the installed array."""
+    from pyrad_amd import settings
+    z = load_golden("G6_composition")
+    source(co2=unpack_lines(z, "co2.lines"), co2_636=unpack_lines(z, "co2_636.lines"), h2o=unpack_lines(z, "h2o.lines"))
+
+    def run(step):
+        settings.set_layer_step(step)
+        try:
+            pyrad.Layer.hasAtmosphere = False
+            layer = pyrad.Layer(float(z["depth"]), int(z["T"]), float(z["P"]), 1000, 1040)
+            layer.addMolecule('co2', isotopeDepth=2, ppm=400)
+            layer.addMolecule('h2o', **{'%': 1.5})
+            k0 = np.array(pyrad.getAbsCoef(layer))
+            xs0 = np.array(pyrad.getCrossSection(layer[0][0]))
+            layer[0][0].crossSection = 3.0 * xs0                      # somebody's own array; the flag stays set
+            assert layer[0][0].progressCrossSection
+            pyrad.resetCrossSection(layer[0][1])                      # a sibling is due
+            k1 = np.array(pyrad.getAbsCoef(layer))
+            assert np.array_equal(layer[0][0].crossSection, 3.0 * xs0)
+            layer.changeTemperature(250)                              # resets everything: the installed array is gone (cls:38-45)
+            k2 = np.array(pyrad.getAbsCoef(layer))
+            return k0, k1, k2, xs0
+        finally:
+            settings.set_layer_step("merged")
+
+    a, b = run("merged"), run("per-list")
+    for x, y in zip(a, b):
+        assert rel_err(x, y) <= 1e-13
+    k0, k1, k2, xs0 = a
+    f = 400e-6 * float(z["P"]) / 1e4 / 1.38064852E-23 / int(z["T"])
+    assert rel_err(k1 - k0, 2.0 * xs0 * f, floor=float(np.max(k0)) * 1e-3) <= 1e-9      # the layer gained exactly 2 x that cross section
+    assert rel_err(k2, k0) > 1e-3

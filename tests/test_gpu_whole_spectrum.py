@@ -121,18 +121,27 @@ def test_whole_spectrum_cell_vs_c_oracle(ctx, workload, mode):
             assert np.all(e <= ((tol * k_ref * cfg["depth"] + 4e-16) * tr + 2e-15) * np.maximum(orc.planckWavenumber(xa, 288), xs_planck))
             # the same cell through ONE merged accumulate job (lbl_layer_merged_step_dev): the absorption coefficient
             # sum_m f_m sum_iso xs_iso accumulated directly, no cross-section array written (the outputs are poisoned first)
-            for b in (L.abs_coef, L.trans, L.I_out):
-                b.fill(float("nan"))
-            L.enqueue(surface_T=288, merged=True)
-            r = L.results()
-            worst("%s %s variant %d MERGED abs_coef" % (workload, mode, variant), r["abs_coef"], k_ref, tol)
-            e = np.abs(r["transmittance"] - tr)
-            assert np.all(e <= (tol * k_ref * cfg["depth"] + 4e-16) * tr + 1e-300)
-            e = np.abs(r["transmission"] - xs_planck)
-            assert np.all(e <= ((tol * k_ref * cfg["depth"] + 4e-16) * tr + 2e-15) * np.maximum(orc.planckWavenumber(xa, 288), xs_planck))
+            # (round 6: the far-field kernel's production shape exists in two builds - Gaussian runs of 16 points at four
+            # waves per SIMD and of 32 points at three - and the library picks by the size of the launch: both are forced here)
+            for grun in ((16, 32) if variant == 5 and workload == "C3" else (0,)):
+                ctx.set_option("accum_gauss_run", grun)
+                for b in (L.abs_coef, L.trans, L.I_out):
+                    b.fill(float("nan"))
+                L.enqueue(surface_T=288, merged=True)
+                r = L.results()
+                worst("%s %s variant %d MERGED (Gaussian runs: %d) abs_coef" % (workload, mode, variant, grun), r["abs_coef"], k_ref, tol)
+                e = np.abs(r["transmittance"] - tr)
+                assert np.all(e <= (tol * k_ref * cfg["depth"] + 4e-16) * tr + 1e-300)
+                e = np.abs(r["transmission"] - xs_planck)
+                assert np.all(e <= ((tol * k_ref * cfg["depth"] + 4e-16) * tr + 2e-15) * np.maximum(orc.planckWavenumber(xa, 288), xs_planck))
+                if grun:
+                    L.enqueue(surface_T=288)             # the per-list step through the same build
+                    worst("%s %s variant %d per-list (Gaussian runs: %d) abs_coef" % (workload, mode, variant, grun),
+                          L.results()["abs_coef"], k_ref, tol)
         finally:
             ctx.set_option("accum_variant", 5)
             ctx.set_option("accuracy", 0)
+            ctx.set_option("accum_gauss_run", 0)
     L.free()
 
 
@@ -238,3 +247,42 @@ def test_whole_spectrum_windows_at_the_kernel_routing_boundary(ctx, W):
     L.enqueue(surface_T=288, merged=True)              # the same window through one merged accumulate job
     worst("W = %d MERGED abs_coef" % W, L.results()["abs_coef"], k_ref, tol)
     L.free()
+
+
+@pytest.mark.parametrize("mode", ["exact", "budget"])
+@pytest.mark.parametrize("G,rank", [(8, 4), (2, 1)])
+def test_whole_spectrum_merged_shard_vs_c_oracle(ctx, G, rank, mode):
+    """What rank `rank` of G computes in `bench.py --gpus G` (BASELINE config 4, merged step, cost-balanced bounds): its
+    contiguous range of the 100-2500 cm^-1 cell from its halo of lines, ONE merged accumulate job, with the launch shape
+    the library picks for a launch of that size (a shard of 8: four waves per span; the whole cell: unsplit spans with
+    32-point Gaussian runs) - EVERY point of the range against the C oracle run on the same lines (round-5 verdict, item 3a)."""
+    from oracle import pyrad_oracle as orc
+    from pyrad_amd import engine
+    cfg = synthetic.config_c3()
+    mols = mols_of(cfg)
+    g = orc.layer_grid(cfg["P"], cfg["range_min"], cfg["range_max"], cfg["base_resolution"], cfg["dynamic_resolution"])
+    plan = engine.balanced_shards([dict(cfg, molecules=mols)], G, rank)
+    part = engine.ResidentLayer(ctx, cfg["depth"], cfg["T"], cfg["P"], cfg["range_min"], cfg["range_max"], mols,
+                                cfg["base_resolution"], cfg["dynamic_resolution"], shard=plan, keep_host_lines=True)
+    sl = slice(part.first, part.first + part.count)
+    jobs = [(lines, cfg["T"], cfg["P"], m["conc"], m["isotopologues"][0]["molmass"], m["isotopologues"][0]["q_T"],
+             m["isotopologues"][0]["q296"], g) for m, lines in zip(mols, part._keep)]
+    res = oracle_xsecs(jobs)
+    k_ref = np.zeros(g["n_base"])
+    for m, (xs, _, _) in zip(mols, res):
+        k_ref = k_ref + orc.abs_coef(np.zeros(g["n_base"]) + xs, m["conc"], cfg["P"], cfg["T"])
+    xa = orc.x_axis(cfg["range_min"], cfg["range_max"], cfg["base_resolution"])
+    tol = tolerance(mode, xa, cfg["T"], g["dfc"])
+    ctx.set_option("accuracy", MODES[mode][0])
+    try:
+        for b in (part.abs_coef, part.trans, part.I_out):
+            b.fill(float("nan"))
+        part.enqueue(surface_T=288, merged=True)
+        r = part.results()
+    finally:
+        ctx.set_option("accuracy", 0)
+    worst("C3 %s merged shard %d of %d (%d points) abs_coef" % (mode, rank, G, part.count), r["abs_coef"][sl], k_ref[sl], tol[sl])
+    tr = orc.transmittance(k_ref, cfg["depth"])[sl]
+    e = np.abs(r["transmittance"][sl] - tr)
+    assert np.all(e <= (tol[sl] * k_ref[sl] * cfg["depth"] + 4e-16) * tr + 1e-300)
+    part.free()

@@ -270,3 +270,48 @@ def test_c_oracle_matches_numpy_oracle_and_golden():
     work, counts, _ = c_oracle.create_cross_section_work(selb, 220, 0.05, 4e-4, sp["molmass"],
                                                          synthetic.q_value("co2", 220), sp["q296"], grid)
     assert counts[0] > 5 and rel_err(work, z5["b.xsec"]) <= TOL
+
+
+def test_g12_hitran_shaped_rows():
+    """Rows of the kinds real HITRAN files hold beside the seeded lists' ranges (gamma_self = 0, gamma_air = 0 - both: the
+    Gaussian-only branch over the full 500-point window at 1013 mbar, cls:379-381 - n_air < 0, delta_air > 0, E" = -1, S = 0,
+    wavenumbers on exact grid multiples and on the window's ends, one wavenumber in two isotopologues, 1e-40 and 5e-16
+    intensities, a 0.5 cm^-1 half-width), computed by the reference's own classes: NumPy and C restatements, per-line
+    quantities, regime select, both isotopologues, two temperatures (round-5 verdict, item 3b)."""
+    from oracle import c_oracle
+    c_oracle.build(); c_oracle.load()
+    z = load_golden("G12_hitran_shaped_rows")
+    grid = orc.layer_grid(1013.25, 600, 700, .01, True)
+    assert grid["W"] == 500
+    for T in (296, 250):
+        t = "T%d." % T
+        k = np.zeros(grid["n_base"])
+        xs_co2 = np.zeros(grid["n_base"])
+        for tag, species, key in (("lines", "co2", "iso0"), ("lines2", "co2_636", "iso1")):
+            sel = orc.select_window(unpack_lines(z, tag), grid["eff_min"], grid["eff_max"])
+            sp = synthetic.SPECIES[species]
+            xs, counts = orc.create_cross_section(sel, T, 1013.25, 4e-4, sp["molmass"], synthetic.q_value(species, T), sp["q296"], grid)[:2]
+            assert rel_err(xs, z[t + key + ".xsec"]) <= TOL
+            work, c_counts, _ = c_oracle.create_cross_section_work(sel, T, 1013.25, 4e-4, sp["molmass"], synthetic.q_value(species, T),
+                                                                   sp["q296"], grid)
+            assert rel_err(work, z[t + key + ".xsec"]) <= TOL and tuple(c_counts) == tuple(counts)
+            if tag == "lines":
+                assert tuple(counts) == tuple(np.bincount(z[t + "regime"], minlength=3)) and counts[0] == 3
+                lq = orc.line_quantities(sel, T, 1013.25, 4e-4, sp["molmass"], 600, .01)
+                # the reference's Line objects come out of a dict keyed by wavenumber: same order as the sorted selection
+                assert np.array_equal(sel["nu"], z[t + "line_nu"]) and np.array_equal(lq["index"], z[t + "line_index"])
+                assert rel_err(lq["lhw"], z[t + "line_lhw"]) <= 4e-16 and rel_err(lq["ghw"], z[t + "line_ghw"]) <= 4e-16
+            xs_co2 = xs_co2 + xs
+        k = k + orc.abs_coef(xs_co2, 4e-4, 1013.25, T)
+        sp = synthetic.SPECIES["h2o"]
+        sel = orc.select_window(unpack_lines(z, "h2o.lines"), grid["eff_min"], grid["eff_max"])
+        xs = orc.create_cross_section(sel, T, 1013.25, 0.01, sp["molmass"], synthetic.q_value("h2o", T), sp["q296"], grid)[0]
+        assert rel_err(xs, z[t + "h2o.xsec"]) <= TOL
+        k = k + orc.abs_coef(xs, 0.01, 1013.25, T)
+        assert rel_err(k, z[t + "abs_coef"]) <= TOL
+    assert rel_err(xs_co2 * 0 + z["T296.co2.xsec"], z["T296.iso0.xsec"] + z["T296.iso1.xsec"]) <= 1e-15
+    one = {f: v[unpack_lines(z, "lines")["nu"] == 612.34] for f, v in unpack_lines(z, "lines").items()}
+    sp = synthetic.SPECIES["co2"]
+    xs = orc.create_cross_section(one, 296, 1013.25, 4e-4, sp["molmass"], synthetic.q_value("co2", 296), sp["q296"], grid)[0]
+    assert np.array_equal(xs != 0, z["gauss_only.xsec"] != 0) and rel_err(xs, z["gauss_only.xsec"]) <= TOL
+    assert np.count_nonzero(xs) == 3              # 7e-4 cm^-1 wide on a 0.01 grid: the rest of the 500-point window underflows to 0
