@@ -320,6 +320,161 @@ def api_path_column(cfg, reps=5):
         engine.shutdown()
 
 
+def choose_step(step_arg, n_points, n_lists, n_layers, shard_world, unfused=False, variant=None):
+    """--step auto: the merged step unless the cell's per-list accumulate launch is at most about two rounds of workgroups
+    (measured on shards of the 100-2500 cm^-1 cell, per-list / merged: of 8 0.0575 / 0.0589 ms, of 4 0.0943-0.0961 /
+    0.0970-0.0975, of 2 0.1658-0.1680 / 0.1559-0.1577, the whole cell 0.306 / 0.260)."""
+    few_rounds = float(n_points) * n_lists / shard_world <= 2.1 * 4.0 * 256 * 1024
+    return (step_arg == "merged" or (step_arg == "auto" and not (few_rounds and n_lists > n_layers))) \
+        and not unfused and variant in (None, 3, 5)
+
+
+def workload_leg(name, device, steps, warmup, step_arg="auto", accuracy="exact", want_api=True, shards="auto",
+                 ctx=None, comm=None, world=1, rank=0, red=None, cfg_desc=None):
+    """One BASELINE configuration beside the line's own (round-5 verdict, item 2: C1, C2 and C5 had only ever been timed by
+    the builder): the resident step of that workload, `steps` steps between stream syncs after `warmup` steps and a tenth
+    of a second of preconditioning, then a few steps with every kernel class bracketed by events.  world > 1 (C5 under
+    `--gpus N`): every rank computes its contiguous grid range of all layers (the fold is independent per grid point) and
+    ONE all-gather per step collects the outgoing spectrum (in stream: a step's spectrum is complete before the next step
+    starts); ms_per_step is then the max over ranks between RCCL barriers, and the breakdown times the step's kernels and
+    its all-gather separately.  Untimed-region style: not the line's value."""
+    from pyrad_amd import _native as nat, engine
+    cfg, desc = cfg_desc if cfg_desc is not None else build_workload(name, 1)
+    is_column = name == "C5"
+    if is_column:
+        layer_cfgs = [dict(c, molecules=molecules_of(c)) for c in cfg["layers"]]
+    else:
+        layer_cfgs = [dict(cfg, molecules=molecules_of(cfg))]
+    own_ctx = ctx is None
+    if own_ctx:
+        ctx = nat.Context(device)
+        if accuracy == "budget":
+            ctx.set_option("accuracy", 1)
+    shard, shard_choice = None, "none"
+    if world > 1:
+        shard, shard_choice = engine.choose_shards(layer_cfgs, world, rank, shards)
+    t0 = time.perf_counter()
+    if is_column:
+        L = engine.ResidentColumn(ctx, layer_cfgs, cfg["surface_T"], shard=shard)
+        g = L.layers[0].g
+        n_lists, n_layers = len(L.jobs), len(L.layers)
+    else:
+        c = layer_cfgs[0]
+        L = engine.ResidentLayer(ctx, c["depth"], c["T"], c["P"], c["range_min"], c["range_max"], c["molecules"],
+                                 c["base_resolution"], c.get("dynamic_resolution", True), shard=shard)
+        g = L.g
+        n_lists, n_layers = len(L.jobs), 1
+    merged = choose_step(step_arg, g["n_work"], n_lists, n_layers, world)
+    kw = dict(layer_arrays=False, merged=merged) if is_column else dict(surface_T=288.0, merged=merged)
+
+    def one():
+        L.enqueue(**kw)
+        if comm is not None:
+            if is_column:
+                L.enqueue_allgather(comm)
+            else:
+                L.enqueue_allgather(comm, (L.abs_coef,))
+
+    def barrier():
+        ctx.sync()
+        if comm is not None:
+            comm.fence_dev(-1)
+            ctx.sync()
+            comm.allgather_dev(red, rank, 1, red)
+            ctx.sync()
+
+    def max_over_ranks(v):
+        if comm is None:
+            return float(v), [float(v)]
+        red.upload(np.array([v], dtype=np.float64), offset=rank)
+        comm.allgather_dev(red, rank, 1, red)
+        a = red.download(world)
+        return float(a.max()), [float(x) for x in a]
+
+    one()
+    barrier()
+    t_setup = time.perf_counter() - t0
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.1:
+        for _ in range(5):
+            one()
+        ctx.sync()
+    for _ in range(warmup):
+        one()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    barrier()
+    t_step, t_by_rank = max_over_ranks((time.perf_counter() - t0) / steps)
+    classes = ["line_prep", "xsec_accumulate", "layer_sweep", "column_sweep"] + (["allgather"] if comm is not None else [])
+    n_extra = 3
+    ctx.profile_enable(classes)
+    ctx.profile_reset()
+    for _ in range(n_extra):
+        one()
+    barrier()
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    kernel_ms = {k: prof[k][1] / n_extra for k in classes if prof[k][0]}
+    evals_local = float(L.evals)
+    evals_total = evals_local
+    if comm is not None:
+        red.upload(np.array([evals_local], dtype=np.float64), offset=rank)
+        comm.allgather_dev(red, rank, 1, red)
+        evals_total = float(red.download(world).sum())
+    pts = L.count if L.plan is not None else g["n_work"]
+    out = {"workload": desc, "step": "merged" if merged else "per-list", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": t_step * 1e3, "evals_per_step": evals_total, "evals_per_s": evals_total / t_step,
+           "kernel_ms_per_step": kernel_ms, "grid_points_per_gpu": int(pts), "lines_per_gpu": int(L.n_lines),
+           "xsec_accumulate_launches_per_step": prof["xsec_accumulate"][0] / n_extra, "setup_s": t_setup, "accuracy": accuracy,
+           "what": "%d steps of the resident step between stream syncs (max over ranks) after %d warm-up steps and 0.1 s of the same "
+                   "steps; kernel_ms_per_step from %d further steps with every kernel class bracketed by HIP events (a pair of event "
+                   "records costs the stream a few microseconds: the parts can sum to more than ms_per_step); not the line's value"
+                   % (steps, warmup, n_extra)}
+    if is_column and merged and kernel_ms.get("column_sweep") and kernel_ms.get("line_prep"):
+        t_fold, t_k1 = kernel_ms["column_sweep"] * 1e-3, kernel_ms["line_prep"] * 1e-3
+        b_fold = 8.0 * pts * (n_layers + 1)                        # one absorption coefficient per layer read, the outgoing spectrum written
+        b_k1 = 128.0 * L.n_lines                                   # per line: 56 B of HITRAN fields + 4 B of the merged-order map read, 68 B of records written
+        out["fold"] = {"kernel": "column_step_kernel", "algorithmic_bytes_per_launch": b_fold, "avg_launch_ms": t_fold * 1e3,
+                       "hbm_frac": b_fold / t_fold / 1e9 / HBM_PEAK_GBS}
+        out["line_prep"] = {"kernel": "line_prep_merged_kernel", "algorithmic_bytes_per_launch": b_k1, "avg_launch_ms": t_k1 * 1e3,
+                            "hbm_frac": b_k1 / t_k1 / 1e9 / HBM_PEAK_GBS}
+    if comm is not None:
+        # where the sharded step's time goes: its kernels without the collective, and the collective alone, in stream
+        n_b = max(5, min(20, steps))
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_b):
+            L.enqueue(**kw)
+        barrier()
+        t_k, k_by_rank = max_over_ranks((time.perf_counter() - t0) / n_b)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_b):
+            if is_column:
+                L.enqueue_allgather(comm)
+            else:
+                L.enqueue_allgather(comm, (L.abs_coef,))
+        barrier()
+        t_g, _ = max_over_ranks((time.perf_counter() - t0) / n_b)
+        recv = (world - 1) * L.S * 8.0
+        out["config"] = {"shards": shard_choice, "shard_bounds": None if L.plan is None else [list(b) for b in L.plan.bounds],
+                         "allgather": "in stream, one per step: the outgoing spectrum" if is_column else "in stream, one per step: the absorption coefficient"}
+        out["sharded_step_breakdown"] = {"kernels_only_ms_per_step": t_k * 1e3, "kernels_only_ms_by_rank": [round(v * 1e3, 4) for v in k_by_rank],
+                                         "step_ms_by_rank": [round(v * 1e3, 4) for v in t_by_rank],
+                                         "allgather_alone_ms_per_step": t_g * 1e3, "allgather_bytes_received_per_rank_per_step": recv,
+                                         "allgather_alone_GBps_per_rank": (recv / t_g / 1e9) if t_g > 0 else None,
+                                         "what": "two short passes after the leg's timed steps, wall clock between barriers, max over ranks: the "
+                                                 "step's kernels with no all-gather, and its all-gather alone in stream"}
+    L.free()
+    if own_ctx:
+        ctx.close()
+    if want_api and world == 1 and rank == 0:
+        out["api_path"] = api_path_column(cfg) if is_column else api_path(cfg)
+    return out
+
+
 class _StdoutToStderr:
     """RCCL prints a version banner on stdout when a communicator is created; rank 0 must print
     exactly one JSON line there, so file descriptor 1 points at stderr while RCCL initialises."""
@@ -611,6 +766,10 @@ def main():
                          "ROCm 7.2: C1 0.021 vs 0.017 ms, C2 0.077 vs 0.074, a shard of 8 of C3 0.074 vs 0.071)")
     ap.add_argument("--lines", type=int, default=None, help="experiment: C2 with this many lines instead of 65,536")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--legs", default="auto",
+                    help="other BASELINE configurations timed after the line's own and reported as workload_legs (untimed-region style, "
+                         "not the value): a comma list of C1,C2,C3,C5 | none | auto = C1,C2,C5 beside the default workload on one GPU, "
+                         "and C5 sharded N-way with its single all-gather under --gpus N")
     ap.add_argument("--no-direct-pass", action="store_true",
                     help="skip the extra untimed pass of the all-direct kernel (profiles/collect.sh: keeps the PMC passes "
                          "to the kernels of the timed path)")
@@ -741,9 +900,7 @@ def main():
     # (auto: per-list for a cell of several line lists whose per-list accumulate launch is at most about two rounds of workgroups:
     #  measured on shards of the 100-2500 cm^-1 cell, per-list / merged: of 8 0.0575 / 0.0589 ms, of 4 0.0943-0.0961 / 0.0970-0.0975,
     #  of 2 0.1658-0.1680 / 0.1559-0.1577, the whole cell 0.306 / 0.260)
-    few_rounds = float(g0["n_work"]) * n_lists / shard_world <= 2.1 * 4.0 * 256 * 1024
-    merged = (args.step == "merged" or (args.step == "auto" and not (few_rounds and n_lists > len(layer_cfgs)))) \
-        and not args.unfused and args.variant in (None, 3, 5)
+    merged = choose_step(args.step, g0["n_work"], n_lists, len(layer_cfgs), shard_world, args.unfused, args.variant)
     step_kwargs = (dict(layer_arrays=bool(args.column_layer_arrays), merged=merged) if args.workload == "C5"
                    else dict(surface_T=288.0, fused=not args.unfused, merged=merged))
 
@@ -1210,6 +1367,10 @@ def main():
             result["budget_leg"] = budget_leg
         if per_list_leg is not None:
             result["per_list_leg" if merged else "merged_leg"] = per_list_leg
+        # the figure comparable with rounds 1-4 (whose step wrote one cross section per line list) stays on the top level,
+        # whichever step --step auto made the line's value (advisor, round 5)
+        result["value_step"] = "merged" if merged else "per-list"
+        result["value_per_list"] = value if not merged else (per_list_leg["evals_per_s"] * world if per_list_leg is not None else None)
         if ablated:
             result["ablated"] = True
             result["invalid"] = "a debug_* option was set: parts of the kernels are switched off, results are wrong, timing experiment only"
@@ -1221,6 +1382,20 @@ def main():
         if args.check:
             result["check"] = oracle_check(layer, cfg)
     want_api = rank == 0 and world == 1 and not args.no_api_path and not args.shard_of
+    legs = []
+    if args.legs == "auto":
+        if args.workload == "C3" and not args.shard_of and args.scale == 1 and strong and args.variant is None and not args.unfused:
+            legs = ["C1", "C2", "C5"] if (world == 1 and comm is None) else ["C5"]
+    elif args.legs != "none":
+        legs = [w for w in args.legs.split(",") if w]
+    leg_results = {}
+    if comm is not None and legs:
+        # every rank, in lockstep: the leg's workload sharded over the same ranks through the same communicator
+        for w in legs:
+            barrier()
+            leg_results[w] = workload_leg(w, local_rank, args.steps, args.warmup, args.step, args.accuracy, want_api=False,
+                                          shards=args.shards, ctx=ctx.first, comm=comm, world=world, rank=rank, red=red)
+        legs = []
     if rdzv is not None:
         rdzv.arrive("done")
         rdzv.cleanup()
@@ -1244,7 +1419,13 @@ def main():
             result["in_flight_leg"] = in_flight_leg(cfg, merged=merged)
         elif n_flight == 1:
             result["in_flight_leg"] = in_flight_leg(cfg, n_flight=2, steps=60, merged=merged)     # so that ratios can be formed in either mode
+    if rank == 0 and world == 1:
+        for w in legs:
+            leg_results[w] = workload_leg(w, local_rank, args.steps, args.warmup, args.step, args.accuracy,
+                                          want_api=(w == "C5" and not args.no_api_path))
     if rank == 0:
+        if leg_results:
+            result["workload_legs"] = leg_results
         print(json.dumps(result))
 
 

@@ -6,7 +6,7 @@
 # Counters are collected in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass,
 # MI355X_MICROARCH.md "rocprofv3 PMC slots") and never together with the trace domains.
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 WORKLOAD=${2:-C3}
 SHARD=$3          # optional "G,r": shard r of a G-way sharding (what a rank of a G-GPU run computes); label <workload>s<G>
 R=$GRAFT_REPO_ROOT
@@ -16,7 +16,11 @@ cd /tmp && export TMPDIR=/tmp
 WL=$WORKLOAD
 EXTRA=""
 if [ -n "$SHARD" ]; then WL=${WORKLOAD}s${SHARD%%,*}; EXTRA="--shard-of $SHARD"; fi
-CMD="$R/bench.py --steps 20 --warmup 3 --blocks 1 --no-cpu-baseline --no-api-path --no-direct-pass --workload $WORKLOAD $EXTRA"
+# (--step is pinned to what --step auto picks for the shape, so that the committed profiles do not depend on a measured threshold:
+#  advisor, round 5; --legs none: the other workloads have collections of their own)
+STEP=merged
+case "$WL" in C3s8|C3s4) STEP=per-list;; esac
+CMD="$R/bench.py --steps 20 --warmup 3 --blocks 1 --no-cpu-baseline --no-api-path --no-direct-pass --legs none --step $STEP --workload $WORKLOAD $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$WL -- python3 $CMD > $OUT/trace_$WL.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$WL -- python3 $CMD > $OUT/pmc_fetch_$WL.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$WL -- python3 $CMD > $OUT/pmc_write_$WL.log 2>&1
@@ -27,7 +31,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY S
 rocprofv3 --pmc SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT/pmc_sq3_$WL -- python3 $CMD > $OUT/pmc_sq3_$WL.log 2>&1
 # summaries first (pmc_traffic.json then carries this build's source hash), then the bench line that quotes them
 python3 $R/profiles/summarize.py $OUT $TAG $WL > $OUT/summary_$WL.txt
-python3 $R/bench.py --steps 20 --warmup 3 --workload $WORKLOAD $EXTRA > $R/profiles/${TAG}_${WL}_bench.json 2> $OUT/bench_$WL.err
+python3 $R/bench.py --steps 20 --warmup 3 --legs none --workload $WORKLOAD $EXTRA > $R/profiles/${TAG}_${WL}_bench.json 2> $OUT/bench_$WL.err
 # which box was this?  every collection appends its line to the round's list (profiles/<tag>_boxes.jsonl): the set is collected
 # ONCE per round, whatever box comes up; the steady-state blocks inside the bench line say how much this box scatters
 python3 - "$R/profiles/${TAG}_${WL}_bench.json" "$R/profiles/${TAG}_boxes.jsonl" "$WL" <<'PY'

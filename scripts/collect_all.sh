@@ -4,7 +4,7 @@
 #   gpurun --timeout 1200 -- 'bash scripts/collect_all.sh r05 a'      (C3 and its shards of 8, 4, 2)
 #   gpurun --timeout 1200 -- 'bash scripts/collect_all.sh r05 b'      (C5, C2, C1)
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r05}
+TAG=${1:-r06}
 PART=${2:-a}
 mkdir -p $R/gpurun_out
 if [ "$PART" = a ]; then set -- "C3" "C3 8,4" "C3 4,2" "C3 2,1"; else set -- "C5" "C2" "C1"; fi

@@ -75,6 +75,21 @@ def test_default_contract():
     c = d["cpu_baseline"]
     assert "SAME sample" in c["c_port_sample"] and "SAME sample" in c["vectorised_sample"]
     assert "1/16" in c["at_survey_extent"]["what"] and c["at_survey_extent"]["c_port_value"] > 1e7
+    # round 6: every other BASELINE configuration rides on the default line as a leg (the driver had only ever timed C3)
+    legs = d["workload_legs"]
+    assert sorted(legs) == ["C1", "C2", "C5"] and d["value_step"] == "merged" and 0 < d["value_per_list"] < d["value"]
+    for w, points, step in (("C1", 10000, "merged"), ("C2", 400000, "merged"), ("C5", 2400000, "merged")):
+        g = legs[w]
+        assert g["steps"] == 5 and g["warmup"] == 2 and g["n_gpus"] == 1 and g["grid_points_per_gpu"] == points and g["step"] == step
+        assert g["ms_per_step"] > 0 and g["evals_per_s"] == pytest.approx(g["evals_per_step"] / (g["ms_per_step"] * 1e-3))
+        assert g["kernel_ms_per_step"]["xsec_accumulate"] > 0 and g["kernel_ms_per_step"]["line_prep"] > 0
+    assert "600-700" in legs["C1"]["workload"] and "500-900" in legs["C2"]["workload"] and "column" in legs["C5"]["workload"]
+    assert legs["C1"]["ms_per_step"] < legs["C2"]["ms_per_step"] < d["ms_per_step"] < legs["C5"]["ms_per_step"]
+    c5 = legs["C5"]
+    assert c5["evals_per_step"] > 2.5e10 and 0.3 < c5["fold"]["hbm_frac"] < 1.0 and 0.3 < c5["line_prep"]["hbm_frac"] < 1.0
+    assert c5["fold"]["algorithmic_bytes_per_launch"] == 8.0 * 2400000 * 31 and c5["kernel_ms_per_step"]["column_sweep"] > 0
+    assert c5["api_path"]["ms_per_call"] > 0 and c5["api_path"]["bytes_downloaded_per_call"] == 8 * 2400000
+    assert "api_path" not in legs["C1"] and "sharded_step_breakdown" not in c5
 
 
 def test_forced_single_rank_communicator_pipeline():
@@ -94,6 +109,20 @@ def test_forced_single_rank_communicator_pipeline():
     d2 = run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--workload", "C1", "--no-overlap"],
                    {"PYRAD_FORCE_COMM": "1"})
     assert d2["config"]["allgather"] == "in-stream" and d2["kernel_ms_per_step"]["allgather"] > 0
+
+
+def test_sharded_column_leg_through_the_communicator():
+    """`bench.py --gpus N` carries BASELINE config 5 beside config 4: the 30-layer column sharded N-way by contiguous grid
+    range with its single all-gather per step and a breakdown - here with one rank forced through the RCCL communicator."""
+    d = run_bench(["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-direct-pass"], {"PYRAD_FORCE_COMM": "1"})
+    assert "sharded_step_breakdown" in d and sorted(d["workload_legs"]) == ["C5"]
+    g = d["workload_legs"]["C5"]
+    assert g["n_gpus"] == 1 and g["step"] == "merged" and g["evals_per_step"] > 2.5e10 and g["ms_per_step"] > 1.0
+    assert "outgoing spectrum" in g["config"]["allgather"] and g["kernel_ms_per_step"]["allgather"] > 0
+    bd = g["sharded_step_breakdown"]
+    assert 0 < bd["kernels_only_ms_per_step"] <= g["ms_per_step"] * 1.1 and bd["allgather_alone_ms_per_step"] > 0
+    assert len(bd["kernels_only_ms_by_rank"]) == 1 and bd["allgather_bytes_received_per_rank_per_step"] == 0.0
+    assert 0.3 < g["fold"]["hbm_frac"] < 1.0
 
 
 def test_self_launch_on_a_one_gpu_box_fails_loudly():
