@@ -356,6 +356,34 @@ int lbl_column_fold_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const* abs_coef,
                         int64_t first, int64_t count, lbl_buffer* I_in, double surface_T,
                         lbl_buffer* const* trans, lbl_buffer* I_out);
 
+/* ---- resident column (ABI 5) ---------------------------------------------------------------------------------------
+ * The argument blocks of a column's merged accumulate jobs (lbl_layers_merged_accumulate_dev) and of its fold
+ * (lbl_column_fold_dev) kept on the C side between calls, so that a host's per-call work does not grow with layers x line
+ * lists: pyrad_amd.model.Atmosphere.transmission (the fold of pyradClasses.py:784-787 over the layers' absorption
+ * coefficients, pyradClasses.py:707-712) is ONE call of lbl_column_transmission and one lbl_download_wait.
+ *   lbl_column_create        arguments as lbl_layers_merged_accumulate_dev plus the layers' depths; all layers share one
+ *                            wavenumber range and base grid.  The handle owns nothing on the device: line lists and buffers stay
+ *                            the caller's and must outlive it (or be replaced with lbl_column_set_layer first).
+ *   lbl_column_set_layer     replaces one layer's line lists / parameters / grid / volume fractions / depth / buffer (what a
+ *                            mutator of the reference changes: changeTemperature, changePressure, changeRange, changeDepth,
+ *                            setPPM ...; the layer keeps its numbers of line lists and molecules)
+ *   lbl_column_transmission  due[l] != 0 (due == NULL: every layer): layer l's absorption coefficient is recomputed (ONE merged
+ *                            accumulate job per due layer, all in one launch sequence); then the fold bottom to top,
+ *                            I <- T_l I + (1 - T_l) B(nu, T_l) with I_0 = I_in or B(nu, surface_T), in `pieces` pieces of the
+ *                            grid, each piece's part of I_out copied to host_out (page-locked, lbl_host_alloc; may be NULL: no
+ *                            download) while the next piece is folded.  Returns when everything is ENQUEUED:
+ *                            lbl_download_wait(ctx) before host_out is read.  The sweeps' default arithmetic only
+ *                            ("sweep_ieee_divisions" 1: LBL_ERR_BAD_ARG). */
+typedef struct lbl_column lbl_column;
+int lbl_column_create(lbl_ctx* ctx, int n_layers, const int32_t* n_iso, lbl_lines* const* lines, const lbl_iso_params* iso,
+                      const lbl_grid* grid, const int32_t* iso_mol, const int32_t* n_mol, const double* conc,
+                      const double* depth, lbl_buffer* const* abs_coef, lbl_column** out);
+int lbl_column_destroy(lbl_column* column);
+int lbl_column_set_layer(lbl_column* column, int layer, lbl_lines* const* lines, const lbl_iso_params* iso,
+                         const lbl_grid* grid, const double* conc, double depth, lbl_buffer* abs_coef);
+int lbl_column_transmission(lbl_column* column, const uint8_t* due, lbl_buffer* I_in, double surface_T, lbl_buffer* I_out,
+                            double* host_out, int pieces);
+
 /* Column fold of Layer.transmission over layers bottom to top (pyradClasses.py:784-787):
  *   I <- trans_l * I + (1 - trans_l) * B(nu_j, layer_T[l]),  I_0 = I_in or B(nu_j, surface_T). */
 int lbl_column_sweep_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const* trans, const double* layer_T,

@@ -100,6 +100,11 @@ SIGNATURES = {
                                                    C.POINTER(_P)]),
     "lbl_column_fold_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), _D, _D, C.c_double, C.c_double, C.c_int64, C.c_int64,
                                       C.c_int64, _P, C.c_double, C.POINTER(_P), _P]),
+    "lbl_column_create": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.POINTER(_P), C.POINTER(IsoParams), C.POINTER(Grid),
+                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32), _D, _D, C.POINTER(_P), C.POINTER(_P)]),
+    "lbl_column_destroy": (C.c_int, [_P]),
+    "lbl_column_set_layer": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(IsoParams), C.POINTER(Grid), _D, C.c_double, _P]),
+    "lbl_column_transmission": (C.c_int, [_P, C.POINTER(C.c_uint8), _P, C.c_double, _P, _P, C.c_int]),
     "lbl_column_sweep_dev": (C.c_int, [_P, C.c_int, C.POINTER(_P), _D, C.c_double, C.c_double, C.c_int64,
                                        C.c_int64, C.c_int64, _P, C.c_double, _P]),
     "lbl_column_step_dev": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32), C.POINTER(_P), C.POINTER(C.c_int32),
@@ -141,7 +146,7 @@ def source_hash() -> str:
     committed PMC numbers were measured on other kernels than the ones it is timing."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("Makefile", "lbl_api.hip", "lbl_device.h", "lbl_kernels.hip"):
+    for f in ("Makefile", "lbl_api.hip", "lbl_device.h", "lbl_kernels.hip", "lbl_launch_shapes.h"):
         h.update(f.encode())
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
@@ -470,6 +475,10 @@ class Context:
             arr(C.c_int32, [int(m) for L in layers for m in L["iso_mol"]]), arr(C.c_int32, [len(L["conc"]) for L in layers]),
             arr(C.c_double, [float(c) for L in layers for c in L["conc"]]), arr(_P, [L["abs_coef"].h for L in layers])))
 
+    def column(self, layers):
+        """Resident column (lbl_column_create): ``layers`` as for layers_merged_accumulate_dev, each with ``depth``."""
+        return Column(self, layers)
+
     def column_fold_dev(self, abs_coef, layer_T, depth, range_min, range_max, n, I_out, I_in=None, surface_T=0.0,
                         trans=None, first=0, count=0):
         """Column step from the layers' absorption coefficients, bottom to top (lbl_column_fold_dev); ``trans``: None or
@@ -542,6 +551,61 @@ class Context:
 
     def line_survey_dev(self, lines, grid, out):
         self.check(self.lib.lbl_line_survey_dev(self.h, lines.h, C.byref(grid), out.h))
+
+
+class Column:
+    """lbl_column: the argument blocks of a column's merged accumulate jobs and of its fold, kept on the C side between
+    calls.  ``layers``: list of dict(lines=[Lines], iso=[IsoParams], grid=Grid, iso_mol=[int], conc=[float], depth=float,
+    abs_coef=Buffer).  The handle owns nothing on the device; the Python object keeps the line lists and buffers it was
+    given alive."""
+
+    def __init__(self, ctx: "Context", layers):
+        self.ctx = ctx
+        self.n_layers = len(layers)
+        arr = lambda typ, vals: (typ * max(len(vals), 1))(*vals)
+        ls = [l for L in layers for l in L["lines"]]
+        self._keep = [(list(L["lines"]), L["abs_coef"]) for L in layers]
+        h = _P()
+        ctx.check(ctx.lib.lbl_column_create(
+            ctx.h, self.n_layers, arr(C.c_int32, [len(L["lines"]) for L in layers]), arr(_P, [l.h for l in ls]),
+            arr(IsoParams, [i for L in layers for i in L["iso"]]), arr(Grid, [L["grid"] for L in layers]),
+            arr(C.c_int32, [int(m) for L in layers for m in L["iso_mol"]]), arr(C.c_int32, [len(L["conc"]) for L in layers]),
+            arr(C.c_double, [float(c) for L in layers for c in L["conc"]]), arr(C.c_double, [float(L["depth"]) for L in layers]),
+            arr(_P, [L["abs_coef"].h for L in layers]), C.byref(h)))
+        self.h = h
+        self._due = (C.c_uint8 * self.n_layers)()
+        ctx._children.append(self)
+
+    def set_layer(self, l, lines, iso, grid, conc, depth, abs_coef):
+        arr = lambda typ, vals: (typ * max(len(vals), 1))(*vals)
+        self.ctx.check(self.ctx.lib.lbl_column_set_layer(self.h, int(l), arr(_P, [x.h for x in lines]), arr(IsoParams, list(iso)),
+                                                         C.byref(grid), arr(C.c_double, [float(c) for c in conc]), float(depth),
+                                                         abs_coef.h))
+        self._keep[l] = (list(lines), abs_coef)
+
+    def transmission(self, due, I_out, host=None, I_in=None, surface_T=0.0, pieces=1):
+        """Enqueue: the merged accumulate jobs of the layers with due[l] true (None: all), the fold in ``pieces`` pieces, each
+        piece's part of I_out on its way into ``host`` (Context.host_array); Context.download_wait() before reading it."""
+        flags = None
+        if due is not None:
+            flags = self._due
+            for l, d in enumerate(due):
+                flags[l] = 1 if d else 0
+        hp = None
+        if host is not None:
+            if not (host.dtype == np.float64 and host.flags["C_CONTIGUOUS"]):
+                raise ValueError("the host array must be contiguous float64")
+            hp = _ptr(host)
+        self.ctx.check(self.ctx.lib.lbl_column_transmission(self.h, flags, I_in.h if I_in is not None else None, float(surface_T),
+                                                            I_out.h, hp, int(pieces)))
+
+    def free(self):
+        if self.h:
+            self.ctx.check(self.ctx.lib.lbl_column_destroy(self.h))
+            self.h = None
+            self._keep = []
+            if self in self.ctx._children:
+                self.ctx._children.remove(self)
 
 
 class Buffer:

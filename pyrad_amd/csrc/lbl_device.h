@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "lbl_launch_shapes.h"
 
 namespace lbl {
 
@@ -164,14 +165,10 @@ struct SchedJob {
     int32_t span_first;    // first span of this job in the group's span table
     int32_t tile_first;    // first (job, tile) item of this job in the group's positional item list
 };
-bool sched_device_supported(int total_tiles, int n_cu);
-size_t sched_scratch_bytes(int total_tiles);
 void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, int total_tiles, int R, int spans_per_tile,
                            long long far_reach, double cost_near, double cost_edge, double cost_far, double cost_fixed,
                            int n_cu, int32_t* tabs, void* scratch, int2* worklist, hipStream_t s, int xcd_chunks = 32, bool xcd_pack = true,
                            int single_round_chunks = 1, int xcd_tol = 3, int xcd_local = -1);
-// entries of the dispatch list of a launch (a single-round launch packed per XCD has more positions than tiles: the rest exit at once)
-int sched_launch_items(int total_tiles, int n_cu, bool xcd_pack);
 
 // ---- fused sweep arguments (passed by value / by pointer to the sweep kernels) ----------
 // line lists of one MERGED accumulate job (6 bits of the merged-order map, PrepJob blocks in K1's LDS) and arrays a layer
@@ -247,7 +244,6 @@ void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R,
 // narrow windows: every lane walks the lines that reach its own R points (skewed ranges); tiles of 256 R points
 void launch_accumulate_skew(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, const int2* worklist, int total_tiles,
                             hipStream_t s, int LS = 1);      // LS 2 | 4: R = 8 only (waves of a workgroup share a span and deal its records)
-int accumulate_tile_points(int R, int LS, int variant);
 void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost, int budget = 0);
 // balanced variant (4): span ranges -> prefix sum -> equal shares of (span, line) pairs per wave -> slab reduce
 int balanced_workers(int R, int n_cu);
@@ -260,7 +256,6 @@ void launch_layer_sweep(const SweepArgs& a, hipStream_t s);
 void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s, int budget = 0);
 void launch_column_sweep(const ColumnArgs* d_args, long long n, hipStream_t s, int budget = 0);
 void launch_planck(double* out, long long n, double start, double stop, double T, double rT, double pa, double pb, hipStream_t s);
-int band_partial_count(long long n);
 void launch_band_integral(const double* y, long long n, double* partial, double* result, hipStream_t s);
 struct SumArgs { const double* in[kMaxIso]; int32_t n_in; double* out; long long n; };
 void launch_sum(const SumArgs& a, hipStream_t s);

@@ -40,6 +40,7 @@
 // K2 is fp64-VALU bound, not HBM bound: its compulsory traffic is 56 B per line and 8 B per grid
 // point against 5 fp64 instructions per directly evaluated (line, grid point) pair.
 #include "lbl_device.h"
+#include "lbl_launch_shapes.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -2692,37 +2693,8 @@ __global__ __launch_bounds__(512) void sched_order_pack_xcd_kernel(const unsigne
     }
 }
 
-// Entries of a launch's dispatch list: the tiles, or - single round on a chip of 8 XCDs - eight runs of `m_cap` positions
-int sched_xcd_positions(int total_tiles, int n_cu) {
-    if (total_tiles <= 0 || total_tiles > 4 * n_cu || total_tiles > 1024 || n_cu % 8 != 0 || n_cu < 64 || n_cu > 512) return 0;
-    const int b = n_cu / 8;                                      // bins per XCD; up to twice an eighth of the tiles per XCD (a
-    int m = 2 * ((total_tiles + 7) / 8);                         // sparse spectral region is many cheap tiles), in whole tiers
-    m = (m + b - 1) / b * b;                                     // of b positions, at most 7
-    if (m > 7 * b) m = 7 * b;
-    if (8 * m < total_tiles) return 0;
-    return m;
-}
-int sched_launch_items(int total_tiles, int n_cu, bool xcd_pack) {
-    const int m = xcd_pack ? sched_xcd_positions(total_tiles, n_cu) : 0;
-    return m > 0 ? 8 * m : total_tiles;
-}
-
-// What the device build covers (else the caller builds the schedule on the host), and the scratch it needs.
-bool sched_device_supported(int total_tiles, int n_cu) {
-    if (total_tiles <= 4 * n_cu) return total_tiles <= 1024 && n_cu <= 512;
-    return total_tiles <= (1 << 20);
-}
-static int sched_key_stride(int total_tiles) {
-    int p = 1;
-    while (p < total_tiles) p <<= 1;
-    return p;
-}
-size_t sched_scratch_bytes(int total_tiles) {         // tile costs | items | prefix | global sort keys (8 parts)
-    const size_t n = (size_t)total_tiles;
-    return ((n * 4 + 255) & ~(size_t)255) + ((n * 8 + 255) & ~(size_t)255) + (((n + 1) * 8 + 255) & ~(size_t)255) +
-           8 * (size_t)sched_key_stride(total_tiles) * 8 + 256;
-}
-
+// (sched_xcd_positions, sched_launch_items, sched_device_supported, sched_key_stride, sched_scratch_bytes: lbl_launch_shapes.h -
+// pure host arithmetic shared with the sanitizer harness of the host shim)
 void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, int total_tiles, int R, int spans_per_tile,
                            long long far_reach, double cost_near, double cost_edge, double cost_far, double cost_fixed,
                            int n_cu, int32_t* tabs, void* scratch, int2* worklist, hipStream_t s, int xcd_chunks, bool xcd_pack,
@@ -3205,10 +3177,6 @@ void accumulate_far_field_params(int R, int* far_half_spans, double* far_cost, i
     *far_cost = (3.0 * 17.0 + 12.0) / 64.0 / (5.0 * R);           // (17 terms: the average over a +-39 half-span window, either mode)
 }
 
-// grid points one workgroup covers
-int accumulate_tile_points(int R, int LS, int variant) {
-    return variant >= 3 ? 64 * R * ((LS > 4 ? LS : 4) / LS) : 256 * R;
-}
 
 void launch_accumulate(const AccumJob* d_jobs, int n_jobs, int max_tiles, int R, int LS, int variant,
                        const int2* worklist, int total_tiles, hipStream_t s, int budget, int gauss_run) {
@@ -3393,10 +3361,6 @@ void launch_planck(double* out, long long n, double start, double stop, double T
                        T, rT, pa, pb);
 }
 
-int band_partial_count(long long n) {
-    long long b = (n + 16383) / 16384;       // 16384 points per block
-    return (int)(b < 1 ? 1 : b);
-}
 
 void launch_band_integral(const double* y, long long n, double* partial, double* result, hipStream_t s) {
     const int nb = band_partial_count(n);

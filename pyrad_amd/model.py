@@ -590,6 +590,8 @@ class Isotope(_OpticalMixin, list):
         self._xs_installed = False       # somebody assigned ``crossSection`` an array of their own (and nothing has recomputed it since):
                                          # the layer's sums must use THAT array, as the reference's getters do (cls:32-35, 566-571)
         self._inputs_version = 0         # bumped by everything that marks the cross section dirty (resetCrossSection, new lines)
+        self._struct_version = 0         # bumped when the line list itself changes or somebody installs a cross section: a resident
+                                         # column (Atmosphere._column_fast) then re-reads this layer's blocks
         self._regime_counts = (0, 0, 0)
         _copy_of_layer_cross_section(Isotope.crossSection, self, self.layer)
         self.exotic = molecule.exotic
@@ -668,6 +670,7 @@ class Isotope(_OpticalMixin, list):
             self._dev_lines = None
         self.progressCrossSection = False
         self._inputs_version += 1
+        self._struct_version += 1
 
     def _host_array_assigned(self, which):
         if which == "_crossSection_host":           # somebody installed a host array: the device copy is stale
@@ -675,6 +678,7 @@ class Isotope(_OpticalMixin, list):
             self._xs_deferred = False
             self._xs_version += 1
             self._xs_installed = True
+            self._struct_version += 1
 
     def _defer_cross_section(self):
         """A merged layer step (one accumulate job over all the layer's line lists, settings.LAYER_STEP) has just produced
@@ -1072,6 +1076,20 @@ class Layer(_OpticalMixin, list):
         for m in self:
             m._mark_sum_ready()
 
+    def _column_stamp(self):
+        """(values, versions) for Atmosphere's resident column: ``values`` changes when the layer's blocks on the C side must be
+        re-read (a mutator changed T, P, the range, a concentration, the depth, the line lists, or somebody installed a cross
+        section), ``versions`` when any of its line lists is due (resetCrossSection, cls:38-45).  A handful of attribute
+        reads: this runs for every layer on every Atmosphere.transmission before the first kernel is enqueued."""
+        ver = struct = 0
+        conc = []
+        for m in self:
+            conc.append(m.concentration)
+            for iso in m:
+                ver += iso._inputs_version
+                struct += iso._struct_version
+        return (self.T, self.P, self.rangeMin, self.rangeMax, self.resolution, len(self), struct, tuple(conc), self.depth), ver
+
     def _merged_step_applies(self, flat, lbl):
         """settings.LAYER_STEP "merged" (default): the layer's property chain comes from one merged accumulate job when
         any of its line lists is due (all of them line-by-line: a measured cross-section table has no lines to merge).
@@ -1263,6 +1281,9 @@ class Atmosphere(list):
         goes through the per-line-list cross sections of the whole column (lbl_column_step_dev)."""
         if settings.LAYER_STEP != "merged":
             return None
+        fast = self._transmission_resident(ctx, layers, n, surfaceSpectrum, surfaceTemperature)
+        if fast is not None:
+            return fast
         plan = []
         for L in layers:
             members, conc = L._sweep_members()
@@ -1320,6 +1341,97 @@ class Atmosphere(list):
         finally:
             # (also when a piece raised: copies into `host` may be in flight, and its page-locked block must not go back to
             # the pool before they have landed - advisor, round 5)
+            ctx.download_wait()
+        self._column_remember(ctx, layers, n, plan)
+        return host
+
+    # -- the resident column: the next call's argument blocks are already on the C side (lbl_column, ABI 5) --------------
+    def _column_drop(self):
+        fast = self.__dict__.pop("_column_fast", None)
+        if fast is not None and fast["col"].h and fast["col"].ctx.h:
+            fast["col"].free()
+
+    def _column_remember(self, ctx, layers, n, plan):
+        """After a call through the general route: if every layer was one merged job, keep the column's blocks in a C-side
+        handle; the next call then only looks at every layer's stamp (Layer._column_stamp)."""
+        self._column_drop()
+        if not plan or any(p[6] is None for p in plan):
+            return
+        col = ctx.column([dict(lines=[i._device_lines(ctx) for i in flat], iso=[_iso_params(i) for i in flat],
+                               grid=_engine.native_grid(g), iso_mol=[m for m, isos in enumerate(members) for _ in isos], conc=conc,
+                               depth=L.depth, abs_coef=st.bufs["abs_coef"]) for (L, st, g, members, flat, conc, key) in plan])
+        stamps = [L._column_stamp() for L in layers]
+        self.__dict__["_column_fast"] = dict(
+            col=col, glob=(id(ctx), n, utils.BASE_RESOLUTION, settings.ACCURACY), layers=list(layers),
+            val=[s_[0] for s_ in stamps], done=[(s_[0][:-1], s_[1]) for s_ in stamps], kbuf=[p[1].bufs["abs_coef"] for p in plan],
+            n_iso=[len(p[4]) for p in plan])
+        import weakref
+        weakref.finalize(self, lambda c=col: c.free() if (c.h and c.ctx.h) else None)
+
+    def _transmission_resident(self, ctx, layers, n, surfaceSpectrum, surfaceTemperature):
+        """The call through the resident column handle, or None (no handle yet, another context / grid / accuracy mode, the
+        list of layers changed, a layer can no longer be one merged job: the general route then rebuilds the handle)."""
+        fast = self.__dict__.get("_column_fast")
+        if fast is None:
+            return None
+        col = fast["col"]
+        if (fast["glob"] != (id(ctx), n, utils.BASE_RESOLUTION, settings.ACCURACY) or not col.h or len(layers) != len(fast["layers"])
+                or any(a is not b for a, b in zip(layers, fast["layers"]))):
+            return None
+        due, redo = [], []
+        for l, L in enumerate(layers):
+            val, ver = L._column_stamp()
+            st = L.__dict__.get("_sweep_state")
+            if st is None or st.bufs.get("abs_coef") is not fast["kbuf"][l]:
+                return None
+            if val != fast["val"][l]:
+                if val[-1:] != fast["val"][l][-1:] and val[:-1] == fast["val"][l][:-1]:
+                    redo.append((l, L, val, True))              # only the depth (changeDepth resets nothing, cls:754-755)
+                else:
+                    redo.append((l, L, val, False))
+            due.append((val[:-1], ver) != fast["done"][l])
+        for l, L, val, depth_only in redo:
+            members, conc = L._sweep_members()
+            flat = [iso for isos in members for iso in isos]
+            if (len(flat) != fast["n_iso"][l] or any(i.exotic for i in flat) or len(conc) != len(val[7])
+                    or any(i._xs_installed and i.progressCrossSection for i in flat)):
+                return None
+            g = L._grid()
+            if g["n_base"] != n:
+                return None
+            _check_window(g)
+            col.set_layer(l, [i._device_lines(ctx) for i in flat], [_iso_params(i) for i in flat], _engine.native_grid(g), conc,
+                          L.depth, fast["kbuf"][l])
+            fast["val"][l] = val
+        ast = self.__dict__.get("_toa_state")
+        if ast is None:
+            ast = self.__dict__["_toa_state"] = _SweepState(self)
+        out = ast.reserve(ctx, n).buf(ctx, "toa")
+        I_in = None
+        if surfaceSpectrum is not None:
+            I_in = ast.buf(ctx, "I_in").upload(np.ascontiguousarray(surfaceSpectrum, dtype=np.float64))
+        host = ctx.host_array(n)
+        try:
+            # eight pieces: what is left after the last fold piece is an eighth of the spectrum on its way home
+            col.transmission(due, out, host=host, I_in=I_in, surface_T=float(surfaceTemperature or 0.0),
+                             pieces=8 if n >= (1 << 19) else (4 if n >= (1 << 16) else 1))
+            # bookkeeping of the object model, while the device works: what the general route does for the layers it recomputed
+            for l, L in enumerate(layers):
+                if not due[l]:
+                    continue
+                members, conc = L._sweep_members()
+                flat = [iso for isos in members for iso in isos]
+                key = L._merged_key(flat, conc, L, L._grid())
+                L.__dict__["_sweep_state"].key = key[:-1] + ("absorption coefficient only",)
+                for iso in flat:
+                    iso._defer_cross_section()
+                L._members_ready()
+                val, ver = L._column_stamp()                  # (_defer_cross_section bumps no input version)
+                fast["done"][l] = (val[:-1], ver)
+        except Exception:
+            self._column_drop()
+            raise
+        finally:
             ctx.download_wait()
         return host
 
