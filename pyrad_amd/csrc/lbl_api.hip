@@ -965,7 +965,9 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
     if (ctx->capturing) { (void)capture_refuses(ctx, "building a dispatch schedule"); return nullptr; }
     TraceScope tr("group_schedule", (long long)jobs_in_group.size());
     auto evict_oldest = [&]() {
-        if (ctx->schedules.size() >= 16) {                    // small cache: drop the oldest entry
+        // (64 entries: a 30-layer atmosphere used through per-layer getters holds one schedule per layer, and every eviction is a
+        // stream sync, a hipFree and a stale graph - advisor, round 5; an entry is a few MB: dispatch list, span table, merged order)
+        if (ctx->schedules.size() >= 64) {                    // drop the least recently used entry
             ctx->epoch++;
             (void)hipStreamSynchronize(ctx->stream);
             if (ctx->schedules.front()->d_block) (void)hipFree(ctx->schedules.front()->d_block);

@@ -98,8 +98,7 @@ def resetCrossSection(obj):
             n = int((obj.rangeMax - obj.rangeMin) / utils.BASE_RESOLUTION)
             type(obj).crossSection.defer(obj, lambda n=n: np.zeros(n))      # the zeros of cls:41, made when read
             if isinstance(obj, Isotope):
-                obj._host_array_assigned("_crossSection_host")
-                obj._xs_installed = False            # (the zeros above are the reference's reset, not somebody's array)
+                obj._host_array_assigned("_crossSection_host", installed=False)      # (the zeros above are the reference's reset, not somebody's array)
                 obj._inputs_version += 1             # (a merged layer step computed from this isotopologue is stale too)
             obj.progressCrossSection = False
     if isinstance(obj, Isotope):
@@ -672,13 +671,14 @@ class Isotope(_OpticalMixin, list):
         self._inputs_version += 1
         self._struct_version += 1
 
-    def _host_array_assigned(self, which):
+    def _host_array_assigned(self, which, installed=True):
         if which == "_crossSection_host":           # somebody installed a host array: the device copy is stale
             self._dev_xsec_valid = False
             self._xs_deferred = False
             self._xs_version += 1
-            self._xs_installed = True
-            self._struct_version += 1
+            self._xs_installed = bool(installed)
+            if installed:
+                self._struct_version += 1
 
     def _defer_cross_section(self):
         """A merged layer step (one accumulate job over all the layer's line lists, settings.LAYER_STEP) has just produced
@@ -1050,14 +1050,22 @@ class Layer(_OpticalMixin, list):
             self.resolution = max(10**int(np.log10((self.P / 1013.25))) * .01, utils.BASE_RESOLUTION)
 
     def _grid(self):
-        """Grid scalars for the C ABI from the layer's CURRENT attributes (cls:672, 700, 377)."""
+        """Grid scalars for the C ABI from the layer's CURRENT attributes (cls:672, 700, 377).  (Remembered by the attributes
+        they are computed from: len(np.arange(...)) alone is 1 us, and the getters and the column ask for the grid of every
+        layer on every call.)"""
         base = utils.BASE_RESOLUTION
-        return dict(dfc=self.distanceFromCenter, eff_min=self.effectiveRangeMin, eff_max=self.effectiveRangeMax,
-                    resolution=self.resolution, base_resolution=base,
-                    n_base=int((self.rangeMax - self.rangeMin) / base),
-                    n_work=int((self.rangeMax - self.rangeMin) / self.resolution),
-                    W=len(np.arange(0, self.distanceFromCenter, self.resolution)),
-                    range_min=self.rangeMin, range_max=self.rangeMax)
+        key = (self.distanceFromCenter, self.effectiveRangeMin, self.effectiveRangeMax, self.resolution, base, self.rangeMin, self.rangeMax)
+        hit = self.__dict__.get("_grid_cache")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        g = dict(dfc=self.distanceFromCenter, eff_min=self.effectiveRangeMin, eff_max=self.effectiveRangeMax,
+                 resolution=self.resolution, base_resolution=base,
+                 n_base=int((self.rangeMax - self.rangeMin) / base),
+                 n_work=int((self.rangeMax - self.rangeMin) / self.resolution),
+                 W=len(np.arange(0, self.distanceFromCenter, self.resolution)),
+                 range_min=self.rangeMin, range_max=self.rangeMax)
+        self.__dict__["_grid_cache"] = (key, g)
+        return g
 
     def __str__(self):
         return '%s; %s' % (self.name, '; '.join(str(m) for m in self))
@@ -1412,9 +1420,9 @@ class Atmosphere(list):
             I_in = ast.buf(ctx, "I_in").upload(np.ascontiguousarray(surfaceSpectrum, dtype=np.float64))
         host = ctx.host_array(n)
         try:
-            # eight pieces: what is left after the last fold piece is an eighth of the spectrum on its way home
+            # (four pieces: eight measured no faster, and every piece is one more argument block in the library's cache of eight)
             col.transmission(due, out, host=host, I_in=I_in, surface_T=float(surfaceTemperature or 0.0),
-                             pieces=8 if n >= (1 << 19) else (4 if n >= (1 << 16) else 1))
+                             pieces=4 if n >= (1 << 16) else 1)
             # bookkeeping of the object model, while the device works: what the general route does for the layers it recomputed
             for l, L in enumerate(layers):
                 if not due[l]:

@@ -732,24 +732,24 @@ def resident_xsec(ctx, dev_lines, species, conc, T, P, rmin, rmax, base, dyn):
 @pytest.mark.parametrize("build", [1, 0])
 def test_schedule_cache_survives_eviction(ctx, build):
     """The schedule (dispatch order + per-span line ranges; built on the device or on the host) is cached per (line
-    lists, grid), 16 entries, least recently used out first: 40 different grids over one resident line list, revisited in
+    lists, grid), 64 entries, least recently used out first: 90 different grids over one resident line list, revisited in
     another order, give the same bits as on first sight - and as the kernel that searches its ranges itself."""
     lines = synthetic.make_lines(321, 700, 630, 700)
     L = ctx.lines(lines)
     ctx.set_option("schedule_build", build)
     try:
         first = {}
-        for i in range(40):
-            rmin = 640.0 + 0.25 * i
+        for i in range(90):
+            rmin = 640.0 + 0.125 * i
             first[i], _ = resident_xsec(ctx, L, "co2", 4e-4, 296, 1013.25, rmin, rmin + 8.0, .001, False)
             assert np.all(np.isfinite(first[i]))
-        for i in list(range(0, 40, 3)) + [39, 0, 20]:
-            rmin = 640.0 + 0.25 * i
+        for i in list(range(0, 90, 7)) + [89, 0, 20]:
+            rmin = 640.0 + 0.125 * i
             xs, _ = resident_xsec(ctx, L, "co2", 4e-4, 296, 1013.25, rmin, rmin + 8.0, .001, False)
             assert np.array_equal(xs, first[i]), i
         ctx.set_option("accum_longest_first", 0)              # no schedule: every wave searches the centre indices
-        for i in (0, 17, 39):
-            rmin = 640.0 + 0.25 * i
+        for i in (0, 17, 89):
+            rmin = 640.0 + 0.125 * i
             xs, _ = resident_xsec(ctx, L, "co2", 4e-4, 296, 1013.25, rmin, rmin + 8.0, .001, False)
             assert np.array_equal(xs, first[i]), i
     finally:
