@@ -19,9 +19,9 @@ import bench  # noqa: E402
 from pyrad_amd import _native as nat, engine  # noqa: E402
 
 
-def time_steps(ctxs, objs, is_column, steps, budget_s=1.5):
+def time_steps(ctxs, objs, is_column, steps, merged, budget_s=1.5):
     """objs[i] lives on ctxs[i]: len(objs) independent steps in flight, dealt round-robin"""
-    kw = dict(layer_arrays=False) if is_column else dict(surface_T=288.0)
+    kw = dict(layer_arrays=False, merged=merged) if is_column else dict(surface_T=288.0, merged=merged)
     n = [0]
 
     def step():
@@ -50,13 +50,16 @@ def time_steps(ctxs, objs, is_column, steps, budget_s=1.5):
 
 def main():
     workloads = [w for w in sys.argv[1:] if w in ("C2", "C3", "C5")] or ["C3", "C5"]
-    in_flight = 1
+    in_flight, step_arg = 1, "auto"
     for a in sys.argv[1:]:
         if a.startswith("--in-flight="):
             in_flight = int(a.split("=")[1])
+        if a.startswith("--step="):
+            step_arg = a.split("=")[1]            # auto (what bench.py --gpus N runs) | merged | per-list
     ctxs = [nat.Context(0) for _ in range(in_flight)]
     ctx = ctxs[0]
-    out = {"device": ctx.device_info()["name"], "steps_in_flight_sharded": in_flight,
+    out = {"device": ctx.device_info()["name"], "steps_in_flight_sharded": in_flight, "step": step_arg,
+           "source_hash": nat.source_hash(),
            "unit": "ms per step (K1 + K2 + sweep; C5: + column step); t_full with ONE step in flight (what N = 1 runs), "
                    "shards with steps_in_flight_sharded", "rows": []}
     for wl in workloads:
@@ -75,7 +78,10 @@ def main():
             return engine.ResidentLayer(ctx, c["depth"], c["T"], c["P"], c["range_min"], c["range_max"], c["molecules"],
                                         c["base_resolution"], c.get("dynamic_resolution", True), shard=shard)
         full = build(None)
-        t_full = time_steps([ctx], [full], is_column, steps)
+        g0 = (full.layers[0] if is_column else full).g
+        n_lists, n_layers = len(full.jobs), (len(full.layers) if is_column else 1)
+        step_of = lambda G: bench.choose_step(step_arg, g0["n_work"], n_lists, n_layers, G)
+        t_full = time_steps([ctx], [full], is_column, steps, step_of(1))
         evals_full = full.evals
         full.free()
         print("%s full: %.4f ms" % (wl, t_full), file=sys.stderr)
@@ -86,11 +92,11 @@ def main():
                     plan = engine.balanced_shards(layer_cfgs, G, r) if mode == "balanced" else engine.as_plan((G, r), full.n)
                     bounds = plan.bounds
                     parts = [build(plan, c) for c in ctxs]
-                    ts.append(time_steps(ctxs, parts, is_column, steps))
+                    ts.append(time_steps(ctxs, parts, is_column, steps, step_of(G)))
                     ev += parts[0].evals
                     for part in parts:
                         part.free()
-                row = dict(workload=wl, G=G, bounds=mode, t_full_ms=t_full, t_r_ms=ts, max_ms=max(ts), sum_ms=sum(ts),
+                row = dict(workload=wl, G=G, bounds=mode, step="merged" if step_of(G) else "per-list", t_full_ms=t_full, t_r_ms=ts, max_ms=max(ts), sum_ms=sum(ts),
                            predicted_speedup=t_full / max(ts), fixed_ms_per_step=(sum(ts) - t_full) / (G - 1),
                            imbalance=max(ts) / (sum(ts) / G), evals_match=bool(ev == evals_full),
                            shard_points=[c for _, c in bounds])
