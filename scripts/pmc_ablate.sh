@@ -9,7 +9,7 @@ for b in $BITS; do
   OUT=$R/gpurun_out/pmcab_${TAG}_$b
   rm -rf $OUT; mkdir -p $OUT
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT -- \
-    python3 $R/bench.py --steps 6 --warmup 2 --blocks 1 --no-cpu-baseline --no-api-path --no-direct-pass "$@" --set debug_ablate=$b > $OUT/log.txt 2>&1 || tail -3 $OUT/log.txt
+    python3 $R/bench.py --steps 6 --warmup 2 --blocks 1 --no-cpu-baseline --no-api-path --no-direct-pass --legs none "$@" --set debug_ablate=$b > $OUT/log.txt 2>&1 || tail -3 $OUT/log.txt
   python3 - "$OUT" "$TAG" "$b" <<'PY'
 import csv, glob, collections, sys
 out, tag, bits = sys.argv[1:4]
