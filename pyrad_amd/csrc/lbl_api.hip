@@ -56,6 +56,8 @@ struct lbl_ctx {
     void* host_stage = nullptr;   // pinned staging ring for job descriptors
     size_t host_stage_cap = 0;
     size_t host_stage_head = 0;
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};   // one per half of the ring: "every copy out of this half has been enqueued"
+    bool stage_ev_set[2] = {false, false};
     struct DescSlot { std::vector<char> bytes; void* dptr = nullptr; size_t cap = 0; };
     DescSlot desc_cache[4];
     int desc_next = 0;
@@ -263,26 +265,46 @@ static void prof_end(lbl_ctx* ctx, int kind, hipEvent_t start) {
     ctx->ev_rec[kind].emplace_back(start, e);
 }
 
-// Pinned staging for descriptors that a later hipMemcpyAsync reads: bump-allocated from a
-// ring; the stream is drained only when the ring wraps (or grows), so a slot is never
-// rewritten while an earlier copy from it may still be pending.
+// Pinned staging for descriptors that a later hipMemcpyAsync reads: bump-allocated from a ring of two halves.  A half is
+// reused only after the copies that read it have run: leaving a half records an event on the stream (every copy out of that
+// half was enqueued before it), entering a half waits for ITS event - recorded half a ring of descriptors ago, so normally long
+// complete.  (Until round 6 a wrap drained the whole stream: a step with fresh descriptors - a re-windowed column, whose
+// blocks are ~150 KB per call - then stalled for everything it had just enqueued, 7 ms of a 14 ms call every sixth call or so.)
 static int stage_alloc(lbl_ctx* ctx, size_t bytes, void** out) {
     bytes = (bytes + 255) & ~(size_t)255;
     if (ctx->capturing) return capture_refuses(ctx, "staging a host-to-device copy");
-    if (bytes > ctx->host_stage_cap) {
+    if (bytes * 8 > ctx->host_stage_cap) {                 // (an allocation never exceeds an eighth of the ring: a quarter of a half)
+        TraceScope tr("staging ring grow", (long long)bytes);
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->host_stage) HIP_TRY(ctx, hipHostFree(ctx->host_stage));
         ctx->host_stage = nullptr; ctx->host_stage_cap = 0; ctx->host_stage_head = 0;
+        ctx->stage_ev_set[0] = ctx->stage_ev_set[1] = false;
+#ifdef LBL_SANITIZER_BUILD
+        size_t want = bytes * 8;                               // (the harness wants the ring to wrap often)
+#else
         size_t want = std::max<size_t>(bytes * 8, (size_t)1 << 20);
+#endif
         HIP_TRY(ctx, hipHostMalloc(&ctx->host_stage, want, hipHostMallocDefault));
         ctx->host_stage_cap = want;
     }
-    if (ctx->host_stage_head + bytes > ctx->host_stage_cap) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->host_stage_head = 0;
+    const size_t half = ctx->host_stage_cap / 2;
+    const int from = ctx->host_stage_head < half ? 0 : 1;
+    size_t head = ctx->host_stage_head;
+    if (head < half && head + bytes > half) head = half;                    // no allocation straddles the two halves
+    if (head + bytes > ctx->host_stage_cap) head = 0;
+    const int to = head < half ? 0 : 1;
+    if (to != from) {
+        for (int h = 0; h < 2; ++h)
+            if (!ctx->stage_ev[h]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->stage_ev[h], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(ctx->stage_ev[from], ctx->stream));
+        ctx->stage_ev_set[from] = true;
+        if (ctx->stage_ev_set[to]) {
+            TraceScope tr("staging ring: wait for a half", (long long)to);
+            HIP_TRY(ctx, hipEventSynchronize(ctx->stage_ev[to]));
+        }
     }
-    *out = (char*)ctx->host_stage + ctx->host_stage_head;
-    ctx->host_stage_head += bytes;
+    *out = (char*)ctx->host_stage + head;
+    ctx->host_stage_head = head + bytes;
     return LBL_OK;
 }
 
@@ -307,6 +329,7 @@ static int device_args(lbl_ctx* ctx, const void* host, size_t bytes, void** dptr
         ctx->epoch++;                                                           // a captured graph may point at it
     }
     if (slot->cap < bytes) {
+        TraceScope tr("argument slot alloc", (long long)bytes);
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (slot->dptr) HIP_TRY(ctx, hipFree(slot->dptr));
         slot->dptr = nullptr; slot->cap = 0; slot->bytes.clear();
@@ -416,6 +439,7 @@ extern "C" int lbl_ctx_destroy(lbl_ctx* ctx) try {
     DeviceArena* arenas[] = {&ctx->recs, &ctx->cold, &ctx->cidx, &ctx->work, &ctx->jobs, &ctx->counts, &ctx->bal, &ctx->red, &ctx->zeros, &ctx->sched, &ctx->merge_tmp, &ctx->ktmp};
     for (DeviceArena* a : arenas) if (a->ptr) (void)hipFree(a->ptr);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+    for (int h = 0; h < 2; ++h) if (ctx->stage_ev[h]) (void)hipEventDestroy(ctx->stage_ev[h]);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
     (void)hipStreamDestroy(ctx->stream);
@@ -979,6 +1003,7 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
         const size_t list_bytes = (std::max<size_t>(n_items, 1) * sizeof(int2) + 255) & ~(size_t)255;
         const size_t tab_bytes = (std::max<size_t>(n_tab_ints, 8) * sizeof(int32_t) + 255) & ~(size_t)255;
         void* blk = nullptr;
+        TraceScope tr("schedule block alloc", (long long)(list_bytes + tab_bytes + n_src * sizeof(int32_t)));
         if (hipMalloc(&blk, list_bytes + tab_bytes + n_src * sizeof(int32_t)) != hipSuccess) return nullptr;
         *d_list = (int2*)blk;
         *d_tabs = (int32_t*)((char*)blk + list_bytes);
@@ -1445,6 +1470,7 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
         auto& e = ctx->desc_cache[ctx->desc_next];
         ctx->desc_next = (ctx->desc_next + 1) % 4;
         if (e.cap < ctx->desc_build.size()) {
+            TraceScope tr("descriptor slot alloc", (long long)ctx->desc_build.size());
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (e.dptr) HIP_TRY(ctx, hipFree(e.dptr));
             e.dptr = nullptr; e.cap = 0;

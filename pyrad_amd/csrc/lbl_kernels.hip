@@ -2029,25 +2029,57 @@ __global__ __launch_bounds__(256) void span_ranges_kernel(const AccumJob* __rest
 #endif
 
 // exclusive prefix sum of n counts into prefix[0..n] (single workgroup of 1024 threads)
+static int scan_blocks(int n) { const int tiles = (n + 1023) / 1024; return tiles < 1 ? 1 : (tiles > 64 ? 64 : tiles); }
+
+// Exclusive prefix sums of n counts, prefix[n] = the total.  Round 6: up to 64 workgroups instead of one (a single block spent
+// 48-143 us on the 30,472 / 79,696 tile costs of a re-windowed column: 78 strided loads per thread, twice).  Block b owns a
+// segment of whole 1024-element tiles; it first adds up everything BEFORE its segment (the whole block, coalesced - the last
+// block reads the array once: 320 KB from L2), then scans its own tiles with a wave prefix + 16 wave totals.  No block waits
+// for another.
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const unsigned int* __restrict__ counts, int n,
                                                            unsigned long long* __restrict__ prefix) {
-    __shared__ unsigned long long part[1024];
-    const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = min(t * per, n), hi = min(lo + per, n);
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tiles = (n + 1023) / 1024;
+    const int tiles_per_block = (tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const long long lo = (long long)blockIdx.x * tiles_per_block * 1024;
+    const long long hi = min(lo + (long long)tiles_per_block * 1024, (long long)n);
+    if (n == 0) { if (blockIdx.x == 0 && t == 0) prefix[0] = 0ull; return; }
+    if (lo >= n) return;
     unsigned long long s = 0;
-    for (int i = lo; i < hi; ++i) s += counts[i];
-    part[t] = s;
+    for (long long i = t; i < lo; i += 1024) s += counts[i];
+    s = wave_incl_scan_u64(s, lane);
+    if (lane == 63) s_wave[wave] = s;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
-        unsigned long long v = (t >= off) ? part[t - off] : 0ull;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    if (t == 0) {
+        unsigned long long b = 0;
+        for (int w = 0; w < 16; ++w) b += s_wave[w];
+        s_base = b;
     }
-    unsigned long long run = part[t] - s;                 // exclusive base of this thread's segment
-    for (int i = lo; i < hi; ++i) { prefix[i] = run; run += counts[i]; }
-    if (t == 1023) prefix[n] = part[1023];
+    __syncthreads();
+    unsigned long long base = s_base;
+    for (long long tile = lo; tile < hi; tile += 1024) {
+        const long long i = tile + t;
+        const unsigned long long v = i < hi ? (unsigned long long)counts[i] : 0ull;
+        const unsigned long long incl = wave_incl_scan_u64(v, lane);
+        __syncthreads();                                   // (s_wave of the previous tile has been read by everybody)
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        unsigned long long before = 0, total = 0;
+        for (int w = 0; w < 16; ++w) { const unsigned long long x = s_wave[w]; if (w < wave) before += x; total += x; }
+        if (i < hi) prefix[i] = base + before + incl - v;
+        base += total;
+    }
+    if (hi == n && t == 0) prefix[n] = base;
 }
 
 #ifdef LBL_DIAG
@@ -2201,7 +2233,7 @@ static void launch_balanced_r(const AccumJob* d_jobs, int n_jobs, int total_span
                               unsigned int* counts, unsigned long long* prefix, double* slab, hipStream_t s) {
     const int span_blocks = (total_spans + 3) / 4;
     hipLaunchKernelGGL((span_ranges_kernel<R>), dim3(span_blocks), dim3(256), 0, s, d_jobs, n_jobs, total_spans, spans, counts);
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, counts, total_spans, prefix);
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(scan_blocks(total_spans)), dim3(1024), 0, s, counts, total_spans, prefix);
     hipLaunchKernelGGL((xsec_accumulate_balanced_kernel<R>), dim3((n_workers + 3) / 4), dim3(256), 0, s, d_jobs, n_jobs,
                        total_spans, spans, prefix, n_workers, slab);
     hipLaunchKernelGGL((span_finalize_kernel<R>), dim3(span_blocks), dim3(256), 0, s, d_jobs, n_jobs, total_spans, prefix,
@@ -2723,7 +2755,7 @@ void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, 
         }
         return;
     }
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, tile_cost, total_tiles, prefix);
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(scan_blocks(total_tiles)), dim3(1024), 0, s, tile_cost, total_tiles, prefix);
     // 128 KB of dynamic LDS for the per-XCD sort (gfx950 has 160 KB per CU).  The attribute belongs to the (kernel, device)
     // pair and this runs once per new window, so it is simply set on every call, for the device the caller has made current
     // (lbl_api.hip: hipSetDevice(ctx->device)) - a process-wide "already set" flag missed a second device and raced between

@@ -59,6 +59,7 @@ inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new mock_event{0}; ++mock
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; --mockhip::live_events; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->stamp = ++mockhip::clock; return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->stamp - a->stamp) * 1e-3f; return hipSuccess; }
 inline hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) { s->capturing = true; return hipSuccess; }
 inline hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) { s->capturing = false; *g = new mock_graph{1}; ++mockhip::live_graphs; return hipSuccess; }
