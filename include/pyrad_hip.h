@@ -327,9 +327,10 @@ int lbl_layer_step_dev(lbl_ctx* ctx, int n_iso, lbl_lines* const* lines, const l
  * reference's loop adds (pyradClasses.py:392-400) is still evaluated.  A per-isotopologue cross section
  * (Isotope.crossSection) is produced on demand by lbl_xsec_accumulate_dev, as before.
  * Arithmetic: fp64; differs from the per-line-list path by the order of summation and one rounding per line (the
- * factor rides on the amplitude instead of on the sum): a few 1e-16 relative; the sweeps' default arithmetic
- * ("sweep_ieee_divisions" 0) for transmittance and Planck radiance whatever that option says.  "accuracy" applies as
- * usual.  Needs "accum_variant" 3 or 5 and the device schedule build (LBL_ERR_BAD_ARG otherwise: use the per-list step).
+ * factor rides on the amplitude instead of on the sum): a few 1e-16 relative.  They exist in the sweeps' default arithmetic
+ * only: with "sweep_ieee_divisions" 1 lbl_layer_merged_step_dev, lbl_column_fold_dev and lbl_column_transmission answer
+ * LBL_ERR_BAD_ARG (ABI 5; until then the option was silently ignored there) - use the per-line-list entry points, which honour
+ * it.  "accuracy" applies as usual.  At most 64 line lists per layer (lbl_limit "merged_lists_per_job").  Needs "accum_variant" 3 or 5 and the device schedule build (LBL_ERR_BAD_ARG otherwise: use the per-list step).
  *
  * lbl_layer_merged_step_dev: one layer (gas cell) - line prep, ONE accumulate job over the merged lists, and in its
  * output stage k, transmittance exp(-k depth) and outgoing radiance trans * I_in + (1 - trans) * B(nu, T)

@@ -266,6 +266,10 @@ class Context:
 
     def set_option(self, key: str, value: int):
         self.check(self.lib.lbl_set_option(self.h, key.encode(), int(value)))
+        self.__dict__.setdefault("options", {})[key] = int(value)      # what was set through this object (hosts choose routes by it)
+
+    def option(self, key: str, default: int = 0) -> int:
+        return self.__dict__.get("options", {}).get(key, default)
 
     PROFILE_KINDS = {"line_prep": 0, "xsec_accumulate": 1, "regrid": 2, "layer_sweep": 3, "column_sweep": 4,
                      "allgather": 5}

@@ -1103,6 +1103,7 @@ class Layer(_OpticalMixin, list):
         any of its line lists is due (all of them line-by-line: a measured cross-section table has no lines to merge).
         With every cross section current (somebody asked for each of them) the sweep kernel over those arrays is cheaper."""
         return (settings.LAYER_STEP == "merged" and bool(lbl) and len(lbl) == len(flat)
+                and not _ctx().option("sweep_ieee_divisions")            # (the reference's rounding chain: per-line-list entry points only)
                 and len(flat) <= nat.limit("merged_lists_per_job")      # (more line lists: the per-line-list step, up to "arrays_per_layer")
                 and not any(i._xs_installed and i.progressCrossSection for i in lbl)     # an installed array is not the lines' (advisor, round 5)
                 and any(not i.progressCrossSection or i._xs_deferred for i in lbl))
@@ -1287,7 +1288,7 @@ class Atmosphere(list):
         line lists than a job takes, an installed cross section) brings its absorption coefficient by its own route
         (_ensure_swept) and is folded with the others.  None only when settings.LAYER_STEP is not "merged": the caller then
         goes through the per-line-list cross sections of the whole column (lbl_column_step_dev)."""
-        if settings.LAYER_STEP != "merged":
+        if settings.LAYER_STEP != "merged" or ctx.option("sweep_ieee_divisions"):
             return None
         fast = self._transmission_resident(ctx, layers, n, surfaceSpectrum, surfaceTemperature)
         if fast is not None:

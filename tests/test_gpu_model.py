@@ -672,3 +672,32 @@ def test_an_installed_cross_section_is_what_the_layer_sums(pyrad):
     f = 400e-6 * float(z["P"]) / 1e4 / 1.38064852E-23 / int(z["T"])
     assert rel_err(k1 - k0, 2.0 * xs0 * f, floor=float(np.max(k0)) * 1e-3) <= 1e-9      # the layer gained exactly 2 x that cross section
     assert rel_err(k2, k0) > 1e-3
+
+
+def test_the_reference_rounding_chain_takes_the_per_list_route(pyrad):
+    """advisor, round 5: "sweep_ieee_divisions" 1 (the reference's own chain of correctly rounded divisions) used to be silently
+    ignored by the merged entry points, which the object model takes by default.  Now the library refuses it there
+    (LBL_ERR_BAD_ARG) and the model, seeing the option on its context, takes the per-line-list route, which honours it: the
+    absorption coefficient is then bit for bit NumPy's expression on the device's cross sections."""
+    from pyrad_amd import _native as nat
+    z = load_golden("G6_composition")
+    source(co2=unpack_lines(z, "co2.lines"), co2_636=unpack_lines(z, "co2_636.lines"), h2o=unpack_lines(z, "h2o.lines"))
+    pyrad.Layer.hasAtmosphere = False
+    layer = pyrad.Layer(float(z["depth"]), int(z["T"]), float(z["P"]), 1000, 1040)
+    layer.addMolecule('co2', isotopeDepth=2, ppm=400)
+    layer.addMolecule('h2o', **{'%': 1.5})
+    ctx = pyrad._ctx()
+    ctx.set_option("sweep_ieee_divisions", 1)
+    try:
+        k = np.array(pyrad.getAbsCoef(layer))
+        assert not any(iso._xs_deferred for m in layer for iso in m)          # the per-list route ran: the cross sections exist
+        xs = [sum(np.array(pyrad.getCrossSection(iso)) for iso in m) for m in layer]
+        want = sum(x * m.concentration * layer.P / 1E4 / 1.38064852E-23 / layer.T for x, m in zip(xs, layer))
+        assert np.array_equal(k, want)
+        g = pyrad._engine.native_grid(layer._grid())
+        flat = [iso for m in layer for iso in m]
+        with pytest.raises(nat.LblError, match="default arithmetic"):
+            ctx.layer_merged_step_dev([i._device_lines(ctx) for i in flat], [pyrad._iso_params(i) for i in flat], g, [0, 0, 1],
+                                      [m.concentration for m in layer], layer.depth, abs_coef=ctx.buffer(g.n_base))
+    finally:
+        ctx.set_option("sweep_ieee_divisions", 0)
