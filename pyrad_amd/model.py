@@ -1095,7 +1095,7 @@ class Layer(_OpticalMixin, list):
             conc.append(m.concentration)
             for iso in m:
                 ver += iso._inputs_version
-                struct += iso._struct_version
+                struct += iso._struct_version + id(iso)          # (WHICH isotopologues: a molecule swapped for another re-reads the layer)
         return (self.T, self.P, self.rangeMin, self.rangeMax, self.resolution, len(self), struct, tuple(conc), self.depth), ver
 
     def _merged_step_applies(self, flat, lbl):

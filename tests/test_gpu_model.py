@@ -701,3 +701,48 @@ def test_the_reference_rounding_chain_takes_the_per_list_route(pyrad):
                                       [m.concentration for m in layer], layer.depth, abs_coef=ctx.buffer(g.n_base))
     finally:
         ctx.set_option("sweep_ieee_divisions", 0)
+
+
+def test_resident_column_follows_every_kind_of_change(pyrad):
+    """Atmosphere.transmission through the resident column handle (lbl_column, round 6) against a freshly built atmosphere
+    through the general route, after each kind of change between calls: temperature, pressure (new windows), range, depth,
+    concentration, a molecule swapped for another one, a layer added, the surface given as a spectrum - and unchanged calls."""
+    lines = dict(co2=synthetic.make_lines(71, 900, 580, 720), h2o=synthetic.make_lines(72, 600, 580, 720), ch4=synthetic.make_lines(73, 300, 580, 720))
+    source(**lines)
+    spec = [(1e4, 288, 1013.25), (2e4, 270, 700.0), (5e4, 240, 300.0)]
+
+    def build(mods):
+        pyrad.Layer.hasAtmosphere = False
+        atm = pyrad.Atmosphere("col")
+        for depth, T, P in spec:
+            L = atm.addLayer(depth, T, P, 600, 700)
+            L.addMolecule('co2', ppm=400)
+            L.addMolecule('h2o', percentage=0.5)
+        for f in mods:
+            f(atm)
+        return atm
+
+    mods = []
+    live = build(mods)
+    first = np.array(live.transmission(surfaceTemperature=288))
+    assert "_column_fast" in live.__dict__                                   # the handle exists after the first call
+    assert np.array_equal(live.transmission(surfaceTemperature=288), first)  # unchanged: nothing is due, the fold runs
+
+    def swap_molecule(a):
+        gone = a[2].pop(1)
+        a[2].addMolecule(6, ppm=1.8)
+
+    steps = [lambda a: a[1].changeTemperature(255), lambda a: a[0].changePressure(900.0), lambda a: a[2].changeDepth(7e4),
+             lambda a: a[1][0].setPPM(420), swap_molecule, lambda a: [L.changeRange(610, 690) for L in a],
+             lambda a: a.addLayer(8e4, 220, 80.0, 610, 690).addMolecule('co2', ppm=400)]
+    for i, f in enumerate(steps):
+        f(live)
+        mods.append(f)
+        got = np.array(live.transmission(surfaceTemperature=288))
+        fresh = build(mods)
+        fresh.__dict__["_column_fast"] = None
+        want = np.array(fresh.transmission(surfaceTemperature=288))
+        assert got.shape == want.shape and rel_err(got, want) <= 1e-13, i
+        surf = np.array(live[0].planck(300))
+        assert rel_err(live.transmission(surfaceSpectrum=surf), fresh.transmission(surfaceSpectrum=surf)) <= 1e-13, i
+        assert np.array_equal(live.transmission(surfaceTemperature=288), got), i
