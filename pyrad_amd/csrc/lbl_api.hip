@@ -1088,8 +1088,13 @@ static lbl_ctx::Schedule* group_schedule(lbl_ctx* ctx, int variant, const std::v
                 iF1 = std::min(std::max(below(lo + 32 * R - reach), iB), iC);      // first line with c > fl
                 iF2 = std::min(std::max(below(lo + 32 * R + reach), iF1), iC);     // first line with c >= fr
             }
+            int32_t iN1 = iF1, iN2 = iF2;                                          // the bounds at 3 half-spans (FF_MID), inside [iF1, iF2]
+            if (far_field) {
+                iN1 = std::min(std::max(below(lo + 32 * R - 3LL * 32 * R), iF1), iF2);
+                iN2 = std::min(std::max(below(lo + 32 * R + 3LL * 32 * R), iN1), iF2);
+            }
             int32_t* e = T + t * 8;
-            e[0] = iA; e[1] = iB; e[2] = iC; e[3] = iD; e[4] = iF1; e[5] = iF2;
+            e[0] = iA; e[1] = iB; e[2] = iC; e[3] = iD; e[4] = iF1; e[5] = iF2; e[6] = iN1; e[7] = iN2;
         }
         // cost of every tile (a workgroup's points): lines it walks, far lines at their series price
         const long long n_tiles = (sc + tile_pts - 1) / tile_pts;
@@ -1335,11 +1340,15 @@ static int enqueue_accumulate(lbl_ctx* ctx, int n_jobs, lbl_lines* const* lines,
             choose_shape(ctx, g.variant, pts, lns, mh, &g.R, &g.LS);
             // with the R actually chosen (a small grid may have shrunk it): does any job of the group have far lines?
             if (ctx->accum_variant == 5 && mxh < 32LL * g.R * (far_half_spans + 1)) g.variant = 3;
-            // Gaussian runs of 32 points (the far-field kernel's three-waves-per-SIMD build, lbl_kernels.hip) for launches of
-            // more than one round of the chip's wave slots at four per SIMD; a launch that fits one round keeps the 16-point build
+            // Gaussian runs of 32 points (the far-field kernel's three-waves-per-SIMD build, lbl_kernels.hip).  Budget mode: for
+            // launches of more than one round of the chip's wave slots at four per SIMD, a launch that fits one round keeps the
+            // 16-point build.  Exact mode: the 32-point build is also the one whose series starts at 3 half-spans (fewer
+            // instructions per span), so it takes every launch except those that fit one round at four waves per SIMD but not
+            // at three (column of 50 layers, forced 16 / this rule / forced 32, same box: 3.797 / 3.623 -> 3.60 / 3.604 ms).
             if (g.variant == 5 && g.R == 4 && g.LS == 1) {
-                const long long waves = (pts + 255) / 256, slots = 16LL * (ctx->n_cu > 0 ? ctx->n_cu : 256);
-                g.grun = ctx->gauss_run ? ctx->gauss_run : (waves > slots ? 32 : 16);
+                const long long waves = (pts + 255) / 256, n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+                const bool run32 = ctx->accuracy ? waves > 16 * n_cu : !(waves > 12 * n_cu && waves <= 16 * n_cu);
+                g.grun = ctx->gauss_run ? ctx->gauss_run : (run32 ? 32 : 16);
             }
         }
         if ((g.variant == 3 || g.variant == 5 || g.variant == 6) && (ctx->lpt || merge)) {

@@ -631,13 +631,13 @@ __device__ __forceinline__ void wave_line_ranges(const int32_t* __restrict__ cid
 //   [iB, iF1)  far-left interior lines,  c <= fl      [iF2, iC)  far-right interior lines,  c >= fr
 __device__ __forceinline__ void wave_line_ranges_far(const int32_t* __restrict__ cidx, int n_lines, int wlo, int whi, int H,
                                                      long long fl, long long fr, int lane, int& iA, int& iB, int& iC,
-                                                     int& iD, int& iF1, int& iF2) {
+                                                     int& iD, int& iF1, int& iF2, int& iN1, int& iN2, long long nl, long long nr) {
     const long long tA = (long long)wlo - H, tB = (long long)whi - H;
     const long long tC = (long long)wlo + H + 1, tD = (long long)whi + H + 1;
     const int q = lane >> 3, jj = lane & 7;
-    const long long tgt = q == 0 ? tA : q == 1 ? tB : q == 2 ? tC : q == 3 ? tD : q == 4 ? fl + 1 : fr;
+    const long long tgt = q == 0 ? tA : q == 1 ? tB : q == 2 ? tC : q == 3 ? tD : q == 4 ? fl + 1 : q == 5 ? fr : q == 6 ? nl + 1 : nr;
     const unsigned long long gmask = 0xFFull << (q * 8);
-    int lo = 0, hi = (q < 6) ? n_lines : 0;
+    int lo = 0, hi = n_lines;
     while (__any(hi > lo)) {
         const long long len = (long long)hi - lo;
         const int pos = lo + (int)(((long long)(jj + 1) * len) / 9);
@@ -660,6 +660,8 @@ __device__ __forceinline__ void wave_line_ranges_far(const int32_t* __restrict__
     if (tB >= tC) { iB = iD; iC = iD; }
     iF1 = min(max(iF1, iB), iC);
     iF2 = min(max(iF2, iF1), iC);
+    iN1 = min(max(__builtin_amdgcn_readlane(lo, 48), iF1), iF2);       // the bounds at FF_MID half-spans, inside [iF1, iF2]
+    iN2 = min(max(__builtin_amdgcn_readlane(lo, 56), iN1), iF2);
 }
 
 // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so each XCD gets a
@@ -956,7 +958,10 @@ __device__ __forceinline__ void chunk_extras(const double* __restrict__ lh, cons
 template <int R, int LONGG = 0, int RUN = 16>
 __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRec* cold, int mA, int mD, int iB, int iC,
                                                  int wlo, int whi, double x0, double Hf, double* lh, double* lc, int lane,
-                                                 WaveAcc<R>& S, double (&G16)[RUN], int stride = 64, int step = 1, int phase = 0) {
+                                                 WaveAcc<R>& S, double (&G16)[RUN], int stride = 64, int step = 1, int phase = 0,
+                                                 int nL = 0, int nR = 0x7fffffff) {
+    // [nL, nR): the records whose LORENTZ term this walk adds (round 6: the lines between FF_MID and FF_FAR half-spans take
+    // their Lorentz term from the series and only their Gaussian part from this walk)
     // step > 1 (with stride = 64): every wave of the span walks ALL chunks but takes only the records
     // j % step == phase of each, so the split is exact to a line.  Dealing whole chunks left one wave
     // of a two-way split with 128 of a span's ~210 near lines and the other with 82.
@@ -985,7 +990,7 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
         const bool gauss = valid && mine && max(0, max(ci - whi, wlo - ci)) < dgi;
         const bool direct = valid && (fl & REC_DIRECT_DIV) != 0;
         const unsigned long long gmask = __ballot(gauss);
-        const unsigned long long dmask = __ballot(direct) & stripe;
+        const unsigned long long dmask = __ballot(direct && c0 + lane >= nL && c0 + lane < nR) & stripe;
         const unsigned long long emask = __ballot((fl & REC_NO_RECUR) != 0);
         const unsigned long long lmask = LONGG ? __ballot((fl & (RUN == 32 ? REC_LONG_RUN32 : REC_LONG_RUN)) != 0) : 0ull;
         v2f64 w0 = h0, w1 = h1;
@@ -1006,12 +1011,12 @@ __device__ __forceinline__ void accumulate_lines(const HotRec* hot, const ColdRe
             h0 = gh[r]; h1 = gh[r + 1];
         }
         // the three classes of lines inside this chunk, as offsets into the chunk
-        const int a0 = 0, a1 = max(min(iB, c1), c0) - c0;
+        const int a1 = max(min(iB, c1), c0) - c0;
         const int b1 = max(min(iC, c1), c0) - c0;
-        const int e1 = c1 - c0;
-        rf_segment<R, true>(lh, a0, a1, x0, Hf, S, step, phase);
-        rf_segment<R, false>(lh, a1, b1, x0, Hf, S, step, phase);
-        rf_segment<R, true>(lh, b1, e1, x0, Hf, S, step, phase);
+        const int n0 = max(min(nL, c1), c0) - c0, n1 = max(min(nR, c1), c0) - c0;     // the chunk's share of [nL, nR)
+        rf_segment<R, true>(lh, n0, min(a1, n1), x0, Hf, S, step, phase);
+        rf_segment<R, false>(lh, max(a1, n0), min(b1, n1), x0, Hf, S, step, phase);
+        rf_segment<R, true>(lh, max(b1, n0), n1, x0, Hf, S, step, phase);
         if (gmask | dmask) {
             if (gauss || (direct && mine)) {
                 reinterpret_cast<v2f64*>(lc)[lane * 2] = c0v;
@@ -1064,6 +1069,15 @@ constexpr int FF_NT_BUDGET = 18;
 // 50.2, the column 3.78 vs 3.90 ms: no gain overall.  The threshold stays a template constant per mode.)
 constexpr int FF_FAR_BUDGET = 4;
 template <int NT> struct FarThreshold { static constexpr int value = NT == FF_NT_BUDGET ? FF_FAR_BUDGET : FF_FAR; };
+// Round 6, the three-waves-per-SIMD build of the exact mode (32-point Gaussian runs, 168 VGPRs): the series takes the
+// Lorentz terms from FF_MID = 3 half-spans on, with FF_NT_MID = 38 terms for the chunks nearer than 4 (rho <= 1/3: remainder
+// <= rho^38 (38 (1 - rho) + 1) (1 + rho)^2 / (1 - rho)^2 = 7.8e-17 of a line's own smallest term on the span, below half an ulp).
+// The lines between 3 and 4 half-spans - a quarter of what the running fraction used to walk - keep their Gaussian parts in
+// the near walk's runs (the span table carries both bounds: slots 4, 5 at FF_FAR, slots 6, 7 at FF_MID).  Measured with the
+// Gaussian parts switched off (diagnostic builds, same box): K2 165 -> 151.5 us on the merged 100-2500 cm^-1 cell.
+constexpr int FF_MID = 3;
+constexpr int FF_NT_MID = 38;
+template <int NT> struct LorentzNear { static constexpr int value = NT == FF_NT_MID ? FF_MID : FarThreshold<NT>::value; };
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_move_f64(double v) {
@@ -1126,8 +1140,8 @@ __device__ __forceinline__ void wave_sum_rows(double (&C)[NT], double* scratch, 
 // Budget mode (NT = 18, 5.9e-10): d >= 8: 12 (2.8e-10), d >= 16: 9 (1.8e-10), d >= 32: 7 (2.6e-10).  With a window of
 // +-39 half-spans two thirds of the far lines are beyond 16 half-spans: 17 terms on average instead of 30.
 template <int NT> struct FarTerms {
-    static constexpr bool exact = NT == FF_NT, budget = NT == FF_NT_BUDGET;
-    static constexpr int t4 = budget ? 18 : NT;            // (exact mode's threshold IS 4 half-spans: its nearest class takes all NT)
+    static constexpr bool exact = NT == FF_NT || NT == FF_NT_MID, budget = NT == FF_NT_BUDGET;
+    static constexpr int t4 = budget ? 18 : (NT == FF_NT_MID ? FF_NT : NT);     // (from 4 half-spans on: 30 terms; nearer, NT = 38: the build whose series starts at 3)
     static constexpr int t8 = exact ? 20 : (budget ? 12 : NT);
     static constexpr int t16 = exact ? 15 : (budget ? 9 : NT);
     static constexpr int t32 = exact ? 12 : (budget ? 7 : NT);
@@ -1151,7 +1165,8 @@ __device__ __forceinline__ void series_terms(double al, double bp, double& qa, d
 template <int R, int NT>
 __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec* cold, int m0, int m1, int stride,
                                                 double xc, int wlo, int whi, double x0, double Hf, double* lh, double* lc,
-                                                int lane, double (&C)[NT], WaveAcc<R>& S) {
+                                                int lane, double (&C)[NT], WaveAcc<R>& S, int gx_lo = 0, int gx_hi = 0) {
+    // records [gx_lo, gx_hi): their Gaussian parts belong to the near walk (lines between FF_MID and FF_FAR half-spans)
     typedef double v2f64 __attribute__((ext_vector_type(2)));
     typedef const v2f64 __attribute__((address_space(1)))* GlobalF64x2;
     const GlobalF64x2 gh = (GlobalF64x2)(unsigned long long)hot;
@@ -1171,7 +1186,7 @@ __device__ __forceinline__ void far_field_lines(const HotRec* hot, const ColdRec
         }
         const int ci = (int)w0.x;
         const int dgi = __double2loint(w1.y), fl = __double2hiint(w1.y);
-        const bool gauss = valid && max(0, max(ci - whi, wlo - ci)) < dgi;
+        const bool gauss = valid && max(0, max(ci - whi, wlo - ci)) < dgi && !(c0 + lane >= gx_lo && c0 + lane < gx_hi);
         const unsigned long long gmask = __ballot(gauss);
         if (gmask) {                                   // rare: a far line with a Gaussian part that reaches the span
             const unsigned long long emask = __ballot((fl & REC_NO_RECUR) != 0);
@@ -1673,17 +1688,24 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         // chunks of every class are dealt round-robin to the LS waves, each class starting at a
         // different wave so that the short classes do not all land on wave 0
         constexpr int FAR = FarThreshold<NT>::value;
+        constexpr int NEAR = LorentzNear<NT>::value;          // the series takes the Lorentz terms from here on (< FAR: round 6)
+        static_assert(NEAR == FAR || EDGE_SKEW, "the mid class needs the near walk that knows the Lorentz sub-range");
         const long long fl = (long long)wlo + 32 * R - 1 - (long long)FAR * 32 * R;
         const long long fr = (long long)wlo + 32 * R + (long long)FAR * 32 * R;
         const double xc = (double)wlo + (32.0 * R - 0.5);
-        int iA, iB, iC, iD, iF1, iF2;
+        int iA, iB, iC, iD, iF1, iF2, iN1, iN2;
         if (tab) {           // wave-uniform values: keep them in scalar registers
             iA = uniform_i32(tab[0]); iB = uniform_i32(tab[1]); iC = uniform_i32(tab[2]); iD = uniform_i32(tab[3]);
             iF1 = uniform_i32(tab[4]); iF2 = uniform_i32(tab[5]);
+            iN1 = NEAR < FAR ? uniform_i32(tab[6]) : iF1; iN2 = NEAR < FAR ? uniform_i32(tab[7]) : iF2;
         }
-        else wave_line_ranges_far(J.cidx, J.n_lines, wlo, whi, H, fl, fr, lane, iA, iB, iC, iD, iF1, iF2);
+        else {
+            wave_line_ranges_far(J.cidx, J.n_lines, wlo, whi, H, fl, fr, lane, iA, iB, iC, iD, iF1, iF2, iN1, iN2,
+                                 (long long)wlo + 32 * R - 1 - (long long)FF_MID * 32 * R, (long long)wlo + 32 * R + (long long)FF_MID * 32 * R);
+            if (!(NEAR < FAR)) { iN1 = iF1; iN2 = iF2; }
+        }
         if (LBL_ABLATE(J, 8)) { iA = iB; iD = iC; }                       // (diagnostic builds, timing only: no edge lines)
-        const bool any_far = !LBL_ABLATE(J, 256) && (iF1 - iB) + (iC - iF2) > 0;      // (256: far lines dropped)
+        const bool any_far = !LBL_ABLATE(J, 256) && (iN1 - iB) + (iC - iN2) > 0;      // (256: far lines dropped)
         // edge lines first (skewed walk), while neither the series coefficients nor the Gaussian run sums are live
         // (also on spans without any far line - windows just above the kernel's limit, grid ends: their interior lines
         // are all near, [iF1, iF2) = [iB, iC))
@@ -1719,8 +1741,9 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
             double C[NTC];
 #pragma unroll
             for (int n = 0; n < NTC; ++n) C[n] = 0.0;
-            far_field_lines<R, NTC>(J.hot, J.cold, iB + ((part + 1) % LS) * 64, iF1, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S);
-            far_field_lines<R, NTC>(J.hot, J.cold, iF2 + ((part + 2) % LS) * 64, iC, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S);
+            // (the Gaussian parts of the records [iF1, iF2) belong to the near walk below)
+            far_field_lines<R, NTC>(J.hot, J.cold, iB + ((part + 1) % LS) * 64, iN1, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S, iF1, iF2);
+            far_field_lines<R, NTC>(J.hot, J.cold, iN2 + ((part + 2) % LS) * 64, iC, 64 * LS, xc, wlo, whi, x0, Hf, lh, lc, lane, C, S, iF1, iF2);
             wave_sum_rows<NTC>(C, s_stage[wave], lane);
 #pragma unroll
             for (int k = 0; k < R; ++k) {
@@ -1740,7 +1763,7 @@ void xsec_accumulate_lds_kernel(const AccumJob* __restrict__ jobs, const int2* _
         for (int k = 0; k < GRUN; ++k) G[k] = 0.0;
         if (LBL_ABLATE(J, 512)) {                                            // (512: near lines dropped)
         } else if (edges_done) {
-            accumulate_lines<R, 1, GRUN>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
+            accumulate_lines<R, 1, GRUN>(J.hot, J.cold, iF1, iF2, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part, iN1, iN2);
         } else {
             accumulate_lines<R, 1, GRUN>(J.hot, J.cold, iA, any_far ? iB : iD, iB, iC, wlo, whi, x0, Hf, lh, lc, lane, S, G, 64, LS, part);
             if (any_far) {
@@ -2296,8 +2319,14 @@ __global__ __launch_bounds__(256) void sched_spans_kernel(const SchedJob* __rest
         iF1 = min(max(lower_bound_i32(J.cidx, J.n_lines, lo + 32 * R - far_reach), iB), iC);     // first line with c > fl
         iF2 = min(max(lower_bound_i32(J.cidx, J.n_lines, lo + 32 * R + far_reach), iF1), iC);    // first line with c >= fr
     }
+    int iN1 = iF1, iN2 = iF2;                                           // the bounds at FF_MID half-spans, inside [iF1, iF2]
+    if (far_reach > 0) {
+        const long long mid_reach = (long long)FF_MID * 32 * R;
+        iN1 = min(max(lower_bound_i32(J.cidx, J.n_lines, lo + 32 * R - mid_reach), iF1), iF2);
+        iN2 = min(max(lower_bound_i32(J.cidx, J.n_lines, lo + 32 * R + mid_reach), iN1), iF2);
+    }
     int32_t* e = tabs + ((size_t)J.span_first + (size_t)q) * 8;
-    e[0] = iA; e[1] = iB; e[2] = iC; e[3] = iD; e[4] = iF1; e[5] = iF2; e[6] = 0; e[7] = 0;
+    e[0] = iA; e[1] = iB; e[2] = iC; e[3] = iD; e[4] = iF1; e[5] = iF2; e[6] = iN1; e[7] = iN2;
     // wave-instructions of the span, as group_schedule prices them
     const double n_far = (double)((iF1 - iB) + (iC - iF2)), n_edge = (double)((iB - iA) + (iD - iC)), n_near = (double)(iF2 - iF1);
     const double c = n_near * cost_near + n_edge * cost_edge + n_far * cost_far + cost_fixed;
@@ -3175,8 +3204,8 @@ static void launch_accum_lds(const AccumJob* d_jobs, int n_jobs, int max_tiles, 
         case 2: hipLaunchKernelGGL((xsec_accumulate_lds_kernel<R, 2, NT>), grid, dim3(256), pad, s, d_jobs, worklist); break;
         default:
             if constexpr (R == 4 && NT > 0) {
-                if (gauss_run == 32) {
-                    hipLaunchKernelGGL((xsec_accumulate_lds_kernel<4, 1, NT, 32>), grid, dim3(256), pad, s, d_jobs, worklist);
+                if (gauss_run == 32) {        // the three-waves-per-SIMD build; exact mode: its series starts at FF_MID half-spans (38 terms)
+                    hipLaunchKernelGGL((xsec_accumulate_lds_kernel<4, 1, (NT == FF_NT ? FF_NT_MID : NT), 32>), grid, dim3(256), pad, s, d_jobs, worklist);
                     break;
                 }
             }

@@ -23,11 +23,21 @@ FLOOR_REL = 1e-250
 
 
 @pytest.fixture(scope="module")
-def ctx():
+def _ctx():
     from pyrad_amd import _native as nat
     c = nat.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(params=[0, 16], ids=["runs:auto", "runs:16"])
+def ctx(_ctx, request):
+    """Every test of this module twice: with the library's own choice of the far-field kernel's build (exact mode: the
+    32-point Gaussian runs whose series starts at 3 half-spans, for almost every launch) and with the 16-point build forced
+    (series from 4 half-spans) - the two builds differ in which lines take which path."""
+    _ctx.set_option("accum_gauss_run", request.param)
+    yield _ctx
+    _ctx.set_option("accum_gauss_run", 0)
 
 
 @pytest.fixture(scope="module")
