@@ -3,6 +3,8 @@
 # bench passes per workload since round 5):
 #   gpurun --timeout 1200 -- 'bash scripts/collect_all.sh r05 a'      (C3 and its shards of 8, 4, 2)
 #   gpurun --timeout 1200 -- 'bash scripts/collect_all.sh r05 b'      (C5, C2, C1)
+# Copy gpurun_out/<tag>/final/* into profiles/ BETWEEN the two calls: a box only receives the repo (gpurun_out/ does not travel),
+# so the second call extends the profiles/pmc_traffic.json and profiles/<tag>_boxes.jsonl it finds there.
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r06}
 PART=${2:-a}
