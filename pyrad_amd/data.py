@@ -83,8 +83,10 @@ _WINDOWS = {}
 def _note_window(views, master, first, count):
     nu_view = views["nu"]
     key = id(nu_view)
+    # (the sibling views themselves, held while the wavenumber view lives: the test below is object identity - an id can be
+    #  reused by another view of the same list once the original has been dropped)
     _WINDOWS[key] = (_weakref.ref(nu_view, lambda _r, k=key: _WINDOWS.pop(k, None)), _weakref.ref(master), int(first), int(count),
-                     {f: id(v) for f, v in views.items()})
+                     {f: v for f, v in views.items() if f != "nu"})
 
 
 def master_slice(lines: dict, fields):
@@ -95,10 +97,10 @@ def master_slice(lines: dict, fields):
     if hit is not None and hit[0]() is nu:
         master, first, n = hit[1](), hit[2], hit[3]
         if master is not None and _MASTERS.get(id(master["nu"])) is master:
+            sib = hit[4]
             for f in fields:
-                a, m = lines.get(f), master.get(f)
-                # (the very view objects gatherData made together - alive, so their ids are theirs; an array somebody swapped in fails here)
-                if a is None or m is None or id(a) != hit[4].get(f) or a.base is not m:
+                # (the very view objects gatherData made together; an array somebody swapped in fails here)
+                if f != "nu" and lines.get(f) is not sib.get(f, master):
                     break
             else:
                 return master, first, n
