@@ -2128,7 +2128,7 @@ extern "C" int lbl_column_fold_dev(lbl_ctx* ctx, int n_layers, lbl_buffer* const
     void* d_args = nullptr;
     if ((rc = device_args(ctx, a, sizeof(ColumnStepArgs), &d_args))) return rc;
     hipEvent_t ev = prof_begin(ctx, PROF_COLUMN);
-    launch_column_step((const ColumnStepArgs*)d_args, first, count, ctx->stream, 1);
+    launch_column_step((const ColumnStepArgs*)d_args, first, count, ctx->stream, 1, 1);
     prof_end(ctx, PROF_COLUMN, ev);
     HIP_TRY(ctx, hipGetLastError());
     return LBL_OK;

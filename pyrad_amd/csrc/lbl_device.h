@@ -253,7 +253,8 @@ void launch_accumulate_balanced(const AccumJob* d_jobs, int n_jobs, int total_sp
 void launch_regrid(const double* work, long long n_work, double* out, long long n_base, double start, double stop,
                    hipStream_t s);
 void launch_layer_sweep(const SweepArgs& a, hipStream_t s);
-void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s, int budget = 0);
+// kfold: every term is a whole layer with factor 1 (the fold over absorption coefficients): the kernel then skips the per-molecule sums
+void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s, int budget = 0, int kfold = 0);
 void launch_column_sweep(const ColumnArgs* d_args, long long n, hipStream_t s, int budget = 0);
 void launch_planck(double* out, long long n, double start, double stop, double T, double rT, double pa, double pb, hipStream_t s);
 void launch_band_integral(const double* y, long long n, double* partial, double* result, hipStream_t s);

@@ -2969,14 +2969,16 @@ __device__ __forceinline__ double expm1_tiny(double x) {
     return x * fma(x, fma(x, fma(x, 1.0 / 24.0, 1.0 / 6.0), 0.5), 1.0);
 }
 
-template <int NP, bool BUDGET = false>
+// KFOLD (round 6): the fold over absorption coefficients (lbl_column_fold_dev, the column handle) - every term IS a layer, its
+// factor 1: the per-molecule sums are skipped (0 + v = v, v * 1 = v: the same bits) and the flags are never read.
+template <int NP, bool BUDGET = false, bool KFOLD = false>
 __global__ __launch_bounds__(256, (NP == 4 ? 3 : 1)) void column_step_kernel(const ColumnStepArgs* __restrict__ Ap, long long first, long long count) {
 #pragma clang fp contract(off)
     // NP grid points per thread (2: 16-byte loads, 4: 32-byte; the host gives these instantiations a first point and a count
     // that are multiples of NP)
     // terms per batch of loads (two batches in flight).  Four points per thread: 2 - 144 VGPRs, three waves per SIMD, the fold of the
     // 30-layer column 147-150 us; 3 needs 169 (two waves per SIMD: 172 us; capped at 168 it spills: 161 us)
-    constexpr int NB = NP == 4 ? 2 : 6;
+    constexpr int NB = NP == 4 ? 2 : 6;     // (KFOLD with 3: 168 VGPRs and 70 spilled)
     typedef double vec __attribute__((ext_vector_type(NP)));
     typedef const vec __attribute__((address_space(1)))* GlobalVec;
     const ColumnStepArgs& A = *Ap;
@@ -3018,11 +3020,13 @@ __global__ __launch_bounds__(256, (NP == 4 ? 3 : 1)) void column_step_kernel(con
         int l = 0;
         auto term = [&](auto fast_tag, int t, vec v) {
             constexpr bool FAST = decltype(fast_tag)::value;
-            const int f = A.term_flags[t];
+            const int f = KFOLD ? (TERM_LAST_MOL | TERM_LAST_LAYER) : A.term_flags[t];
+            if (!KFOLD) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) xs[p] += v[p];
+                for (int p = 0; p < NP; ++p) xs[p] += v[p];
+            }
             if (LBL_ABLATE(A, 16)) { I[0] += v[0]; return; }       // (diagnostic builds: memory traffic only)
-            if (f & TERM_LAST_MOL) {
+            if (!KFOLD && (f & TERM_LAST_MOL)) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     kk[p] += BUDGET ? xs[p] * A.term_factor[t] : abs_coef_term(xs[p], A.term_conc[t], A.term_P[t], A.term_T[t], A.term_rT[t]);
@@ -3034,9 +3038,10 @@ __global__ __launch_bounds__(256, (NP == 4 ? 3 : 1)) void column_step_kernel(con
                 if (FAST) E0 = exp_clamped(pb_n[0] * A.term_pbkT[t]);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    const double tr = BUDGET ? exp_neg_budget(kk[p] * A.term_depth[t]) : exp(-kk[p] * A.term_depth[t]);
+                    const double kp = KFOLD ? v[p] : kk[p];
+                    const double tr = BUDGET ? exp_neg_budget(kp * A.term_depth[t]) : exp(-kp * A.term_depth[t]);
                     if (layer_arrays) {
-                        if (A.abs_coef[l]) A.abs_coef[l][j + p] = kk[p];
+                        if (A.abs_coef[l]) A.abs_coef[l][j + p] = kp;
                         if (A.trans[l]) A.trans[l][j + p] = tr;
                     }
                     double B;
@@ -3051,9 +3056,15 @@ __global__ __launch_bounds__(256, (NP == 4 ? 3 : 1)) void column_step_kernel(con
                     } else {
                         B = planck_at(pa_n[p], pb_n[p], A.term_T[t], A.term_rT[t]);
                     }
-                    const double transmitted = tr * I[p];
-                    const double emitted = (1.0 - tr) * B;
-                    I[p] = transmitted + emitted;
+                    if (FAST) {
+                        // tr I + (1 - tr) B as B + tr (I - B): two instructions instead of four (default arithmetic only; the
+                        // difference is formed first, so I = B stays B and the result is within an ulp of the reference's form)
+                        I[p] = fma(tr, I[p] - B, B);
+                    } else {
+                        const double transmitted = tr * I[p];
+                        const double emitted = (1.0 - tr) * B;
+                        I[p] = transmitted + emitted;
+                    }
                     kk[p] = 0.0;
                 }
                 if (layer_arrays) ++l;
@@ -3325,16 +3336,16 @@ void launch_layer_sweep(const SweepArgs& a, hipStream_t s) {
 }
 
 template <bool BUDGET>
-static void launch_column_step_b(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s);
+static void launch_column_step_b(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s, bool kfold);
 
-void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s, int budget) {
+void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s, int budget, int kfold) {
     if (count <= 0) return;
-    if (budget) launch_column_step_b<true>(d_args, first, count, s);
-    else launch_column_step_b<false>(d_args, first, count, s);
+    if (budget) launch_column_step_b<true>(d_args, first, count, s, kfold != 0);
+    else launch_column_step_b<false>(d_args, first, count, s, false);
 }
 
 template <bool BUDGET>
-static void launch_column_step_b(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s) {
+static void launch_column_step_b(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t s, bool kfold) {
 #ifdef LBL_DIAG
     static const bool pairs = !getenv("LBL_DIAG_COLUMN_NP1");
 #else
@@ -3345,7 +3356,8 @@ static void launch_column_step_b(const ColumnStepArgs* d_args, long long first, 
     if constexpr (BUDGET) {
         if (pairs && (first & 3) == 0 && count >= 4) {
             const long long quad = count & ~3LL;
-            hipLaunchKernelGGL((column_step_kernel<4, true>), dim3(sweep_blocks(quad / 4)), dim3(256), 0, s, d_args, first, quad);
+            if (kfold) hipLaunchKernelGGL((column_step_kernel<4, true, true>), dim3(sweep_blocks(quad / 4)), dim3(256), 0, s, d_args, first, quad);
+            else hipLaunchKernelGGL((column_step_kernel<4, true>), dim3(sweep_blocks(quad / 4)), dim3(256), 0, s, d_args, first, quad);
             if (count & 3) hipLaunchKernelGGL((column_step_kernel<1, true>), dim3(1), dim3(64), 0, s, d_args, first + quad, count & 3);
             return;
         }

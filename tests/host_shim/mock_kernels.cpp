@@ -224,7 +224,7 @@ void launch_layer_sweep(const SweepArgs& a, hipStream_t) {
 }
 
 // column_step_kernel: reads every term's array over [first, first + count), writes I_out there and the layers' optional arrays
-void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t, int) {
+void launch_column_step(const ColumnStepArgs* d_args, long long first, long long count, hipStream_t, int, int) {
     if (count <= 0) return;
     const ColumnStepArgs& A = *d_args;
     CHECK(A.n_terms >= 0 && A.n_terms <= kMaxColumnIso && A.n_layers >= 0 && A.n_layers <= kMaxLayers && first >= 0 && first + count <= A.n);
