@@ -2976,9 +2976,9 @@ __global__ __launch_bounds__(256, (NP == 4 ? 3 : 1)) void column_step_kernel(con
 #pragma clang fp contract(off)
     // NP grid points per thread (2: 16-byte loads, 4: 32-byte; the host gives these instantiations a first point and a count
     // that are multiples of NP)
-    // terms per batch of loads (two batches in flight).  Four points per thread: 2 - 144 VGPRs, three waves per SIMD, the fold of the
-    // 30-layer column 147-150 us; 3 needs 169 (two waves per SIMD: 172 us; capped at 168 it spills: 161 us)
-    constexpr int NB = NP == 4 ? 2 : 6;     // (KFOLD with 3: 168 VGPRs and 70 spilled)
+    // terms per batch of loads (two batches in flight).  Four points per thread: 2 - the fold over absorption coefficients 128 VGPRs,
+    // four waves per SIMD (135 us for the 30-layer column), the step from cross sections 138 / three
+    constexpr int NB = NP == 4 ? 2 : 6;     // (the fold over absorption coefficients with 3: 158 VGPRs, three waves per SIMD, no faster; 4 spills)
     typedef double vec __attribute__((ext_vector_type(NP)));
     typedef const vec __attribute__((address_space(1)))* GlobalVec;
     const ColumnStepArgs& A = *Ap;
@@ -3018,8 +3018,11 @@ __global__ __launch_bounds__(256, (NP == 4 ? 3 : 1)) void column_step_kernel(con
                            && dnu_last * A.pbkT_max <= 1e-3 && dnu_last >= 0.0;
         const bool fast = BUDGET && NP > 1 && __builtin_amdgcn_ballot_w64(!plain) == 0ull;
         int l = 0;
-        auto term = [&](auto fast_tag, int t, vec v) {
+        // (arr_tag: std::true_type - per-layer arrays may be asked for, looked up per term; false_type - known to be absent: the
+        //  wave-uniform test per point otherwise splits the four points' exponentials into separate basic blocks, round 6)
+        auto term = [&](auto fast_tag, auto arr_tag, int t, vec v) {
             constexpr bool FAST = decltype(fast_tag)::value;
+            constexpr bool ARRAYS = decltype(arr_tag)::value;
             const int f = KFOLD ? (TERM_LAST_MOL | TERM_LAST_LAYER) : A.term_flags[t];
             if (!KFOLD) {
 #pragma unroll
@@ -3040,7 +3043,7 @@ __global__ __launch_bounds__(256, (NP == 4 ? 3 : 1)) void column_step_kernel(con
                 for (int p = 0; p < NP; ++p) {
                     const double kp = KFOLD ? v[p] : kk[p];
                     const double tr = BUDGET ? exp_neg_budget(kp * A.term_depth[t]) : exp(-kp * A.term_depth[t]);
-                    if (layer_arrays) {
+                    if (ARRAYS && layer_arrays) {
                         if (A.abs_coef[l]) A.abs_coef[l][j + p] = kp;
                         if (A.trans[l]) A.trans[l][j + p] = tr;
                     }
@@ -3057,9 +3060,10 @@ __global__ __launch_bounds__(256, (NP == 4 ? 3 : 1)) void column_step_kernel(con
                         B = planck_at(pa_n[p], pb_n[p], A.term_T[t], A.term_rT[t]);
                     }
                     if (FAST) {
-                        // tr I + (1 - tr) B as B + tr (I - B): two instructions instead of four (default arithmetic only; the
-                        // difference is formed first, so I = B stays B and the result is within an ulp of the reference's form)
-                        I[p] = fma(tr, I[p] - B, B);
+                        // tr I + (1 - tr) B with the last product and sum as one fma (three instructions instead of four).
+                        // (B + tr (I - B) would be two, but loses I against B: with I < 1e-16 B behind a layer of optical
+                        // depth ~1e-16 the result tr I + (1 - tr) B ~ I + 1e-16 B would come out as 1e-16 B alone.)
+                        I[p] = fma(tr, I[p], (1.0 - tr) * B);
                     } else {
                         const double transmitted = tr * I[p];
                         const double emitted = (1.0 - tr) * B;
@@ -3067,7 +3071,7 @@ __global__ __launch_bounds__(256, (NP == 4 ? 3 : 1)) void column_step_kernel(con
                     }
                     kk[p] = 0.0;
                 }
-                if (layer_arrays) ++l;
+                if (ARRAYS && layer_arrays) ++l;
             }
         };
         // two batches of NB loads in flight: the next batch is requested before the current one is consumed
@@ -3078,21 +3082,22 @@ __global__ __launch_bounds__(256, (NP == 4 ? 3 : 1)) void column_step_kernel(con
 #pragma unroll
             for (int u = 0; u < NB; ++u) cur[u] = LBL_ABLATE(A, 32) ? (vec)(1e-22 * (double)(j & 7)) : load(A.xsec[u], j);
         }
-        auto walk = [&](auto fast_tag) {
+        auto walk = [&](auto fast_tag, auto arr_tag) {
             for (int t0 = 0; t0 < n_full; t0 += NB) {
                 if (t0 + NB < n_full) {
 #pragma unroll
                     for (int u = 0; u < NB; ++u) nxt[u] = LBL_ABLATE(A, 32) ? (vec)(1e-22 * (double)(j & 7)) : load(A.xsec[t0 + NB + u], j);
                 }
 #pragma unroll
-                for (int u = 0; u < NB; ++u) term(fast_tag, t0 + u, cur[u]);
+                for (int u = 0; u < NB; ++u) term(fast_tag, arr_tag, t0 + u, cur[u]);
 #pragma unroll
                 for (int u = 0; u < NB; ++u) cur[u] = nxt[u];
             }
-            for (int t = n_full; t < n_terms; ++t) term(fast_tag, t, load(A.xsec[t], j));
+            for (int t = n_full; t < n_terms; ++t) term(fast_tag, arr_tag, t, load(A.xsec[t], j));
         };
-        if (BUDGET && NP > 1 && fast) walk(std::true_type{});
-        else walk(std::false_type{});
+        if (BUDGET && NP > 1 && fast && !layer_arrays) walk(std::true_type{}, std::false_type{});
+        else if (BUDGET && NP > 1 && fast) walk(std::true_type{}, std::true_type{});
+        else walk(std::false_type{}, std::true_type{});
 #pragma unroll
         for (int p = 0; p < NP; ++p) A.I_out[j + p] = I[p];
     }

@@ -385,6 +385,37 @@ def test_sweeps_propagate_nan_in_both_arithmetics(ctx):
         x.free()
 
 
+def test_fold_with_faint_incoming_radiance_and_nearly_transparent_layers(ctx):
+    """Layer.transmission (cls:784-787), T I + (1 - T) B, at its extremes: incoming radiances from 1e-20 B to B behind layers
+    of optical depth 1e-12 .. 1, through the fold's four-points-per-thread path, against the expression in extended
+    precision.  What double precision allows here is set by T itself: exp(-tau) rounds with up to half an ulp of 1, which
+    the factor (I - B) carries into the result - the bound below - and nothing beyond that may be lost (the kernel forms
+    T I + ((1 - T) B) with one fma; B + T (I - B) would be cheaper and, as it happens, no worse than this bound)."""
+    n = 4096
+    rng = np.random.default_rng(5)
+    nu = np.linspace(500.0, 800.0, n)
+    h, c, kB = 6.62607004e-34, 299792458.0, 1.38064852e-23
+    T = 250.0
+    nul = nu.astype(np.longdouble)
+    Bl = 2e8 * h * c * c * nul ** 3 / (np.exp(100 * h * c * nul / kB / T) - 1)
+    tau = 10.0 ** rng.uniform(-12, 0, n)
+    I_in = np.asarray(Bl, float) * 10.0 ** rng.uniform(-20, 0, n)
+    depth = 1000.0
+    k = tau / depth
+    kb, ib, out = ctx.buffer(n).upload(k), ctx.buffer(n).upload(I_in), ctx.buffer(n)
+    try:
+        ctx.column_fold_dev([kb], [T], [depth], 500.0, 800.0, n, out, I_in=ib)
+        got = out.download(n)
+        tr = np.exp(-(k.astype(np.longdouble) * depth))
+        want = tr * I_in.astype(np.longdouble) + (1 - tr) * Bl
+        err = np.asarray(np.abs(got.astype(np.longdouble) - want) / want, float)
+        bound = 1e-14 + 2.5e-16 * np.asarray(np.abs(I_in.astype(np.longdouble) - Bl) / want, float)
+        assert np.all(np.isfinite(got)) and np.all(err <= bound), (float(np.max(err / bound)), int(np.argmax(err / bound)))
+    finally:
+        for x in (kb, ib, out):
+            x.free()
+
+
 def test_production_library_has_no_ablation_option(ctx):
     from pyrad_amd import _native as nat
     with pytest.raises(nat.LblError) as e:
