@@ -159,9 +159,12 @@ int lbl_device_info(lbl_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  *                            skewed-range kernel and deal its records (dense, merged line lists: a chunk of records
  *                            then covers the span again)
  *   "accum_gauss_run"        far-field kernel, production shape (4 points per lane, unsplit spans): points a lane walks per Gaussian
- *                            run.  16: two exp per 16 points, 128 VGPRs, four waves per SIMD | 32: two exp per 32 points, 164
- *                            VGPRs, three waves per SIMD (the 100-2500 cm^-1 cell: -4 %; a launch that fits one round of the
- *                            chip's wave slots: +4 %) | 0 (default): 32 for launches of more than 16 waves per CU, else 16
+ *                            run.  16: two exp per 16 points, 128 VGPRs, four waves per SIMD | 32: two exp per 32 points, 164-166
+ *                            VGPRs, three waves per SIMD; in exact mode also the build whose far-field series starts at 3
+ *                            half-spans instead of 4 (38 terms) | 0 (default): budget mode - 32 for launches of more than 16 waves
+ *                            per SIMD, else 16; exact mode - 32 except for launches of 12-16 waves per SIMD (one round of the
+ *                            chip's wave slots at four per SIMD, two at three).  Results of the two builds agree to ~1e-15
+ *                            (different summation orders), each is reproducible bit for bit.
  *   "accum_far_min_window"   windows below this many points take the skewed-range kernel even where the far-field
  *                            kernel could run them (0, the default: its own limit, 640; measured flat up to 1000)
  *   "debug_ablate"           ONLY in diagnostic builds of the library (make EXTRA=-DLBL_DIAG): timing experiments,
