@@ -9,6 +9,9 @@ from pyrad_amd import _native as nat, engine, synthetic
 
 ctx = nat.Context(0)
 first, count = int(sys.argv[1]), int(sys.argv[2])
+# third argument "mid": every cell through the production shape (4 points per lane, unsplit spans) with the 32-point Gaussian
+# runs forced - in exact mode the build whose series starts at 3 half-spans (round 6); dense line lists (up to 60,000 lines)
+MID = len(sys.argv) > 3 and sys.argv[3] == "mid"
 worst, top = 0.0, []
 for seed in range(first, first + count):
     rng = np.random.default_rng(7000 + seed)
@@ -18,7 +21,7 @@ for seed in range(first, first + count):
     rmin = float(rng.choice([40.0, 650.0, 2300.0]))
     rmax = rmin + float(rng.uniform(8.0, 120.0))
     g = engine.layer_grid(P, rmin, rmax, base, False)
-    n_lines = int(rng.integers(1, 6000))
+    n_lines = int(rng.integers(1, 60000 if MID else 6000))
     lines = synthetic.make_lines(8000 + seed, n_lines, g["eff_min"], g["eff_max"], decimals=7)
     lines["sw"] = 10.0 ** rng.uniform(-30.0, -18.0, n_lines)
     if rng.integers(0, 3) == 0:
@@ -32,6 +35,9 @@ for seed in range(first, first + count):
     ctx.set_option("accum_variant", 3); ctx.set_option("accum_points_per_lane", 0); ctx.set_option("accum_line_split", 0)
     direct, c3 = ctx.xsec_accumulate(sel, iso, G)
     R = [0, 0, 1, 2, 4, 8][int(rng.integers(0, 6))]; LS = [0, 0, 1, 2, 4, 8][int(rng.integers(0, 6))]
+    if MID:
+        R, LS = 4, 1
+    ctx.set_option("accum_gauss_run", 32 if MID else 0)
     ctx.set_option("accum_variant", 5); ctx.set_option("accum_points_per_lane", R); ctx.set_option("accum_line_split", LS)
     series, c5 = ctx.xsec_accumulate(sel, iso, G)
     assert tuple(c3) == tuple(c5) and np.all(np.isfinite(series))
