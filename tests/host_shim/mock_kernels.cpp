@@ -135,7 +135,7 @@ void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, 
         if (J.n_lines > 0) g_sink = J.cidx[J.n_lines - 1];
         for (int q = 0; q < ns; ++q) {
             int32_t* row = tabs + (size_t)(spans + q) * 8;
-            row[0] = 0; row[1] = 0; row[2] = J.n_lines; row[3] = J.n_lines; row[4] = 0; row[5] = J.n_lines; row[6] = row[7] = 0;
+            row[0] = 0; row[1] = 0; row[2] = J.n_lines; row[3] = J.n_lines; row[4] = 0; row[5] = J.n_lines; row[6] = 0; row[7] = J.n_lines;
         }
         for (int t = 0; t < nt; ++t) worklist[tiles + t] = int2{j, t};
         spans += ns; tiles += nt;
@@ -166,6 +166,8 @@ static void accumulate_common(const AccumJob* d_jobs, int n_jobs, int max_tiles,
             for (long long q = 0; q < ns; ++q) {
                 const int32_t* row = J.span_tab + (size_t)q * 8;
                 CHECK(row[0] >= 0 && row[0] <= row[1] && row[1] <= row[2] && row[2] <= row[3] && row[3] <= J.n_lines);
+                // interior lines: far-left | Lorentz term from the series, Gaussian part in the near walk | near | ... | far-right
+                CHECK(row[1] <= row[4] && row[4] <= row[6] && row[6] <= row[7] && row[7] <= row[5] && row[5] <= row[2]);
             }
         }
         for (long long p = J.p_begin; p < J.p_end; ++p) {
