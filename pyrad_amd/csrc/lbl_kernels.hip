@@ -2369,15 +2369,93 @@ __device__ __forceinline__ int sched_chunk_of(const unsigned long long* __restri
 // Launches of several rounds: XCD-partitioned longest-first.  Workgroup i of the accumulate launch runs on XCD i mod 8
 // and every XCD has its own L2: the positional tile sequence is cut into `chunks` (8 x 32) pieces of equal cost,
 // piece c goes to part c mod 8, every part is sorted longest-first and the parts are interleaved - XCD x reads the
-// records of part x only.  One workgroup per part; cap = capacity of the dynamic LDS in keys (a power of two).
+// records of part x only.
 // Parts hold different numbers of items: up to the smallest part the interleave is strict (rank r of part x at slot
 // 8 r + x); what the longer parts have left follows round by round over the parts that still have items (their
 // cheapest tiles; the XCD alignment of that tail does not matter).
+// Round 6: two kernels.  sched_parts_kernel (one workgroup per part) writes the part's keys, in positional order, to global
+// scratch; sched_rank_xcd_kernel (one thread per key, the whole chip) counts the keys of the part that sort before its own -
+// keys are unique (they end in the position), so that count IS the key's place in the sorted part - and writes its item
+// straight to the dispatch list.  n^2 / 2 compares per part instead of n log^2 n / 4 compare-exchanges, but spread over 256 CUs
+// instead of 8 and without a barrier: the 79,696 tiles of a re-windowed column's narrow layers took the bitonic sort in LDS
+// (one workgroup per part, 16,384 keys, 105 passes) 0.36 ms.  Same order as the sort (and as std::stable_sort on the host).
+__global__ __launch_bounds__(1024) void sched_parts_kernel(const unsigned long long* __restrict__ prefix,
+                                                           const unsigned int* __restrict__ tile_cost, int N, int chunks,
+                                                           unsigned long long* __restrict__ g_keys, int g_stride,
+                                                           int* __restrict__ part_count) {
+    __shared__ int s_start[8 * 64 + 1];               // first item of every chunk (chunks <= 512)
+    const int x = blockIdx.x;
+    const double share = (double)prefix[N] / (double)chunks + 1e-9;
+    for (int c = threadIdx.x; c <= chunks; c += blockDim.x) {
+        // first i in [0, N] whose chunk is >= c (chunk numbers do not decrease with i)
+        int lo = 0, hi = N;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sched_chunk_of(prefix, mid, share, chunks) < c) lo = mid + 1; else hi = mid;
+        }
+        s_start[c] = (c == chunks) ? N : lo;
+    }
+    __syncthreads();
+    unsigned long long* keys = g_keys + (size_t)x * (size_t)g_stride;
+    int off = 0;
+    for (int c = x; c < chunks; c += 8) {
+        const int a = s_start[c], b = s_start[c + 1];
+        for (int i = a + (int)threadIdx.x; i < b; i += blockDim.x) keys[off + (i - a)] = sched_key(tile_cost[i], i);
+        off += b - a;
+    }
+    if (threadIdx.x == 0) part_count[x] = off;
+}
+
+__global__ __launch_bounds__(256) void sched_rank_xcd_kernel(const unsigned long long* __restrict__ g_keys, int g_stride,
+                                                             const int* __restrict__ part_count, const int2* __restrict__ items,
+                                                             int2* __restrict__ worklist, int max_part) {
+    constexpr int TILE = 1024;
+    __shared__ unsigned long long s_tile[TILE];
+    const int x = blockIdx.y;
+    const int n_x = part_count[x];
+    if (n_x > max_part || (int)blockIdx.x * 256 >= n_x) return;     // (whole workgroup: no barrier is left behind; larger parts: the sort below)
+    const unsigned long long* keys = g_keys + (size_t)x * (size_t)g_stride;
+    const int r_in = blockIdx.x * 256 + threadIdx.x;
+    const bool mine = r_in < n_x;
+    const unsigned long long key = mine ? keys[r_in] : ~0ull;
+    int rank = 0;
+    for (int t0 = 0; t0 < n_x; t0 += TILE) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < TILE; i += 256) s_tile[i] = t0 + i < n_x ? keys[t0 + i] : ~0ull;     // (padding never sorts before a key)
+        __syncthreads();
+#pragma unroll 8
+        for (int i = 0; i < TILE; ++i) rank += s_tile[i] < key ? 1 : 0;
+    }
+    if (!mine) return;
+    int cnt[8], m = part_count[0];
+#pragma unroll
+    for (int y = 0; y < 8; ++y) { cnt[y] = part_count[y]; m = min(m, cnt[y]); }
+    const int r = rank;
+    const int src = (int)(unsigned int)(key & 0xFFFFFFFFull);
+    long long pos;
+    if (r < m) {
+        pos = 8LL * r + x;
+    } else {
+        pos = 8LL * m;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            pos += max(0, min(cnt[y], r) - m);                     // full rounds m .. r-1
+            if (y < x && cnt[y] > r) pos += 1;                      // parts ahead of x in round r
+        }
+    }
+    worklist[pos] = items[src];
+}
+
+// Parts of more than kRankPartMax items (one part can hold most of a group's cheap tiles when a few tiles carry most of the
+// cost; the build covers up to 2^20 tiles) are not ranked - quadratic - but sorted: one workgroup per such part, bitonic, in the
+// dynamic LDS (cap keys, a power of two) or, beyond that, in the part's global scratch.  min_part: parts up to this size are
+// left to the rank kernel (the two kernels write disjoint positions of the dispatch list).
+constexpr int kRankPartMax = 32768;
 __global__ __launch_bounds__(1024) void sched_order_xcd_kernel(const unsigned long long* __restrict__ prefix,
                                                                const unsigned int* __restrict__ tile_cost,
                                                                const int2* __restrict__ items, int N, int chunks, int cap,
                                                                unsigned long long* __restrict__ g_keys, int g_stride,
-                                                               int2* __restrict__ worklist) {
+                                                               int2* __restrict__ worklist, int min_part) {
     extern __shared__ unsigned long long s_keys_lds[];
     __shared__ int s_start[8 * 64 + 1];               // first item of every chunk (chunks <= 512)
     __shared__ int s_count[8];
@@ -2400,6 +2478,7 @@ __global__ __launch_bounds__(1024) void sched_order_xcd_kernel(const unsigned lo
     }
     __syncthreads();
     const int n_x = s_count[x];
+    if (n_x <= min_part) return;                      // (whole workgroup; the rank kernel places this part's items)
     int size = 1;
     while (size < n_x) size <<= 1;
     // a part that does not fit the LDS (one part can hold most of a group's cheap tiles when a few tiles carry most of
@@ -2785,19 +2864,24 @@ void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, 
         return;
     }
     hipLaunchKernelGGL(scan_counts_kernel, dim3(scan_blocks(total_tiles)), dim3(1024), 0, s, tile_cost, total_tiles, prefix);
-    // 128 KB of dynamic LDS for the per-XCD sort (gfx950 has 160 KB per CU).  The attribute belongs to the (kernel, device)
-    // pair and this runs once per new window, so it is simply set on every call, for the device the caller has made current
-    // (lbl_api.hip: hipSetDevice(ctx->device)) - a process-wide "already set" flag missed a second device and raced between
-    // host threads (advisor, round 4).  Where it is refused the sort takes 32 KB, which needs no attribute: parts that do
-    // not fit go through global scratch, slower, same result.
-    int cap = 16384;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sched_order_xcd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            cap * (int)sizeof(unsigned long long)) != hipSuccess) {
-        (void)hipGetLastError();
-        cap = 4096;
+    // the parts' keys to global scratch, then one thread per key ranks it inside its part (see sched_rank_xcd_kernel)
+    const int chunks = 8 * (xcd_chunks > 0 && xcd_chunks <= 64 ? xcd_chunks : 32);
+    const int stride = sched_key_stride(total_tiles);
+    int* part_count = reinterpret_cast<int*>(g_keys + (size_t)8 * (size_t)stride);         // (the scratch block's last 256 bytes)
+    hipLaunchKernelGGL(sched_parts_kernel, dim3(8), dim3(1024), 0, s, prefix, tile_cost, total_tiles, chunks, g_keys, stride, part_count);
+    const int rank_blocks = (std::min(total_tiles, kRankPartMax) + 255) / 256;
+    hipLaunchKernelGGL(sched_rank_xcd_kernel, dim3(rank_blocks, 8), dim3(256), 0, s, g_keys, stride, part_count, items, worklist, kRankPartMax);
+    if (total_tiles > kRankPartMax) {
+        // (a part of that size sorts in its own slice of the key scratch, which the rank kernel does not read for such a part)
+        int cap = 16384;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(sched_order_xcd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                cap * (int)sizeof(unsigned long long)) != hipSuccess) {
+            (void)hipGetLastError();
+            cap = 4096;
+        }
+        hipLaunchKernelGGL(sched_order_xcd_kernel, dim3(8), dim3(1024), cap * sizeof(unsigned long long), s, prefix, tile_cost, items,
+                           total_tiles, chunks, cap, g_keys, stride, worklist, kRankPartMax);
     }
-    hipLaunchKernelGGL(sched_order_xcd_kernel, dim3(8), dim3(1024), cap * sizeof(unsigned long long), s, prefix, tile_cost, items,
-                       total_tiles, 8 * (xcd_chunks > 0 && xcd_chunks <= 64 ? xcd_chunks : 32), cap, g_keys, sched_key_stride(total_tiles), worklist);
 }
 
 // ----------------------------------------------------------------------------------------
