@@ -436,23 +436,55 @@ __global__ __launch_bounds__(256) void centre_index_kernel(const MergeList* __re
 
 __global__ __launch_bounds__(256) void merge_rank_kernel(const MergeList* __restrict__ lists) {
     const MergeList& M = lists[blockIdx.y];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M.n_lines) return;
-    const long long c = M.tmp_cidx[i];
-    int pos = i;
-    for (int b = M.job_first; b < M.job_first + M.job_count; ++b) {
-        if (b == (int)blockIdx.y) continue;
-        const MergeList& O = lists[b];
-        // lists ahead of this one win ties (count their lines with c_b <= c), lists behind lose them (c_b < c)
-        int lo = 0, hi = O.n_lines;
-        const long long target = b < (int)blockIdx.y ? c + 1 : c;
+    const int i0 = blockIdx.x * blockDim.x;
+    if (i0 >= M.n_lines) return;                                  // (whole workgroup)
+    const int i = i0 + threadIdx.x;
+    const int me = (int)blockIdx.y;
+    // lists ahead of this one win ties (count their lines with c_b <= c), lists behind lose them (c_b < c).
+    // Round 6: the workgroup's 256 lines are consecutive in a sorted list, so their places in another list lie between the
+    // places of its first and of its last line.  Those two are found by two THREADS per other list, side by side (one search
+    // deep, not two); the window between them - a few hundred entries - is staged in LDS with coalesced loads and searched
+    // there.  Before: 34 scattered loads per line and other list, 400 M for a column, at the rate the L2 serves them (0.26 ms).
+    constexpr int WIN = 2048;
+    __shared__ int s_lo[kMaxIso], s_hi[kMaxIso];
+    __shared__ int32_t s_win[WIN];
+    auto search = [&](const int32_t* __restrict__ a, long long target, int lo, int hi) {
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if ((long long)O.tmp_cidx[mid] < target) lo = mid + 1; else hi = mid;
+            if ((long long)a[mid] < target) lo = mid + 1; else hi = mid;
         }
-        pos += lo;
+        return lo;
+    };
+    {
+        const int u = (int)threadIdx.x & 63, which = (int)threadIdx.x >> 6;          // which 0: the first line's place, 1: the last line's
+        const int b = M.job_first + u;
+        if (which < 2 && u < M.job_count && b != me) {
+            const MergeList& O = lists[b];
+            const int i1 = min(i0 + (int)blockDim.x, M.n_lines) - 1;
+            const long long tie = b < me ? 1 : 0;
+            const int r = search(O.tmp_cidx, (long long)M.tmp_cidx[which ? i1 : i0] + tie, 0, O.n_lines);
+            if (which) s_hi[u] = r; else s_lo[u] = r;
+        }
     }
-    M.src_of_job[pos] = (int32_t)(((unsigned int)((int)blockIdx.y - M.job_first) << 26) | (unsigned int)i);
+    __syncthreads();
+    const bool mine = i < M.n_lines;
+    const long long c = mine ? (long long)M.tmp_cidx[i] : 0;
+    int pos = i;
+    for (int b = M.job_first; b < M.job_first + M.job_count; ++b) {
+        if (b == me) continue;
+        const MergeList& O = lists[b];
+        const int lo = s_lo[b - M.job_first], hi = s_hi[b - M.job_first];          // (uniform over the workgroup)
+        const long long target = b < me ? c + 1 : c;
+        if (hi - lo <= WIN) {
+            __syncthreads();
+            for (int k = threadIdx.x; k < hi - lo; k += blockDim.x) s_win[k] = O.tmp_cidx[lo + k];
+            __syncthreads();
+            if (mine) pos += lo + search(s_win, target, 0, hi - lo);
+        } else if (mine) {
+            pos += search(O.tmp_cidx, target, lo, hi);
+        }
+    }
+    if (mine) M.src_of_job[pos] = (int32_t)(((unsigned int)(me - M.job_first) << 26) | (unsigned int)i);
 }
 
 void launch_merge_ranks(const MergeList* d_lists, int n_lists, int max_lines, hipStream_t s) {
@@ -2373,12 +2405,13 @@ __device__ __forceinline__ int sched_chunk_of(const unsigned long long* __restri
 // Parts hold different numbers of items: up to the smallest part the interleave is strict (rank r of part x at slot
 // 8 r + x); what the longer parts have left follows round by round over the parts that still have items (their
 // cheapest tiles; the XCD alignment of that tail does not matter).
-// Round 6: two kernels.  sched_parts_kernel (one workgroup per part) writes the part's keys, in positional order, to global
-// scratch; sched_rank_xcd_kernel (one thread per key, the whole chip) counts the keys of the part that sort before its own -
-// keys are unique (they end in the position), so that count IS the key's place in the sorted part - and writes its item
-// straight to the dispatch list.  n^2 / 2 compares per part instead of n log^2 n / 4 compare-exchanges, but spread over 256 CUs
-// instead of 8 and without a barrier: the 79,696 tiles of a re-windowed column's narrow layers took the bitonic sort in LDS
-// (one workgroup per part, 16,384 keys, 105 passes) 0.36 ms.  Same order as the sort (and as std::stable_sort on the host).
+// Round 6: three kernels over the whole chip instead of one workgroup per part.  (1) sched_parts_kernel writes every part's keys,
+// in positional order, to global scratch; (2) sched_tile_sort_kernel sorts every tile of 1,024 keys by itself; (3)
+// sched_rank_xcd_kernel, one thread per key, adds up how many keys of the part's OTHER tiles sort before its own (a binary search
+// per tile) - keys are unique (they end in the position), so own place + those counts IS the key's place in the sorted part -
+// and writes its item straight to the dispatch list.  The 79,696 tiles of a re-windowed column's narrow layers took the bitonic
+// sort in LDS (one workgroup per part, 16,384 keys, 105 passes) 0.36 ms.  Same order as that sort (and as std::stable_sort on
+// the host).
 __global__ __launch_bounds__(1024) void sched_parts_kernel(const unsigned long long* __restrict__ prefix,
                                                            const unsigned int* __restrict__ tile_cost, int N, int chunks,
                                                            unsigned long long* __restrict__ g_keys, int g_stride,
@@ -2406,27 +2439,47 @@ __global__ __launch_bounds__(1024) void sched_parts_kernel(const unsigned long l
     if (threadIdx.x == 0) part_count[x] = off;
 }
 
-__global__ __launch_bounds__(256) void sched_rank_xcd_kernel(const unsigned long long* __restrict__ g_keys, int g_stride,
-                                                             const int* __restrict__ part_count, const int2* __restrict__ items,
-                                                             int2* __restrict__ worklist, int max_part) {
-    constexpr int TILE = 1024;
-    __shared__ unsigned long long s_tile[TILE];
+// (2) every tile of 1,024 keys of a part sorted by itself (bitonic, in LDS; the last tile padded with keys that sort last)
+__global__ __launch_bounds__(256) void sched_tile_sort_kernel(unsigned long long* __restrict__ g_keys, int g_stride,
+                                                              const int* __restrict__ part_count, int max_part) {
+    __shared__ unsigned long long s_keys[1024];
     const int x = blockIdx.y;
     const int n_x = part_count[x];
-    if (n_x > max_part || (int)blockIdx.x * 256 >= n_x) return;     // (whole workgroup: no barrier is left behind; larger parts: the sort below)
+    const int t0 = blockIdx.x * 1024;
+    if (n_x > max_part || t0 >= n_x) return;                  // (whole workgroup)
+    unsigned long long* keys = g_keys + (size_t)x * (size_t)g_stride + t0;
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_keys[i] = t0 + i < n_x ? keys[i] : ~0ull;
+    bitonic_sort_lds(s_keys, 1024);
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) keys[i] = s_keys[i];
+}
+
+// (3) one thread per key: its place in its own sorted tile + the number of smaller keys in every other tile of the part (a
+// binary search in the tile staged in LDS) is its place in the sorted part; the item goes straight to the dispatch list.
+__global__ __launch_bounds__(1024) void sched_rank_xcd_kernel(const unsigned long long* __restrict__ g_keys, int g_stride,
+                                                              const int* __restrict__ part_count, const int2* __restrict__ items,
+                                                              int2* __restrict__ worklist, int max_part) {
+    __shared__ unsigned long long s_tile[1024];
+    const int x = blockIdx.y;
+    const int n_x = part_count[x];
+    const int t_mine = blockIdx.x;
+    if (n_x > max_part || t_mine * 1024 >= n_x) return;         // (whole workgroup: no barrier is left behind; larger parts: the sort below)
     const unsigned long long* keys = g_keys + (size_t)x * (size_t)g_stride;
-    const int r_in = blockIdx.x * 256 + threadIdx.x;
-    const bool mine = r_in < n_x;
-    const unsigned long long key = mine ? keys[r_in] : ~0ull;
-    int rank = 0;
-    for (int t0 = 0; t0 < n_x; t0 += TILE) {
+    const unsigned long long key = keys[t_mine * 1024 + threadIdx.x];           // (padding: ~0, sorted behind the tile's keys)
+    int rank = threadIdx.x;
+    const int n_tiles = (n_x + 1023) / 1024;
+    for (int t = 0; t < n_tiles; ++t) {
+        if (t == t_mine) continue;                            // (uniform over the workgroup)
         __syncthreads();
-        for (int i = threadIdx.x; i < TILE; i += 256) s_tile[i] = t0 + i < n_x ? keys[t0 + i] : ~0ull;     // (padding never sorts before a key)
+        s_tile[threadIdx.x] = keys[t * 1024 + threadIdx.x];
         __syncthreads();
-#pragma unroll 8
-        for (int i = 0; i < TILE; ++i) rank += s_tile[i] < key ? 1 : 0;
+        int lo = 0, hi = 1024;                                // first index whose key is not below mine (keys are unique): 0 .. 1024
+        while (lo < hi) {                                     // (11 steps at most)
+            const int mid = (lo + hi) >> 1;
+            if (s_tile[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
     }
-    if (!mine) return;
+    if (key == ~0ull) return;
     int cnt[8], m = part_count[0];
 #pragma unroll
     for (int y = 0; y < 8; ++y) { cnt[y] = part_count[y]; m = min(m, cnt[y]); }
@@ -2869,8 +2922,9 @@ void launch_schedule_build(const SchedJob* d_jobs, int n_jobs, int total_spans, 
     const int stride = sched_key_stride(total_tiles);
     int* part_count = reinterpret_cast<int*>(g_keys + (size_t)8 * (size_t)stride);         // (the scratch block's last 256 bytes)
     hipLaunchKernelGGL(sched_parts_kernel, dim3(8), dim3(1024), 0, s, prefix, tile_cost, total_tiles, chunks, g_keys, stride, part_count);
-    const int rank_blocks = (std::min(total_tiles, kRankPartMax) + 255) / 256;
-    hipLaunchKernelGGL(sched_rank_xcd_kernel, dim3(rank_blocks, 8), dim3(256), 0, s, g_keys, stride, part_count, items, worklist, kRankPartMax);
+    const int part_tiles = (std::min(total_tiles, kRankPartMax) + 1023) / 1024;
+    hipLaunchKernelGGL(sched_tile_sort_kernel, dim3(part_tiles, 8), dim3(256), 0, s, g_keys, stride, part_count, kRankPartMax);
+    hipLaunchKernelGGL(sched_rank_xcd_kernel, dim3(part_tiles, 8), dim3(1024), 0, s, g_keys, stride, part_count, items, worklist, kRankPartMax);
     if (total_tiles > kRankPartMax) {
         // (a part of that size sorts in its own slice of the key scratch, which the rank kernel does not read for such a part)
         int cap = 16384;
