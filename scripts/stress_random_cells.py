@@ -4,7 +4,7 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from conftest import rel_err
+from conftest import rel_err, point_tolerance, rel_err_points
 from pyrad_amd import _native as nat, engine, synthetic
 from oracle import pyrad_oracle as orc
 
@@ -46,8 +46,13 @@ for seed in range(first, first + count):
         fails.append((seed, str(ex)[:80])); continue
     worst = max(worst, e)
     top.append((e, seed, g['W'], g['resolution'], round(P, 2), n_lines, R, LS, species))
-    if e > 1e-11:
-        fails.append((seed, e, g["W"], R, LS))
+    # the suite's per-point bound (conftest.point_tolerance: 2e-12 + the nu -> 0 amplification of the reference's own
+    # cancellation in 1 - exp(-c2 nu / T); cells that start at 0 cm^-1 exceed any flat figure)
+    tol = point_tolerance(orc.x_axis(rmin, rmax, base), T, g["dfc"])
+    floor = float(np.max(np.abs(ref))) * 1e-250 if ref.size else 0.0
+    ep = rel_err_points(xs, ref, floor)
+    if ref.size and not np.all(ep <= tol):
+        fails.append((seed, float(np.max(ep / tol)), g["W"], R, LS))
 print("seeds %d..%d worst rel err %.3e fails %s" % (first, first + count - 1, worst, fails))
 for t in sorted(top, reverse=True)[:8]:
     print("  err %.2e seed %d W %d res %g P %s lines %d R %d LS %d %s" % t)
